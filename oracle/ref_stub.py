@@ -1,0 +1,78 @@
+"""TEST INFRASTRUCTURE ONLY (oracle/): import the *unmodified* reference from /root/reference.
+
+The reference package (`naturalspeech2_pytorch/__init__.py:8-24`,
+`naturalspeech2_pytorch.py:17-40`) imports torchaudio, audiolm_pytorch, beartype, ema_pytorch,
+pyworld, inflect, num2words, ... none of which are installed here and none of which are touched
+by the arithmetic of `Model` / `NaturalSpeech2.ddim_sample`.  We pre-populate `sys.modules`
+with inert stand-ins and then execute the reference's own source files unchanged.
+
+Only usable in the build container (where /root/reference exists).  Used by
+`tests/golden/make_golden.py` (fixture generation) and by the CPU-side tests that pin
+`oracle/ns2_oracle.py` against the real reference.  Never imported by the product package.
+"""
+import importlib
+import os
+import sys
+import types
+import typing
+
+REFERENCE_ROOT = os.environ.get("NS2_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "naturalspeech2_pytorch"))
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _install_stubs():
+    import torch
+    from torch import nn
+
+    class _Dummy(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    if "torchaudio" not in sys.modules:
+        ta = _mod("torchaudio")
+        ta.transforms = _mod("torchaudio.transforms", Spectrogram=_Dummy, MelScale=_Dummy, Resample=_Dummy)
+        ta.functional = _mod("torchaudio.functional")
+    if "audiolm_pytorch" not in sys.modules:
+        al = _mod("audiolm_pytorch", SoundStream=type("SoundStream", (_Dummy,), {}),
+                  EncodecWrapper=type("EncodecWrapper", (_Dummy,), {}))
+        al.data = _mod("audiolm_pytorch.data", SoundDataset=object, get_dataloader=lambda *a, **k: None)
+    if "beartype" not in sys.modules:
+        bt = _mod("beartype", beartype=lambda f: f)
+        bt.typing = _mod("beartype.typing", **{k: getattr(typing, k) for k in
+                                               ("Tuple", "Union", "Optional", "List", "Dict", "Callable", "Any")})
+        bt.door = _mod("beartype.door", is_bearable=lambda obj, hint: True)
+    if "ema_pytorch" not in sys.modules:
+        _mod("ema_pytorch", EMA=_Dummy)
+    for name in ("pyworld", "inflect", "num2words", "num_to_words"):
+        if name not in sys.modules:
+            m = _mod(name)
+            m.engine = lambda *a, **k: None          # inflect.engine()
+            m.num2words = lambda *a, **k: ""
+            m.num_to_word = lambda *a, **k: ""
+
+
+_cached = None
+
+
+def load_reference():
+    """Returns the reference module `naturalspeech2_pytorch.naturalspeech2_pytorch` (source unmodified)."""
+    global _cached
+    if _cached is not None:
+        return _cached
+    if not reference_available():
+        raise RuntimeError(f"reference not present at {REFERENCE_ROOT}")
+    _install_stubs()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    _cached = importlib.import_module("naturalspeech2_pytorch.naturalspeech2_pytorch")
+    return _cached

@@ -1,0 +1,135 @@
+"""Generate golden fixtures by executing the UNMODIFIED reference (build container only).
+
+    python tests/golden/make_golden.py
+
+Writes tests/golden/*.pt.  Each fixture holds: the constructor kwargs, the reference's state_dict key->shape
+map, the weight/input seeds (tensors are rebuilt with tests/golden/gen.py), and the reference's outputs
+(plus a few intermediate taps recorded with forward hooks on the reference modules).
+RVQ fixtures come from HF transformers' Encodec RVQ classes (the un-vendored dependency's restatement,
+see oracle/rvq_oracle.py) with seeded random codebooks.
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+from oracle.ref_stub import load_reference          # noqa: E402
+from tests.golden.gen import make_weights, make_input  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+MODEL_CASES = {
+    # name: (ctor kwargs, batch, n, n_prompt, n_cond, cond_scales)
+    "uncond_d64": (dict(dim=64, depth=2), 2, 48, None, None, (1.0,)),
+    "uncond_d128": (dict(dim=128, depth=6), 2, 200, None, None, (1.0,)),
+    "cond_d64_pad": (dict(dim=64, depth=2, dim_prompt=32, condition_on_prompt=True), 2, 48, 13, 40, (1.0, 1.5)),
+    "cond_d64_curtail": (dict(dim=64, depth=2, dim_prompt=64, condition_on_prompt=True, num_latents_m=16), 3, 70, 103, 90, (1.0, 2.0)),
+    "cond_d128": (dict(dim=128, depth=2, dim_prompt=128, condition_on_prompt=True), 2, 160, 50, 160, (1.0, 1.3)),
+}
+
+
+def gen_model_case(ns2, name, spec):
+    kw, b, n, n_p, n_c, scales = spec
+    torch.manual_seed(0)
+    m = ns2.Model(**kw).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = make_weights(shapes, seed=1)
+    m.load_state_dict(sd)
+    dim = kw["dim"]
+    x = make_input("x", (b, n, dim), seed=2)
+    times = make_input("times", (b,), seed=2, uniform=True)
+    prompt = cond = None
+    if kw.get("condition_on_prompt"):
+        prompt = make_input("prompt", (b, n_p, kw["dim_prompt"]), seed=2)
+        cond = make_input("cond", (b, kw["dim_prompt"], n_c), seed=2)
+    taps = {}
+
+    def hook(label):
+        def f(mod, inp, out):
+            taps[label] = (out[0] if isinstance(out, (tuple, list)) else out).detach().clone()
+        return f
+
+    hs = [m.to_time_cond.register_forward_hook(hook("time_cond")),
+          m.wavenet.init_conv.register_forward_hook(hook("wavenet.init")),        # [b, d, n]
+          m.wavenet.stacks[0].blocks[3].register_forward_hook(hook("wavenet.s0.b3")),
+          m.wavenet.register_forward_hook(hook("wavenet.out")),                    # [b, d, n]
+          m.transformer.layers[0][1].register_forward_hook(hook("layer0.attn")),
+          m.transformer.layers[0][5].register_forward_hook(hook("layer0.ff"))]
+    if kw.get("condition_on_prompt"):
+        hs.append(m.perceiver_resampler.register_forward_hook(hook("resampler")))
+        hs.append(m.transformer.layers[0][3].register_forward_hook(hook("layer0.xattn")))
+    outs = {}
+    with torch.no_grad():
+        kws = dict(prompt=prompt, cond=cond) if prompt is not None else {}
+        outs["cond_scale_1.0"] = m.forward_with_cond_scale(x, times, cond_scale=1.0, **kws)
+        first_taps = {k: v for k, v in taps.items()}
+        for h in hs:
+            h.remove()
+        for cs in scales:
+            if cs != 1.0:
+                outs[f"cond_scale_{cs}"] = m.forward_with_cond_scale(x, times, cond_scale=cs, **kws)
+    fix = dict(kind="model", kwargs=kw, shapes=shapes, weight_seed=1, input_seed=2, batch=b, n=n, n_prompt=n_p,
+               n_cond=n_c, outputs=outs, taps=first_taps, torch_version=torch.__version__)
+    torch.save(fix, os.path.join(OUT, f"model_{name}.pt"))
+    print(name, {k: tuple(v.shape) for k, v in outs.items()}, "taps", list(first_taps))
+    return m, sd
+
+
+def gen_ddim(ns2):
+    kw = dict(dim=64, depth=2)
+    m = ns2.Model(**kw).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(make_weights(shapes, seed=1))
+    steps = 6
+    d = ns2.NaturalSpeech2(model=m, codec=None, target_sample_hz=24000, timesteps=steps)
+    noise = make_input("noise", (2, 40, 64), seed=3)
+    # NS2:1387 draws the initial noise from torch.randn; inject ours
+    orig = torch.randn
+    try:
+        torch.randn = lambda *a, **k: noise.clone()
+        out = d.sample(length=40, batch_size=2)
+    finally:
+        torch.randn = orig
+    # loss path (NS2:1503-1684) on latents with injected times / noise
+    audio = make_input("audio", (2, 40, 64), seed=3)
+    fix = dict(kind="ddim", kwargs=kw, shapes=shapes, weight_seed=1, input_seed=3, timesteps=steps, batch=2, n=40,
+               output=out, torch_version=torch.__version__)
+    torch.save(fix, os.path.join(OUT, "ddim_uncond_d64.pt"))
+    print("ddim", tuple(out.shape), float(out.abs().max()))
+
+
+def gen_rvq():
+    from transformers import EncodecConfig
+    from transformers.models.encodec.modeling_encodec import EncodecResidualVectorQuantizer
+    for name, (m, nq, codes, d) in {"rvq_small": (96, 4, 64, 128), "rvq_full": (300, 8, 1024, 128)}.items():
+        cfg = EncodecConfig(codebook_size=codes, codebook_dim=d)
+        rvq = EncodecResidualVectorQuantizer(cfg)
+        cb = make_input("codebooks", (nq, codes, d), seed=5)
+        for i in range(nq):
+            rvq.layers[i].codebook.embed.copy_(cb[i])
+        x = make_input("latents", (m, d), seed=6) * 3.0
+        emb_in = x.t()[None]                       # HF layout [b, d, n]
+        with torch.no_grad():
+            residual = emb_in
+            idxs = []
+            for layer in rvq.layers[:nq]:          # HFENC:431-436 (num_quantizers from bandwidth; use nq)
+                ind = layer.encode(residual)
+                residual = residual - layer.decode(ind)
+                idxs.append(ind)
+            codes_out = torch.stack(idxs)           # [q, 1, n]
+            quant = rvq.decode(codes_out)           # HFENC:440-447 -> [1, d, n]
+        fix = dict(kind="rvq", m=m, nq=nq, codes=codes, d=d, codebook_seed=5, latent_seed=6, latent_scale=3.0,
+                   indices=codes_out[:, 0].t().contiguous(), emb=quant[0].t().contiguous(),
+                   torch_version=torch.__version__)
+        torch.save(fix, os.path.join(OUT, f"{name}.pt"))
+        print(name, tuple(fix["indices"].shape), tuple(fix["emb"].shape))
+
+
+if __name__ == "__main__":
+    gen_rvq()                     # before the reference stubs shadow torchaudio (transformers probes it)
+    ns2 = load_reference()
+    for name, spec in MODEL_CASES.items():
+        gen_model_case(ns2, name, spec)
+    gen_ddim(ns2)
