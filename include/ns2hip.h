@@ -1,0 +1,140 @@
+/* libns2hip — C ABI of the MI355X-native NaturalSpeech2 denoising hot path.
+ *
+ * The reference (lucidrains/naturalspeech2-pytorch) has no FFI/plugin layer: its boundary for this path is the
+ * Python class surface.  This header is the C-ABI a host binds instead; each entry point cites the
+ * reference interface it replaces (NS2 = naturalspeech2_pytorch/naturalspeech2_pytorch.py, ATT = attend.py,
+ * HFENC = transformers/models/encodec/modeling_encodec.py, the restatement of the un-vendored encodec RVQ).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is named host_*; the caller owns all buffers
+ *     (inputs, outputs, workspaces); the library owns only packed-weight blobs (ns2_weight / ns2_model).
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls are stream-ordered and never
+ *     synchronise the device, except ns2_model_finalize / ns2_weight_pack which are one-time set-up calls.
+ *   - return value 0 = ok; otherwise a negative code, message via ns2_last_error() (thread-local).
+ *   - activations travel between kernels as bf16 "split planes": hi = bf16(x), lo = bf16(x - hi).  precision
+ *     3 = hi*hi+hi*lo+lo*hi on the bf16 MFMA (fp32-class, matches the fp32 reference to <1e-3), 1 = hi only.
+ */
+#ifndef NS2HIP_H
+#define NS2HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NS2_OK 0
+#define NS2_ERR_ARG -1
+#define NS2_ERR_HIP -2
+#define NS2_ERR_STATE -3
+
+const char* ns2_last_error(void);
+int ns2_version(void);
+
+/* ------------------------------------------------------------------ packed weights (library-owned) */
+typedef struct ns2_weight ns2_weight;
+/* nn.Linear weight [rows, cols] (taps = 1) or Conv1d weight [rows, cols, taps] (NS2:583-595) -> K-contiguous bf16
+ * split planes, rows padded to 128, each tap's columns padded to 32.  geglu != 0 packs the rows of
+ * FeedForward's first Linear (NS2:1021) so that GEGLU (NS2:1004-1007) fuses into the GEMM epilogue.
+ * extra1x1 (may be null): a [rows, cols, 1] weight appended as one more, unshifted tap (WavenetResBlock.res_conv). */
+int ns2_weight_pack(const float* w, int rows, int cols, int taps, int geglu, const float* extra1x1, ns2_weight** out,
+                    void* stream);
+void ns2_weight_free(ns2_weight* w);
+
+/* ------------------------------------------------------------------ op-level entry points */
+/* fp32 [M, d] (+ optional per-utterance addend) -> split planes [M, ldo] (zero padded) */
+int ns2_split_f32(const float* x, int ldx, int M, int d, uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream);
+
+/* split planes -> fp32 (hi + lo); lo may be null */
+int ns2_join_f32(const uint16_t* hi, const uint16_t* lo, int ld, float* out, int ldo, int64_t M, int d, void* stream);
+
+/* nn.Linear / CausalConv1d as one GEMM (NS2:1051-1069, 1021-1024, 583-595).
+ * conv_taps = 0 for a Linear, 3 for CausalConv1d(k=3) with `dilation`; seq_len = tokens per utterance.
+ * out = A W^T + bias (+ resid), fp32 */
+int ns2_linear_f32(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
+                   int dilation, int seq_len, const float* bias, const float* resid, int ldr, float* out, int ldo,
+                   int precision, void* stream);
+/* same, output as split planes [M, ldo] */
+int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
+                     int dilation, int seq_len, const float* bias, uint16_t* out_hi, uint16_t* out_lo, int ldo,
+                     int precision, void* stream);
+/* FeedForward first half: GEGLU(Linear(x)) (NS2:1004-1007, 1021); w packed with geglu=1; packed_bias from
+ * ns2_geglu_pack_bias; out planes [M, ldo] with ldo = round_up(f, 32) */
+int ns2_linear_geglu(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M,
+                     const float* packed_bias, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream);
+int ns2_geglu_pack_bias(const float* bias, int f, float* packed, int packed_len, void* stream);
+/* fused q/k/v projection (NS2:1051-1053, 1063): columns < split_col -> planes [M, ldo]; columns >= split_col
+ * (the values) -> transposed planes vt[b][col - split_col][n] with row stride vt_ld (for ns2_attention) */
+int ns2_linear_qkv(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int seq_len,
+                   int split_col, uint16_t* out_hi, uint16_t* out_lo, int ldo, uint16_t* vt_hi, uint16_t* vt_lo,
+                   int vt_ld, int precision, void* stream);
+/* WavenetResBlock (NS2:597-642) in one launch: out = tanh(g)*sigmoid(g) + res_conv(x), g = conv_dil(x)*gamma_t+beta_t.
+ * w packed with taps=3 and extra1x1 = res_conv.weight; film[b] = [gamma(dim) | beta(dim)] = to_time_cond(t) */
+int ns2_wavenet_block(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int seq_len,
+                      int dilation, const float* conv_bias, const float* res_bias, const float* film, int film_ld,
+                      uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream);
+
+/* Attend.forward (ATT:77-155), non-causal, head dim 64: o = softmax(q k^T * scale) v */
+int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi,
+                  const uint16_t* k_lo, int ldk, int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld,
+                  uint16_t* o_hi, uint16_t* o_lo, int ldo, int B, int H, int Nq, int Nk, float scale, int precision,
+                  void* stream);
+
+/* RMSNorm.forward (NS2:727-746).  gamma may be null; cond (may be null) holds [gamma_c | beta_c] per batch row */
+int ns2_rmsnorm(const float* x, int ldx, int M, int d, int seq_len, const float* gamma, const float* cond, int cond_ld,
+                uint16_t* out_hi, uint16_t* out_lo, int ldo, float* out_f32, int ldo_f, void* stream);
+
+/* out[b, j] = act(in[b, :] . wt[:, j] + bias[j]); wt K-major [K, J]; act: 0 none, 1 SiLU (conditioning projections) */
+int ns2_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out, int B, int K,
+                      int J, int act, void* stream);
+/* to_time_cond (NS2:108-120, 839-843); wt = Linear weight K-major [dim+1, dt]; feat_ws [B, dim+1] scratch */
+int ns2_time_embed(const float* times, const float* freqs, const float* wt, const float* bias, float* feat_ws, float* out,
+                   int ld_out, int B, int dim, int dt, void* stream);
+int ns2_transpose_f32(const float* in, int batch, int R, int C, float* out, void* stream);
+
+/* one DDIM update (NS2:1396-1430): audio <- f(audio, model_out, times, times_next).  objective 0 'v', 1 'eps', 2 'x0';
+ * schedule 0 sigmoid, 1 cosine, 2 linear (NS2:1133-1148) */
+int ns2_ddim_step(const float* audio, const float* model_out, float* out, const float* times, const float* times_next,
+                  int B, int64_t per_batch, int objective, int schedule, float scale, void* stream);
+/* classifier-free guidance mix (NS2:927) */
+int ns2_cfg_mix(const float* cond_out, const float* null_out, float* out, int64_t n, float cond_scale, void* stream);
+
+/* EnCodec RVQ (HFENC:364-369, 424-447; reference call sites NS2:1445, NS2:1611, NS2:1496).
+ * cb_norm: [Q, C] scratch filled by ns2_rvq_prepare (once per codebook set). codes: [M, Q] int64; emb/residual [M, D] or null */
+int ns2_rvq_prepare(const float* codebooks, float* cb_norm, int Q, int C, int D, void* stream);
+int ns2_rvq_encode(const float* x, const float* codebooks, const float* cb_norm, int64_t* codes, float* emb,
+                   float* residual, int* near_tie_count, int M, int Q, int C, int D, float tie_eps, void* stream);
+int ns2_rvq_decode(const int64_t* codes, const float* codebooks, float* emb, int M, int Q, int C, int D, void* stream);
+
+/* ------------------------------------------------------------------ Model (NS2:811-1000) */
+typedef struct ns2_model ns2_model;
+typedef struct {
+  int dim, depth, dim_head, heads, ff_mult, wavenet_layers, wavenet_stacks, dim_cond_mult;   /* NS2:814-823 */
+  int condition_on_prompt, dim_prompt, num_latents_m, resampler_depth;                       /* NS2:826-831 */
+  int precision;                                                                             /* 3 exact, 1 fast */
+} ns2_model_config;
+
+int ns2_model_create(const ns2_model_config* cfg, ns2_model** out);
+/* register one state_dict entry (reference key names); data = device fp32, contiguous */
+int ns2_model_set_param(ns2_model* m, const char* name, const float* data, int ndim, const int64_t* dims);
+/* pack all weights (one-time, synchronises); the registered parameter tensors must stay alive afterwards only for
+ * the small fp32 vectors the executor reads in place (biases, gammas, sinusoid freqs) */
+int ns2_model_finalize(ns2_model* m, void* stream);
+int64_t ns2_model_workspace_bytes(const ns2_model* m, int B, int N, int n_prompt, int n_cond);
+int64_t ns2_model_cond_bytes(const ns2_model* m, int B, int N, int n_prompt, int n_cond);
+/* step-invariant conditioning (NS2:944-992: to_prompt_cond, perceiver_resampler, cond_to_model_dim, null substitutes)
+ * -> `cond_state` (caller-owned, ns2_model_cond_bytes).  drop != 0 == cond_drop_prob 1 (the CFG null branch). */
+int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_prompt, const float* cond, int n_cond, int drop, int B,
+                           int N, void* cond_state, void* workspace, int64_t workspace_bytes, void* stream);
+/* Model.forward (NS2:929-1000) for x [B, N, dim], times [B] -> out [B, N, dim]; cond_state null iff unconditional;
+ * n_cond = the n_cond the cond_state was prepared with */
+int ns2_model_forward(ns2_model* m, const float* x, const float* times, const void* cond_state, int n_cond, float* out, int B,
+                      int N, void* workspace, int64_t workspace_bytes, void* stream);
+/* optional intermediate taps for parity tests (fp32 copies made during forward / prepare_cond): "t", "c",
+ * "wavenet.init", "wavenet.stack<s>", "wavenet.out", "layer<i>.attn", "layer<i>"; dst = null unregisters */
+int ns2_model_debug_tap(ns2_model* m, const char* name, float* dst, int64_t dst_elems);
+void ns2_model_destroy(ns2_model* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NS2HIP_H */

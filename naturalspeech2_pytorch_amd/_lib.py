@@ -1,0 +1,97 @@
+"""ctypes binding of libns2hip.so (C ABI: include/ns2hip.h).
+
+The HIP library is the product: importing this module FAILS LOUDLY when the shared object is missing or does
+not export the full ABI — there is no CPU / PyTorch fallback for the hot path.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libns2hip.so")
+
+
+class Ns2Error(RuntimeError):
+    pass
+
+
+class ModelConfig(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in (
+        "dim", "depth", "dim_head", "heads", "ff_mult", "wavenet_layers", "wavenet_stacks", "dim_cond_mult",
+        "condition_on_prompt", "dim_prompt", "num_latents_m", "resampler_depth", "precision")]
+
+
+P = c_void_p
+I = c_int
+F = c_float
+L = c_int64
+
+# name -> (restype, argtypes); mirrors include/ns2hip.h line by line
+SIGNATURES = {
+    "ns2_last_error": (c_char_p, []),
+    "ns2_version": (I, []),
+    "ns2_weight_pack": (I, [P, I, I, I, I, P, POINTER(c_void_p), P]),
+    "ns2_weight_free": (None, [P]),
+    "ns2_split_f32": (I, [P, I, I, I, P, P, I, P]),
+    "ns2_join_f32": (I, [P, P, I, P, I, L, I, P]),
+    "ns2_linear_f32": (I, [P, P, P, I, I, I, I, I, P, P, I, P, I, I, P]),
+    "ns2_linear_split": (I, [P, P, P, I, I, I, I, I, P, P, P, I, I, P]),
+    "ns2_linear_geglu": (I, [P, P, P, I, I, P, P, P, I, I, P]),
+    "ns2_geglu_pack_bias": (I, [P, I, P, I, P]),
+    "ns2_linear_qkv": (I, [P, P, P, I, I, I, I, P, P, I, P, P, I, I, P]),
+    "ns2_wavenet_block": (I, [P, P, P, I, I, I, I, P, P, P, I, P, P, I, I, P]),
+    "ns2_attention": (I, [P, P, I, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, F, I, P]),
+    "ns2_rmsnorm": (I, [P, I, I, I, I, P, P, I, P, P, I, P, I, P]),
+    "ns2_skinny_linear": (I, [P, I, P, P, P, I, I, I, I, I, P]),
+    "ns2_time_embed": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "ns2_transpose_f32": (I, [P, I, I, I, P, P]),
+    "ns2_ddim_step": (I, [P, P, P, P, P, I, L, I, I, F, P]),
+    "ns2_cfg_mix": (I, [P, P, P, L, F, P]),
+    "ns2_rvq_prepare": (I, [P, P, I, I, I, P]),
+    "ns2_rvq_encode": (I, [P, P, P, P, P, P, P, I, I, I, I, F, P]),
+    "ns2_rvq_decode": (I, [P, P, P, I, I, I, I, P]),
+    "ns2_model_create": (I, [POINTER(ModelConfig), POINTER(c_void_p)]),
+    "ns2_model_set_param": (I, [P, c_char_p, P, I, POINTER(c_int64)]),
+    "ns2_model_finalize": (I, [P, P]),
+    "ns2_model_workspace_bytes": (L, [P, I, I, I, I]),
+    "ns2_model_cond_bytes": (L, [P, I, I, I, I]),
+    "ns2_model_prepare_cond": (I, [P, P, I, P, I, I, I, I, P, P, L, P]),
+    "ns2_model_forward": (I, [P, P, P, P, I, P, I, I, P, L, P]),
+    "ns2_model_debug_tap": (I, [P, c_char_p, P, L]),
+    "ns2_model_destroy": (None, [P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libns2hip.so and bind every symbol of the ABI; raises Ns2Error if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Ns2Error(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                       f"(or naturalspeech2_pytorch_amd/csrc/build.sh); there is no fallback path")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise Ns2Error(f"libns2hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ns2_last_error()
+        raise Ns2Error(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def header_symbols():
+    """Symbols declared in include/ns2hip.h (used by the CPU test that the .so exports the whole ABI)."""
+    import re
+    hdr = os.path.join(_HERE, "..", "include", "ns2hip.h")
+    return sorted(set(re.findall(r"\b(ns2_[a-z0-9_]+)\(", open(hdr).read())))

@@ -1,0 +1,112 @@
+"""Differentiable PyTorch composite of `Model.forward`, used ONLY when autograd is required
+(`loss.backward()` in training, BASELINE config 1 / NS2:1635, NS2:1886).
+
+The HIP kernels of libns2hip are forward-only (backward kernels are SURVEY §8f item 4, "next"); inference
+(`torch.no_grad()` — `NaturalSpeech2.sample`, `forward_with_cond_scale` in the sampling loop, bench.py) never
+reaches this file.  It reads the module's own parameters so gradients flow to them.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _causal_conv(x_bnc, conv, dilation=1):
+    k = conv.weight.shape[-1]
+    x = F.pad(x_bnc.transpose(1, 2), (dilation * (k - 1), 0))
+    return F.conv1d(x, conv.weight, conv.bias, dilation=dilation).transpose(1, 2)
+
+
+def _rmsnorm(x, norm, t=None):
+    out = F.normalize(x, dim=-1) * math.sqrt(x.shape[-1])
+    if norm.gamma is not None:
+        out = out * norm.gamma
+    if norm.to_gamma_beta is None:
+        return out
+    g, b = norm.to_gamma_beta(t).chunk(2, dim=-1)
+    return out * g[:, None] + b[:, None]
+
+
+def _attention(x, attn, heads, context=None, include_queries=False):
+    ctx = x if context is None else (torch.cat((x, context), dim=1) if include_queries else context)
+    q = attn.to_q(x)
+    k, v = attn.to_kv(ctx).chunk(2, dim=-1)
+    b, n, _ = q.shape
+
+    def sp(t):
+        return t.reshape(b, t.shape[1], heads, -1).transpose(1, 2)
+
+    o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v))
+    return attn.to_out(o.transpose(1, 2).reshape(b, n, -1))
+
+
+def _feedforward(x, ff, causal_conv):
+    h = getattr(ff, "0")(x)
+    a, gate = h.chunk(2, dim=-1)
+    h = F.gelu(gate) * a
+    if causal_conv:
+        h = _causal_conv(h, getattr(getattr(ff, "2"), "1"))
+        return getattr(ff, "3")(h)
+    return getattr(ff, "2")(h)
+
+
+def model_forward_autograd(m, x, times, prompt=None, cond=None, cond_drop_prob=None):
+    b, n, _ = x.shape
+    p = m.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
+    w = getattr(m.to_time_cond, "0").weights
+    tt = times[:, None]
+    fr = tt * w[None] * 2 * math.pi
+    t = F.silu(getattr(m.to_time_cond, "1")(torch.cat((tt, fr.sin(), fr.cos()), dim=-1)))
+    c = None
+    h = x
+    if m.condition_on_prompt:
+        assert prompt is not None and cond is not None
+
+        def mask():
+            if p == 1:
+                return torch.ones(b, dtype=torch.bool, device=x.device)
+            if p == 0:
+                return torch.zeros(b, dtype=torch.bool, device=x.device)
+            return torch.rand(b, device=x.device) < p
+
+        dm = mask()
+        pc = F.silu(getattr(m.to_prompt_cond, "1")(prompt.mean(dim=1)))
+        pc = torch.where(dm[:, None], m.null_prompt_cond, pc)
+        t = torch.cat((t, pc), dim=-1)
+        pr = m.perceiver_resampler
+        px = pr.proj_context(prompt) if hasattr(pr, "proj_context") else prompt
+        lat = pr.latents[None].expand(b, -1, -1)
+        for attn, ff in pr.layers:
+            lat = _attention(lat, attn, m.heads, context=px, include_queries=True) + lat
+            lat = _feedforward(lat, ff, False) + lat
+        c = torch.where(dm[:, None, None], m.null_prompt_tokens, _rmsnorm(lat, pr.norm))
+        cm = F.conv1d(cond, m.cond_to_model_dim.weight, m.cond_to_model_dim.bias)
+        cm = torch.where(mask()[:, None, None], m.null_cond, cm)
+        if cm.shape[-1] > n:
+            cm = cm[..., :n]
+        elif cm.shape[-1] < n:
+            cm = F.pad(cm, (0, n - cm.shape[-1]))
+        h = h + cm.transpose(1, 2)
+    wn = m.wavenet
+    h0 = _causal_conv(h, wn.init_conv)
+    cols = [h0] * m.wavenet_layers
+    skips = []
+    for s, st in enumerate(wn.stacks):
+        nxt = []
+        for i, blk in enumerate(st.blocks):
+            u = cols[i]
+            g, be = blk.to_time_cond(t).chunk(2, dim=-1)
+            z = _causal_conv(u, blk.conv, 2 ** i) * g[:, None] + be[:, None]
+            z = z.tanh() * z.sigmoid() + _causal_conv(u, blk.res_conv)
+            nxt.append(z)
+            if blk.skip_conv is not None:
+                skips.append(_causal_conv(z, blk.skip_conv))
+        cols = nxt
+    h = _causal_conv(torch.stack(skips).sum(0), wn.final_conv)
+    for layer in m.transformer.layers:
+        h = _attention(_rmsnorm(h, getattr(layer, "0"), t), getattr(layer, "1"), m.heads) + h
+        if m.condition_on_prompt:
+            h = _attention(_rmsnorm(h, getattr(layer, "2"), t), getattr(layer, "3"), m.heads, context=c) + h
+        h = _feedforward(_rmsnorm(h, getattr(layer, "4"), t), getattr(layer, "5"), True) + h
+    tp = m.transformer.to_pred
+    return getattr(tp, "1")(_rmsnorm(h, getattr(tp, "0")))

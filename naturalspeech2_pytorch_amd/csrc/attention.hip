@@ -1,0 +1,265 @@
+// Flash-attention forward for the NaturalSpeech2 denoiser on gfx950 (CDNA4): softmax(q k^T / sqrt(64)) v,
+// non-causal, no dropout, optional key-length tail (ATT:77-155; hot path = Attend.flash_attn / math path).
+// Covers self-attention (Nk = N), prompt cross-attention (Nk = 32 perceiver latents) and the
+// PerceiverResampler's own attention (Nq = 32, Nk = 32 + n_prompt).
+//
+// Design (64-wide waves, MFMA 32x32x16 bf16, split-plane operands like the GEMMs):
+//   * one workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows;
+//   * K tile [64 keys][64 d] and V^T tile [64 d][64 keys] are staged global -> VGPR -> LDS (double-buffered,
+//     next tile's loads in flight during the current tile's MFMAs), rows padded to 144 B (9 x 16 B slots,
+//     9 coprime to 16 => conflict-free ds_read_b128 fragments);
+//   * S^T = K Q^T ("swapped" product): the C fragment then holds, per lane, 16 keys of ONE query
+//     (query = lane & 31), so the online softmax runs in registers with a single cross-half exchange;
+//     key rows are read through the bit-swap permutation pi (bits 2<->3) so that each half-wave's
+//     registers r = 8*g1 .. 8*g1+7 are 8 CONSECUTIVE keys: P feeds the second MFMA's B operand directly
+//     and the matching V^T fragment is one 16-B LDS read;
+//   * O^T = V^T P^T accumulates with query = lane & 31 again, so the running rescale is a per-lane scalar;
+//   * V arrives already transposed ([b][h*64+d][n]) from the QKV GEMM epilogue (gemm.hip EPI_QKV).
+// NSPLIT = 3 evaluates both products as hi*hi + hi*lo + lo*hi (fp32-class accuracy), NSPLIT = 1 hi only.
+#include "ns2_common.h"
+#include "ns2_kernels.h"
+
+namespace ns2 {
+
+constexpr int AT_ROWB = 144;               // 128 B payload + 16 B pad
+constexpr int AT_PLANE = 64 * AT_ROWB;     // 9216 B
+
+NS2_DEVINL uint4 ld16g(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// zero the bf16 elements e >= nvalid of an 8-element chunk
+NS2_DEVINL uint4 mask_chunk(uint4 v, int nvalid) {
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (2 * i >= nvalid) w[i] = 0u;
+    else if (2 * i + 1 >= nvalid) w[i] &= 0xffffu;
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
+  constexpr int NP = (NSPLIT == 3) ? 2 : 1;
+  constexpr int STAGE_BYTES = 2 * NP * AT_PLANE;     // K planes then V^T planes
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+  const bool q_ok = qrow < a.Nq;
+
+  const bf16_t* q_pl[2] = {a.q_hi, a.q_lo};
+  const bf16_t* k_pl[2] = {a.k_hi, a.k_lo};
+  const bf16_t* v_pl[2] = {a.vt_hi, a.vt_lo};
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = l31][d = 16c + 8hi .. +7]
+  bf16x8 qf[NP][4];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (q_ok) v = ld16g(q_pl[p] + ((long)b * a.Nq + qrow) * a.ldq + a.q_col0 + h * 64 + 16 * c + 8 * hi);
+      qf[p][c] = *reinterpret_cast<bf16x8*>(&v);
+    }
+
+  // ---- staging coordinates: 2 chunks per plane per thread
+  int srow[2], sch[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    srow[i] = c >> 3;
+    sch[i] = c & 7;
+  }
+  struct Regs { uint4 k[NP][2]; uint4 v[NP][2]; };
+
+  auto load_tile = [&](Regs& rg, int key0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = key0 + srow[i];
+      const bool kok = key < a.Nk;
+      const long koff = ((long)b * a.Nk + key) * a.ldk + a.k_col0 + h * 64 + sch[i] * 8;
+      const int vkey = key0 + sch[i] * 8;
+      const int nvalid = a.Nk - vkey;
+      const long voff = ((long)b * a.H * 64 + h * 64 + srow[i]) * a.vt_ld + vkey;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        rg.k[p][i] = kok ? ld16g(k_pl[p] + koff) : make_uint4(0u, 0u, 0u, 0u);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (nvalid > 0) {
+          v = ld16g(v_pl[p] + voff);                  // vt_ld is a multiple of 8: the chunk is inside the row
+          if (nvalid < 8) v = mask_chunk(v, nvalid);  // finite zeros where P is exactly 0
+        }
+        rg.v[p][i] = v;
+      }
+    }
+  };
+  auto store_tile = [&](const Regs& rg, int s) {
+    unsigned char* base = smem + s * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = srow[i] * AT_ROWB + sch[i] * 16;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        *reinterpret_cast<uint4*>(base + p * AT_PLANE + off) = rg.k[p][i];
+        *reinterpret_cast<uint4*>(base + (NP + p) * AT_PLANE + off) = rg.v[p][i];
+      }
+    }
+  };
+
+  // pi: swap bits 2 and 3 of the MFMA row index -> key row inside a 32-key sub-tile
+  const int pi_row = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+  const int k_frag_off = pi_row * AT_ROWB + hi * 16;          // + js*32*ROWB + c*32
+  const int v_frag_off = l31 * AT_ROWB + hi * 16;             // + dt*32*ROWB + js*64 + g1*32
+
+  f32x16 ot[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sl2 = a.scale * 1.4426950408889634f;
+
+  const int ntiles = (a.Nk + 63) / 64;
+  Regs rg;
+  load_tile(rg, 0);
+  store_tile(rg, 0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = (t + 1) < ntiles;
+    if (more) load_tile(rg, (t + 1) * 64);
+    const unsigned char* sb = smem + (t & 1) * STAGE_BYTES;
+    const int key0 = t * 64;
+
+    // ---- S^T = K Q^T  (2 sub-tiles of 32 keys)
+    f32x16 st[2];
+#pragma unroll
+    for (int js = 0; js < 2; ++js) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[js][r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x8 kf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          kf[p] = *reinterpret_cast<const bf16x8*>(sb + p * AT_PLANE + k_frag_off + js * 32 * AT_ROWB + c * 32);
+        if constexpr (NSPLIT == 3) {
+          st[js] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][c], st[js], 0, 0, 0);
+          st[js] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][c], st[js], 0, 0, 0);
+        }
+        st[js] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][c], st[js], 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax for query l31; register r of sub-tile js is key key0 + 32js + 16(r>>3) + 8hi + (r&7)
+    const bool tail = key0 + 64 > a.Nk;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int js = 0; js < 2; ++js)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = st[js][r] * sl2;
+        if (tail) {
+          const int key = key0 + 32 * js + 16 * (r >> 3) + 8 * hi + (r & 7);
+          if (key >= a.Nk) s = -INFINITY;
+        }
+        st[js][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int js = 0; js < 2; ++js)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[js][r] - m_new);
+        st[js][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int js = 0; js < 2; ++js)
+#pragma unroll
+      for (int g1 = 0; g1 < 2; ++g1) {
+        bf16x8 pf[NP];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float p = st[js][8 * g1 + e];
+          const bf16_t ph = f2bf(p);
+          pf[0][e] = (short)ph;
+          if constexpr (NSPLIT == 3) pf[1][e] = (short)f2bf(p - bf2f(ph));
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16x8 vf[NP];
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            vf[p] = *reinterpret_cast<const bf16x8*>(sb + (NP + p) * AT_PLANE + v_frag_off + dt * 32 * AT_ROWB +
+                                                    js * 64 + g1 * 32);
+          if constexpr (NSPLIT == 3) {
+            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[0], ot[dt], 0, 0, 0);
+            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[1], ot[dt], 0, 0, 0);
+          }
+          ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0], ot[dt], 0, 0, 0);
+        }
+      }
+
+    if (more) store_tile(rg, (t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and write O[q][h*64 + d]: lane holds d = 32dt + 8g + 4hi + e for its query
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q_ok) {
+    const long obase = ((long)b * a.Nq + qrow) * a.ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        bf16_t hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_bf16(ot[dt][4 * gq + e] * inv, hh[e], ll[e]);
+        const long o = obase + 32 * dt + 8 * gq + 4 * hi;
+        *reinterpret_cast<uint2*>(a.o_hi + o) = make_uint2(pack2(hh[0], hh[1]), pack2(hh[2], hh[3]));
+        if (a.o_lo) *reinterpret_cast<uint2*>(a.o_lo + o) = make_uint2(pack2(ll[0], ll[1]), pack2(ll[2], ll[3]));
+      }
+  }
+}
+
+template <int NSPLIT>
+static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
+  const size_t lds = 2 * 2 * (NSPLIT == 3 ? 2 : 1) * AT_PLANE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<NSPLIT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid((a.Nq + 127) / 128, a.H, a.B);
+  hipLaunchKernelGGL((attn_kernel<NSPLIT>), grid, dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_attention(const AttnArgs& a, int nsplit, hipStream_t s) {
+  if (a.B <= 0 || a.H <= 0 || a.Nq <= 0 || a.Nk <= 0 || (a.vt_ld & 7)) return hipErrorInvalidValue;
+  if (nsplit == 3) {
+    if (!a.q_lo || !a.k_lo || !a.vt_lo) return hipErrorInvalidValue;
+    return launch_attn_t<3>(a, s);
+  }
+  return launch_attn_t<1>(a, s);
+}
+
+}  // namespace ns2

@@ -1,0 +1,207 @@
+// extern "C" surface of libns2hip (declared in include/ns2hip.h): error plumbing + op-level entry points.
+// The Model executor entry points live in model_exec.cpp.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ns2_host.h"
+
+namespace ns2 {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace ns2
+
+using namespace ns2;
+
+
+#define HIPRET(expr)                                                                 \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return NS2_ERR_HIP;                                                            \
+    }                                                                                \
+  } while (0)
+#define ARGCHK(cond, msg)            \
+  do {                               \
+    if (!(cond)) {                   \
+      set_error("%s", msg);          \
+      return NS2_ERR_ARG;            \
+    }                                \
+  } while (0)
+static inline int prec_ok(int p) { return p == 1 || p == 3; }
+
+extern "C" const char* ns2_last_error(void) { return g_err; }
+extern "C" int ns2_version(void) { return 100; }
+
+extern "C" int ns2_weight_pack(const float* w, int rows, int cols, int taps, int geglu, const float* extra1x1, ns2_weight** out,
+                               void* stream) {
+  ARGCHK(w && out && rows > 0 && cols > 0 && taps >= 1, "ns2_weight_pack: bad arguments");
+  ARGCHK(!(geglu && (taps != 1 || extra1x1 || (rows & 1))), "ns2_weight_pack: geglu needs taps=1, no extra, even rows");
+  ns2_weight* h = new ns2_weight();
+  h->taps = taps; h->geglu = geglu; h->has_extra = extra1x1 != nullptr; h->cols_p = (cols + 31) / 32 * 32;
+  int r = pack_weight_public(w, rows, cols, taps, geglu, extra1x1, &h->w, &h->owned, (hipStream_t)stream);
+  if (r != NS2_OK) { ns2_weight_free(h); return r; }
+  *out = h;
+  return NS2_OK;
+}
+extern "C" void ns2_weight_free(ns2_weight* w) {
+  if (!w) return;
+  for (void* p : w->owned) hipFree(p);
+  delete w;
+}
+
+extern "C" int ns2_split_f32(const float* x, int ldx, int M, int d, uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream) {
+  ARGCHK(x && out_hi, "ns2_split_f32: null pointer");
+  HIPRET(launch_split(x, ldx, nullptr, 0, 0, 0, out_hi, out_lo, ldo, M, d, 0, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_join_f32(const uint16_t* hi, const uint16_t* lo, int ld, float* out, int ldo, int64_t M, int d, void* stream) {
+  ARGCHK(hi && out, "ns2_join_f32: null pointer");
+  HIPRET(launch_join(hi, lo, ld, out, ldo, (long)M, d, (hipStream_t)stream));
+  return NS2_OK;
+}
+
+extern "C" int ns2_linear_f32(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
+                              int dilation, int seq_len, const float* bias, const float* resid, int ldr, float* out, int ldo,
+                              int precision, void* stream) {
+  ARGCHK(w && a_hi && out && prec_ok(precision), "ns2_linear_f32: bad arguments");
+  ARGCHK(!w->geglu && !w->has_extra && (conv_taps == 0 ? w->taps == 1 : w->taps == conv_taps), "ns2_linear_f32: weight packing does not match");
+  ARGCHK(lda >= w->cols_p, "ns2_linear_f32: lda smaller than the padded K");
+  return gemm_f32(w->w, a_hi, a_lo, lda, M, conv_taps, dilation, seq_len, bias, resid, ldr, out, ldo, precision, (hipStream_t)stream);
+}
+extern "C" int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
+                                int dilation, int seq_len, const float* bias, uint16_t* out_hi, uint16_t* out_lo, int ldo,
+                                int precision, void* stream) {
+  ARGCHK(w && a_hi && out_hi && prec_ok(precision), "ns2_linear_split: bad arguments");
+  ARGCHK(!w->geglu && !w->has_extra && (conv_taps == 0 ? w->taps == 1 : w->taps == conv_taps), "ns2_linear_split: weight packing does not match");
+  ARGCHK(lda >= w->cols_p && (ldo & 1) == 0, "ns2_linear_split: bad leading dimensions");
+  return gemm_split(w->w, a_hi, a_lo, lda, M, conv_taps, dilation, seq_len, bias, out_hi, out_lo, ldo, precision, (hipStream_t)stream);
+}
+extern "C" int ns2_linear_geglu(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M,
+                                const float* packed_bias, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream) {
+  ARGCHK(w && a_hi && out_hi && packed_bias && prec_ok(precision) && w->geglu, "ns2_linear_geglu: bad arguments");
+  ARGCHK(ldo * 2 == w->w.N, "ns2_linear_geglu: ldo must be round_up(f, 32)");
+  return gemm_geglu(w->w, a_hi, a_lo, lda, M, packed_bias, out_hi, out_lo, ldo, precision, (hipStream_t)stream);
+}
+extern "C" int ns2_geglu_pack_bias(const float* bias, int f, float* packed, int packed_len, void* stream) {
+  ARGCHK(bias && packed && f > 0, "ns2_geglu_pack_bias: bad arguments");
+  const int rows_p = ((2 * ((f + 31) / 32 * 32)) + 127) / 128 * 128;
+  ARGCHK(packed_len >= rows_p, "ns2_geglu_pack_bias: packed_len too small");
+  std::vector<float> hb(2 * f), pb(packed_len, 0.f);
+  HIPRET(hipMemcpy(hb.data(), bias, 2 * f * sizeof(float), hipMemcpyDeviceToHost));
+  std::vector<int> m = geglu_row_map(f, rows_p);
+  for (int i = 0; i < rows_p; ++i)
+    if (m[i] >= 0) pb[i] = hb[m[i]];
+  HIPRET(hipMemcpy(packed, pb.data(), packed_len * sizeof(float), hipMemcpyHostToDevice));
+  (void)stream;
+  return NS2_OK;
+}
+extern "C" int ns2_linear_qkv(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int seq_len,
+                              int split_col, uint16_t* out_hi, uint16_t* out_lo, int ldo, uint16_t* vt_hi, uint16_t* vt_lo,
+                              int vt_ld, int precision, void* stream) {
+  ARGCHK(w && a_hi && out_hi && vt_hi && prec_ok(precision), "ns2_linear_qkv: bad arguments");
+  ARGCHK(seq_len > 0 && M % seq_len == 0 && (split_col % 32) == 0 && split_col < w->w.N && vt_ld >= seq_len && (vt_ld & 7) == 0,
+         "ns2_linear_qkv: bad shapes");
+  return gemm_qkv(w->w, a_hi, a_lo, lda, M, seq_len, split_col, out_hi, out_lo, ldo, vt_hi, vt_lo, vt_ld, precision, (hipStream_t)stream);
+}
+extern "C" int ns2_wavenet_block(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int seq_len,
+                                 int dilation, const float* conv_bias, const float* res_bias, const float* film, int film_ld,
+                                 uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream) {
+  ARGCHK(w && a_hi && out_hi && conv_bias && res_bias && film && prec_ok(precision), "ns2_wavenet_block: bad arguments");
+  ARGCHK(w->taps == 3 && w->has_extra && seq_len > 0, "ns2_wavenet_block: weight must be packed with taps=3 and extra1x1");
+  return gemm_wavenet(w->w, a_hi, a_lo, lda, 0, M, seq_len, dilation, 0, 1, conv_bias, res_bias, 0, film, film_ld, 0, out_hi, out_lo,
+                      ldo, 0, ldo, precision, (hipStream_t)stream);
+}
+
+extern "C" int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi,
+                             const uint16_t* k_lo, int ldk, int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld,
+                             uint16_t* o_hi, uint16_t* o_lo, int ldo, int B, int H, int Nq, int Nk, float scale, int precision,
+                             void* stream) {
+  ARGCHK(q_hi && k_hi && vt_hi && o_hi && prec_ok(precision), "ns2_attention: bad arguments");
+  AttnArgs a;
+  a.q_hi = q_hi; a.q_lo = q_lo; a.ldq = ldq; a.q_col0 = q_col0;
+  a.k_hi = k_hi; a.k_lo = k_lo; a.ldk = ldk; a.k_col0 = k_col0;
+  a.vt_hi = vt_hi; a.vt_lo = vt_lo; a.vt_ld = vt_ld;
+  a.o_hi = o_hi; a.o_lo = o_lo; a.ldo = ldo;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+  HIPRET(launch_attention(a, precision, (hipStream_t)stream));
+  return NS2_OK;
+}
+
+extern "C" int ns2_rmsnorm(const float* x, int ldx, int M, int d, int seq_len, const float* gamma, const float* cond, int cond_ld,
+                           uint16_t* out_hi, uint16_t* out_lo, int ldo, float* out_f32, int ldo_f, void* stream) {
+  ARGCHK(x && (out_hi || out_f32), "ns2_rmsnorm: bad arguments");
+  ARGCHK(!cond || seq_len > 0, "ns2_rmsnorm: adaptive norm needs seq_len");
+  NormArgs n;
+  n.x = x; n.ldx = ldx; n.gamma = gamma; n.cond = cond; n.cond_ld = cond_ld;
+  n.out_hi = out_hi; n.out_lo = out_lo; n.ldo = out_hi ? ldo : d; n.out_f = out_f32; n.ldo_f = ldo_f;
+  n.M = M; n.d = d; n.seq_len = seq_len;
+  HIPRET(launch_rmsnorm(n, (hipStream_t)stream));
+  return NS2_OK;
+}
+
+extern "C" int ns2_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out, int B,
+                                 int K, int J, int act, void* stream) {
+  ARGCHK(in && wt && out, "ns2_skinny_linear: null pointer");
+  HIPRET(launch_skinny_linear(in, ld_in, wt, bias, out, ld_out, B, K, J, act, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_time_embed(const float* times, const float* freqs, const float* wt, const float* bias, float* feat_ws,
+                              float* out, int ld_out, int B, int dim, int dt, void* stream) {
+  ARGCHK(times && freqs && wt && feat_ws && out, "ns2_time_embed: null pointer");
+  HIPRET(launch_time_embed(times, freqs, wt, bias, feat_ws, out, ld_out, B, dim, dt, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_transpose_f32(const float* in, int batch, int R, int C, float* out, void* stream) {
+  ARGCHK(in && out, "ns2_transpose_f32: null pointer");
+  HIPRET(launch_transpose_f32(in, batch, R, C, out, (hipStream_t)stream));
+  return NS2_OK;
+}
+
+extern "C" int ns2_ddim_step(const float* audio, const float* model_out, float* out, const float* times, const float* times_next,
+                             int B, int64_t per_batch, int objective, int schedule, float scale, void* stream) {
+  ARGCHK(audio && model_out && out && times && times_next, "ns2_ddim_step: null pointer");
+  ARGCHK(objective >= 0 && objective <= 2 && schedule >= 0 && schedule <= 2, "ns2_ddim_step: bad objective/schedule");
+  DdimArgs a;
+  a.audio = const_cast<float*>(audio); a.model_out = model_out; a.out = out; a.times = times; a.times_next = times_next;
+  a.B = B; a.per_batch = (long)per_batch; a.objective = objective; a.schedule = schedule; a.scale = scale;
+  HIPRET(launch_ddim(a, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_cfg_mix(const float* cond_out, const float* null_out, float* out, int64_t n, float cond_scale, void* stream) {
+  ARGCHK(cond_out && null_out && out, "ns2_cfg_mix: null pointer");
+  HIPRET(launch_cfg_mix(cond_out, null_out, out, (long)n, cond_scale, (hipStream_t)stream));
+  return NS2_OK;
+}
+
+extern "C" int ns2_rvq_prepare(const float* codebooks, float* cb_norm, int Q, int C, int D, void* stream) {
+  ARGCHK(codebooks && cb_norm, "ns2_rvq_prepare: null pointer");
+  HIPRET(launch_rvq_prepare(codebooks, cb_norm, Q, C, D, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_rvq_encode(const float* x, const float* codebooks, const float* cb_norm, int64_t* codes, float* emb,
+                              float* residual, int* near_tie_count, int M, int Q, int C, int D, float tie_eps, void* stream) {
+  ARGCHK(x && codebooks && cb_norm && codes, "ns2_rvq_encode: null pointer");
+  ARGCHK(D == 128 && C % 64 == 0, "ns2_rvq_encode: needs codebook_dim 128 and codebook_size % 64 == 0 (EnCodec: 128 / 1024)");
+  RvqArgs a;
+  a.x = x; a.codebooks = codebooks; a.cb_norm = cb_norm; a.codes = codes; a.emb = emb; a.residual = residual;
+  a.near_tie_count = near_tie_count; a.M = M; a.Q = Q; a.C = C; a.D = D; a.tie_eps = tie_eps;
+  HIPRET(launch_rvq_encode(a, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_rvq_decode(const int64_t* codes, const float* codebooks, float* emb, int M, int Q, int C, int D, void* stream) {
+  ARGCHK(codes && codebooks && emb, "ns2_rvq_decode: null pointer");
+  HIPRET(launch_rvq_decode(codes, codebooks, emb, M, Q, C, D, (hipStream_t)stream));
+  return NS2_OK;
+}

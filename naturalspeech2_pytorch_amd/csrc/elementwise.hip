@@ -1,0 +1,350 @@
+// HBM-bound and tiny kernels of the NaturalSpeech2 denoiser on gfx950: RMSNorm (wavefront reduction), fp32 ->
+// split-plane conversion, time embedding, the batched skinny conditioning projections, DDIM update, CFG mix,
+// weight packing.  All vectorised to 16 B per lane where the layout allows (guide G13).
+#include "ns2_common.h"
+#include "ns2_kernels.h"
+
+namespace ns2 {
+
+// ---------------------------------------------------------------- RMSNorm (NS2:727-746)
+// one wave per row; two passes over the row (the second hits L1/L2), fp32 math, split-plane output.
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const NormArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const float* x = a.x + row * a.ldx;
+  float ss = 0.f;
+  for (int c = lane * 4; c < a.d; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(x + c);
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);     // F.normalize eps
+  const float scale = sqrtf((float)a.d);
+  const int b = a.seq_len > 0 ? (int)(row / a.seq_len) : 0;
+  const float* gc = a.cond ? a.cond + (long)b * a.cond_ld : nullptr;
+  for (int c = lane * 4; c < a.ldo; c += 256) {
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < a.d) {
+      const float4 v = *reinterpret_cast<const float4*>(x + c);
+      const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = xv[e] * inv * scale;
+        if (a.gamma) t *= a.gamma[c + e];
+        if (gc) t = t * gc[c + e] + gc[a.d + c + e];
+        o[e] = t;
+      }
+    }
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_bf16(o[e], h[e], l[e]);
+    if (a.out_hi) {
+      *reinterpret_cast<uint2*>(a.out_hi + row * a.ldo + c) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+      if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + row * a.ldo + c) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+    }
+    if (a.out_f && c < a.d) *reinterpret_cast<float4*>(a.out_f + row * a.ldo_f + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+hipError_t launch_rmsnorm(const NormArgs& a, hipStream_t s) {
+  if (a.M <= 0 || (a.d & 3) || (a.ldo & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- x (+ add) -> split planes
+__global__ __launch_bounds__(256) void split_kernel(const float* x, int ldx, const float* add, int ldadd, int add_rows,
+                                                    int add_valid, bf16_t* out_hi, bf16_t* out_lo, int ldo, long M, int d,
+                                                    int seq_len) {
+  const int chunks = ldo >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * chunks) return;
+  const long row = idx / chunks;
+  const int c = (int)(idx - row * chunks) * 4;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = ((d | ldx | ldadd) & 3) == 0;
+  if (c < d) {
+    if (vec) {
+      const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < d) o[e] = x[row * ldx + c + e];
+    }
+    if (add) {
+      const long b = row / seq_len;
+      const int n = (int)(row - b * seq_len);
+      if (n < add_valid) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < d) o[e] += add[(b * add_rows + n) * ldadd + c + e];
+      }
+    }
+  }
+  bf16_t h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_bf16(o[e], h[e], l[e]);
+  *reinterpret_cast<uint2*>(out_hi + row * ldo + c) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+  if (out_lo) *reinterpret_cast<uint2*>(out_lo + row * ldo + c) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+}
+
+hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, int add_rows_per_batch, int add_valid_rows,
+                        bf16_t* out_hi, bf16_t* out_lo, int ldo, int M, int d, int seq_len, hipStream_t s) {
+  if (M <= 0 || (ldo & 3) || ldo < d || (add && seq_len <= 0)) return hipErrorInvalidValue;
+  const long total = (long)M * (ldo >> 2);
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, add, ldadd,
+                     add_rows_per_batch, add_valid_rows, out_hi, out_lo, ldo, (long)M, d, seq_len);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- skinny linear: out[b,j] = act(in[b,:] . wt[:,j] + bias[j])
+// M = batch rows (<= 32 per pass), weight stored K-major so a wave streams it fully coalesced; the 32 batch
+// rows of the activation chunk sit transposed in LDS and are read as broadcast ds_read_b128.  Weight-bandwidth
+// bound: this is how all 56-68 time/prompt conditioning projections of one denoising step are produced at once.
+constexpr int SK_KC = 128;
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const float* in, int ld_in, const float* wt, const float* bias,
+                                                            float* out, int ld_out, int B, int K, int J, int act) {
+  __shared__ __attribute__((aligned(16))) float s_in[32][SK_KC + 4];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.y * 32;
+  const int nb = min(32, B - b0);
+  const bool jok = j < J;
+  float acc[32];
+#pragma unroll
+  for (int b = 0; b < 32; ++b) acc[b] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += SK_KC) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < SK_KC * 32; i += 256) {
+      const int b = i / SK_KC, k = i - b * SK_KC;          // coalesced along k, conflict-free LDS writes
+      float v = 0.f;
+      if (b < nb && k0 + k < K) v = in[(long)(b0 + b) * ld_in + k0 + k];
+      s_in[b][k] = v;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int k = 0; k < SK_KC; k += 4) {
+      float w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (jok && k0 + k + e < K) ? wt[(long)(k0 + k + e) * J + j] : 0.f;
+#pragma unroll
+      for (int b = 0; b < 32; ++b) {
+        const float4 t = *reinterpret_cast<const float4*>(&s_in[b][k]);   // wave-uniform address: LDS broadcast
+        acc[b] = fmaf(t.x, w[0], acc[b]);
+        acc[b] = fmaf(t.y, w[1], acc[b]);
+        acc[b] = fmaf(t.z, w[2], acc[b]);
+        acc[b] = fmaf(t.w, w[3], acc[b]);
+      }
+    }
+  }
+  if (jok) {
+    const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+    for (int b = 0; b < 32; ++b)
+      if (b < nb) {
+        float v = acc[b] + bj;
+        if (act == 1) v = siluf(v);
+        out[(long)(b0 + b) * ld_out + j] = v;
+      }
+  }
+}
+
+hipError_t launch_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out,
+                                int B, int K, int J, int act, hipStream_t s) {
+  if (B <= 0 || K <= 0 || J <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(skinny_linear_kernel, dim3((J + 255) / 256, (B + 31) / 32), dim3(256), 0, s, in, ld_in, wt, bias,
+                     out, ld_out, B, K, J, act);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- time features (NS2:108-120): [t, sin(2 pi t w), cos(2 pi t w)]
+__global__ void time_feat_kernel(const float* times, const float* freqs, float* feat, int B, int dim) {
+  const int half = dim / 2, K = dim + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * K) return;
+  const int b = i / K, k = i - b * K;
+  const float t = times[b];
+  float v;
+  if (k == 0) v = t;
+  else {
+    const int f = (k - 1) % half;
+    const float fr = t * freqs[f] * 2.0f * 3.14159265358979323846f;   // x * w * 2 * pi, left to right in fp32
+    v = (k - 1 < half) ? sinf(fr) : cosf(fr);
+  }
+  feat[i] = v;
+}
+
+hipError_t launch_time_embed(const float* times, const float* freqs, const float* wt, const float* bias, float* feat_ws,
+                             float* out, int ld_out, int B, int dim, int dt, hipStream_t s) {
+  const int K = dim + 1;
+  hipLaunchKernelGGL(time_feat_kernel, dim3((B * K + 255) / 256), dim3(256), 0, s, times, freqs, feat_ws, B, dim);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return launch_skinny_linear(feat_ws, K, wt, bias, out, ld_out, B, K, dt, /*act=*/1, s);
+}
+
+// ---------------------------------------------------------------- small data movers
+__global__ void transpose_kernel(const float* in, int R, int C, float* out) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const float* src = in + (long)blockIdx.z * R * C;
+  float* dst = out + (long)blockIdx.z * R * C;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < C) dst[(long)c * R + r] = tile[threadIdx.x][i];
+  }
+}
+hipError_t launch_transpose_f32(const float* in, int batch, int R, int C, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(32, 8), 0, s, in, R, C, out);
+  return hipGetLastError();
+}
+
+__global__ void mean_rows_kernel(const float* in, int n, int d, float* out) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  float acc = 0.f;
+  for (int i = 0; i < n; ++i) acc += in[((long)b * n + i) * d + c];
+  out[(long)b * d + c] = acc / (float)n;
+}
+hipError_t launch_mean_rows(const float* in, int B, int n, int d, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(mean_rows_kernel, dim3((d + 255) / 256, B), dim3(256), 0, s, in, n, d, out);
+  return hipGetLastError();
+}
+
+// out[b, :] = bcast[:]  (broadcast a parameter row to every batch entry; used for the CFG "null" conditioning)
+__global__ void bcast_rows_kernel(const float* src, float* out, long row_elems, long ld_out, long n_total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_total) return;
+  const long b = i / row_elems, e = i - b * row_elems;
+  out[b * ld_out + e] = src[e];
+}
+hipError_t launch_bcast_rows(const float* src, float* out, int B, long row_elems, long ld_out, hipStream_t s) {
+  const long n = (long)B * row_elems;
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, out, row_elems, ld_out, n);
+  return hipGetLastError();
+}
+
+// dst[c * ld_dst + col_off + r] = src[r * C + c]   (nn.Linear weight [R=out, C=in] -> K-major slice of a wider matrix)
+__global__ void transpose_into_kernel(const float* src, int R, int C, float* dst, long ld_dst, long col_off) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < C) dst[(long)c * ld_dst + col_off + r] = tile[threadIdx.x][i];
+  }
+}
+hipError_t launch_transpose_into(const float* src, int R, int C, float* dst, long ld_dst, long col_off, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_into_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, s, src, R, C, dst, ld_dst, col_off);
+  return hipGetLastError();
+}
+
+// split planes -> fp32 (hi + lo), used by debug taps and tests
+__global__ void join_kernel(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * d) return;
+  const long r = i / d;
+  const int c = (int)(i - r * d);
+  float v = bf2f(hi[r * ld + c]);
+  if (lo) v += bf2f(lo[r * ld + c]);
+  out[r * ldo + c] = v;
+}
+hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s) {
+  const long n = M * d;
+  hipLaunchKernelGGL(join_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hi, lo, ld, out, ldo, M, d);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- DDIM update (NS2:1396-1430)
+NS2_DEVINL float gamma_of(float t, int schedule) {
+  float g;
+  if (schedule == 0) {        // sigmoid_schedule NS2:1144-1148, start=-3 end=3 tau=1
+    const float vs = 1.0f / (1.0f + expf(3.0f)), ve = 1.0f / (1.0f + expf(-3.0f));
+    const float sg = 1.0f / (1.0f + expf(-(t * 6.0f - 3.0f)));
+    g = (-sg + ve) / (ve - vs);
+    return fminf(fmaxf(g, 1e-9f), 1.0f);
+  } else if (schedule == 1) { // cosine_schedule NS2:1136-1142 (start=0, end=1, tau=1): (v_end - cos^2)/(v_end - 1), v_end ~ 0
+    const float c = cosf(t * 1.57079632679489661923f);
+    return fmaxf(c * c, 1e-9f);
+  }
+  return fmaxf(1.0f - t, 1e-9f);   // simple_linear_schedule NS2:1133-1134
+}
+
+__global__ __launch_bounds__(256) void ddim_kernel(const DdimArgs a) {
+  const int b = blockIdx.y;
+  const float g = gamma_of(a.times[b], a.schedule), gn = gamma_of(a.times_next[b], a.schedule);
+  const float alpha = sqrtf(g) * a.scale, sigma = sqrtf(1.0f - g);
+  const float alpha_n = sqrtf(gn) * a.scale, sigma_n = sqrtf(1.0f - gn);
+  const float inv_sigma = 1.0f / fmaxf(sigma, 1e-10f);      // safe_div NS2:1122-1123
+  const float inv_alpha = 1.0f / fmaxf(alpha, 1e-10f);
+  const long base = (long)b * a.per_batch;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < a.per_batch; i += (long)gridDim.x * 1024) {
+    const float4 x4 = *reinterpret_cast<const float4*>(a.audio + base + i);
+    const float4 v4 = *reinterpret_cast<const float4*>(a.model_out + base + i);
+    const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, vs[4] = {v4.x, v4.y, v4.z, v4.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x0;
+      if (a.objective == 0) x0 = alpha * xs[e] - sigma * vs[e];            // 'v'   NS2:1422
+      else if (a.objective == 1) x0 = (xs[e] - sigma * vs[e]) * inv_alpha;  // 'eps' NS2:1419
+      else x0 = vs[e];                                                      // 'x0'  NS2:1416
+      const float eps = (xs[e] - alpha * x0) * inv_sigma;                   // NS2:1426
+      o[e] = x0 * alpha_n + eps * sigma_n;                                  // NS2:1430
+    }
+    *reinterpret_cast<float4*>(a.out + base + i) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+hipError_t launch_ddim(const DdimArgs& a, hipStream_t s) {
+  if (a.B <= 0 || a.per_batch <= 0 || (a.per_batch & 3)) return hipErrorInvalidValue;
+  const long blocks = (a.per_batch / 4 + 255) / 256;
+  hipLaunchKernelGGL(ddim_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512), a.B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+__global__ void cfg_mix_kernel(const float* cond, const float* null, float* out, long n, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float u = null[i];
+    out[i] = u + (cond[i] - u) * scale;       // NS2:927
+  }
+}
+hipError_t launch_cfg_mix(const float* cond, const float* null, float* out, long n, float scale, hipStream_t s) {
+  const long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(cfg_mix_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, cond, null, out, n, scale);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- weight packing (one-time, at model finalize)
+__global__ void pack_weight_kernel(const float* src, int C, int T, int Cp, const int* row_map, int rows_p, bf16_t* dst_hi,
+                                   bf16_t* dst_lo, int ldk, int k_off) {
+  const int kk = blockIdx.x * 256 + threadIdx.x;          // column inside [0, T*Cp)
+  const int rp = blockIdx.y;
+  if (kk >= T * Cp || rp >= rows_p) return;
+  const int tap = kk / Cp, c = kk - tap * Cp;
+  const int r = row_map ? row_map[rp] : rp;
+  float v = 0.f;
+  if (r >= 0 && c < C) v = src[((long)r * C + c) * T + tap];
+  bf16_t h, l;
+  split_bf16(v, h, l);
+  const long o = (long)rp * ldk + k_off + kk;
+  dst_hi[o] = h;
+  dst_lo[o] = l;
+}
+hipError_t launch_pack_weight(const float* src, int C, int T, int Cp, const int* row_map, int rows_p, bf16_t* dst_hi,
+                              bf16_t* dst_lo, int ldk, int k_off, hipStream_t s) {
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((T * Cp + 255) / 256, rows_p), dim3(256), 0, s, src, C, T, Cp, row_map,
+                     rows_p, dst_hi, dst_lo, ldk, k_off);
+  return hipGetLastError();
+}
+
+}  // namespace ns2

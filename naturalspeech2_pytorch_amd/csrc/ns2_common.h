@@ -1,0 +1,52 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libns2hip.
+//
+// Activation / weight storage format ("split planes"): every GEMM operand is held as two bf16 planes,
+// hi = bf16_rne(x) and lo = bf16_rne(x - float(hi)).  A product of two split operands is evaluated as
+// hi*hi + hi*lo + lo*hi on the bf16 MFMA pipe with fp32 accumulation (3 MFMAs, relative error ~2^-16 per
+// product => fp32-class results); the "fast" mode uses the hi plane only (1 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                           // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;          // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16;         // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define NS2_DEVINL __device__ __forceinline__
+
+// fp32 -> bf16 (round to nearest even); NaN kept quiet.
+NS2_DEVINL bf16_t f2bf(float x) {
+  uint32_t u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+NS2_DEVINL float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// split x into (hi, lo) bf16
+NS2_DEVINL void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = f2bf(x);
+  lo = f2bf(x - bf2f(hi));
+}
+
+NS2_DEVINL uint32_t pack2(bf16_t a, bf16_t b) { return (uint32_t)a | ((uint32_t)b << 16); }
+
+NS2_DEVINL float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+NS2_DEVINL float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+NS2_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+NS2_DEVINL float siluf(float x) { return x / (1.0f + expf(-x)); }
+
+// XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive ids land on one XCD's L2.
+NS2_DEVINL int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  int q = nwg / nx, r = nwg % nx;
+  int xcd = bid % nx, idx = bid / nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

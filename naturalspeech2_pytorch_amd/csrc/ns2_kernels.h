@@ -1,0 +1,129 @@
+// Internal (C++) launcher interface of libns2hip: one launcher per HIP kernel family.
+// The public C ABI is include/ns2hip.h; csrc/capi.cpp and csrc/model_exec.cpp sit on top of these.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+
+namespace ns2 {
+
+enum GemmEpilogue : int {
+  EPI_F32 = 0,      // out_f = acc + bias (+ resid)
+  EPI_SPLIT = 1,    // split planes = acc + bias
+  EPI_QKV = 2,      // columns < split_col -> split planes, columns >= split_col -> transposed planes V^T[b][feat][n]
+  EPI_GEGLU = 3,    // packed [x|gate] wave tiles -> split planes gelu(gate)*x
+  EPI_WAVENET = 4,  // mid-loop FiLM + tanh*sigmoid gate, second K phase = res conv, split planes out
+};
+
+struct GemmArgs {
+  // A operand: activations, bf16 split planes [M, lda]
+  const bf16_t* a_hi; const bf16_t* a_lo; int lda;
+  // W operand: packed weights, bf16 split planes [ceil(N/128)*128, ldw], K contiguous
+  const bf16_t* w_hi; const bf16_t* w_lo; int ldw;
+  int M, N;          // N = valid output columns
+  int nkt;           // number of 32-wide K tiles (total, all taps/phases)
+  int kt_per_tap;    // K tiles per tap (plain linear: == nkt)
+  int conv_taps;     // taps [0, conv_taps) are causal-shifted by (conv_taps-1-tap)*dil rows; later taps unshifted
+  int dil; int dil_z;// dilation; if dil_z the effective dilation is dil << blockIdx-z
+  int seq_len;       // tokens per utterance (rows never read across an utterance start); 0 = no sequence structure
+  int mid_kt;        // EPI_WAVENET: K tile index at which the gate transform runs
+  int epi;
+  // epilogue operands
+  const float* bias; const float* bias2;
+  const float* film; int film_ld;           // gamma at film[b*film_ld + col], beta at film[b*film_ld + N + col]
+  const float* resid; int ldr;
+  float* out_f; int ldo_f;
+  bf16_t* out_hi; bf16_t* out_lo; int ldo_s; int out_ncols;   // writes columns [0, out_ncols) (zero beyond N)
+  bf16_t* vt_hi; bf16_t* vt_lo; int vt_ld; int vt_rows; int split_col;
+  // batching over blockIdx-z (wavenet columns): element offsets per z
+  int nz; long a_zs, w_zs, bias_zs, film_zs, out_zs;
+};
+
+hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s);
+
+// flash attention forward, head dim 64, non-causal (ATT:77-155 hot path)
+struct AttnArgs {
+  const bf16_t* q_hi; const bf16_t* q_lo; int ldq;     // [B*Nq, ldq], head h at columns q_col0 + 64h
+  const bf16_t* k_hi; const bf16_t* k_lo; int ldk;     // [B*Nk, ldk], head h at columns k_col0 + 64h
+  const bf16_t* vt_hi; const bf16_t* vt_lo; int vt_ld; // [B][H*64][vt_ld] transposed values
+  bf16_t* o_hi; bf16_t* o_lo; int ldo;                 // [B*Nq, ldo], head h at columns 64h
+  int q_col0, k_col0;
+  int B, H, Nq, Nk;
+  float scale;
+};
+hipError_t launch_attention(const AttnArgs& a, int nsplit, hipStream_t s);
+
+// RMSNorm (NS2:727-746): out = x / max(|x|, 1e-12) * sqrt(d) [* gamma] [* g_c + b_c]  -> split planes
+struct NormArgs {
+  const float* x; int ldx;           // [M, d]
+  const float* gamma;                // [d] or null
+  const float* cond; int cond_ld;    // adaptive: g_c = cond[b*cond_ld + c], b_c = cond[b*cond_ld + d + c]; null = plain
+  bf16_t* out_hi; bf16_t* out_lo; int ldo;
+  float* out_f; int ldo_f;           // optional fp32 copy (e.g. resampler output)
+  int M, d, seq_len;
+};
+hipError_t launch_rmsnorm(const NormArgs& a, hipStream_t s);
+
+// x (+ add) -> split planes, with optional zero padding to ldo columns
+hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, int add_rows_per_batch, int add_valid_rows,
+                        bf16_t* out_hi, bf16_t* out_lo, int ldo, int M, int d, int seq_len, hipStream_t s);
+
+// LearnedSinusoidalPosEmb + Linear(d+1, dt) + SiLU (NS2:108-120, 839-843): times[B] -> out[B, ld_out] columns [0, dt)
+// wt is the Linear weight stored K-major [dim+1, dt]; feat_ws is a [B, dim+1] fp32 scratch.
+hipError_t launch_time_embed(const float* times, const float* freqs, const float* wt, const float* bias, float* feat_ws,
+                             float* out, int ld_out, int B, int dim, int dt, hipStream_t s);
+
+// out[b, j] = act( sum_k in[b,k] * wt[k, j] + bias[j] ), wt stored K-major ([K, J]); act 0 none, 1 SiLU
+hipError_t launch_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out,
+                                int B, int K, int J, int act, hipStream_t s);
+
+// batched fp32 [R, C] -> [C, R]
+hipError_t launch_transpose_f32(const float* in, int batch, int R, int C, float* out, hipStream_t s);
+
+// mean over n of [B, n, d] -> [B, d]
+hipError_t launch_mean_rows(const float* in, int B, int n, int d, float* out, hipStream_t s);
+
+// out[b*ld_out + e] = src[e] for e < row_elems (broadcast a parameter row over the batch)
+hipError_t launch_bcast_rows(const float* src, float* out, int B, long row_elems, long ld_out, hipStream_t s);
+
+hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s);
+hipError_t launch_transpose_into(const float* src, int R, int C, float* dst, long ld_dst, long col_off, hipStream_t s);
+
+// DDIM update (NS2:1396-1429), objective 'v'/'eps'/'x0', sigmoid/cosine/linear schedule evaluated on device
+struct DdimArgs {
+  float* audio; const float* model_out; float* out;   // [B, n*d]; out may alias audio
+  const float* times; const float* times_next;        // [B]
+  int B; long per_batch;
+  int objective;     // 0 'v', 1 'eps', 2 'x0'
+  int schedule;      // 0 sigmoid, 1 cosine, 2 linear
+  float scale;
+};
+hipError_t launch_ddim(const DdimArgs& a, hipStream_t s);
+
+// CFG mix: out = null + (cond - null) * scale   (NS2:927)
+hipError_t launch_cfg_mix(const float* cond, const float* null, float* out, long n, float scale, hipStream_t s);
+
+// weight packing: fp32 [rows, C, T] (T taps, 1 for linear) -> split planes [rows_p, T*Cp]; row_map[r] = source row or -1
+hipError_t launch_pack_weight(const float* src, int C, int T, int Cp, const int* row_map, int rows_p, bf16_t* dst_hi,
+                              bf16_t* dst_lo, int ldk, int k_off, hipStream_t s);
+
+// EnCodec residual VQ encode (HFENC:364-369, 424-447)
+struct RvqArgs {
+  const float* x;            // [M, D] latents
+  const float* codebooks;    // [Q, C, D]
+  const float* cb_norm;      // [Q, C] 0.5*|e|^2 (from launch_rvq_prepare)
+  int64_t* codes;            // [M, Q]
+  float* emb;                // [M, D] sum of selected codes (may be null)
+  float* residual;           // [M, D] final residual (may be null)
+  int* near_tie_count;       // optional counter of fp64 re-checks taken
+  int M, Q, C, D;
+  float tie_eps;
+};
+hipError_t launch_rvq_prepare(const float* codebooks, float* cb_norm, int Q, int C, int D, hipStream_t s);
+hipError_t launch_rvq_encode(const RvqArgs& a, hipStream_t s);
+// decode: emb[m] = sum_q codebooks[q][codes[m][q]]  (HFENC:440-447)
+hipError_t launch_rvq_decode(const int64_t* codes, const float* codebooks, float* emb, int M, int Q, int C, int D,
+                             hipStream_t s);
+
+}  // namespace ns2

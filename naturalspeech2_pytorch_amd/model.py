@@ -1,0 +1,343 @@
+"""`Model` — drop-in for the reference denoiser class (NS2:811-1000) whose inference forward runs entirely in the
+hand-written HIP kernels of libns2hip (csrc/model_exec.cpp enqueues the whole step on the current HIP stream).
+
+Boundary kept from the reference:
+  * constructor signature NS2:814-831, attributes `.dim`, `.condition_on_prompt`, `.cond_drop_prob`, `.device`;
+  * `forward(x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None)` NS2:929-937 and
+    `forward_with_cond_scale(*args, cond_scale=1., **kwargs)` NS2:914-927;
+  * `state_dict()` key names and shapes (checked against the reference's in tests/test_model_cpu.py), so
+    reference checkpoints load unchanged;  survives copy.deepcopy (EMA, NS2:1793-1798).
+
+The parameter-holder modules below exist only to own same-named parameters with the reference's default
+initialisation; their arithmetic lives in HIP.  PyTorch provides device memory and the stream, nothing else.
+"""
+import ctypes
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import ModelConfig, check
+
+
+# ------------------------------------------------------------------------------------------ parameter holders
+class _Holder(nn.Module):
+    """container whose children are registered under explicit (possibly numeric) names; None entries are skipped
+    exactly like the reference's `Sequential` helper drops them."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for k, v in children.items():
+            if v is not None:
+                self.add_module(k.lstrip("_"), v)
+
+
+def _seq(*mods):
+    h = _Holder()
+    i = 0
+    for m in mods:
+        if m is None:
+            continue
+        h.add_module(str(i), m)
+        i += 1
+    return h
+
+
+class _NoParams(nn.Module):      # stands in for parameter-free reference modules (Rearrange, GEGLU, SiLU, Reduce)
+    pass
+
+
+class _SinusoidalWeights(nn.Module):                       # LearnedSinusoidalPosEmb NS2:108-113
+    def __init__(self, dim):
+        super().__init__()
+        assert dim % 2 == 0
+        self.weights = nn.Parameter(torch.randn(dim // 2))
+
+
+class _RMSNorm(nn.Module):                                 # NS2:727-735
+    def __init__(self, dim, scale=True, dim_cond=None):
+        super().__init__()
+        self.to_gamma_beta = nn.Linear(dim_cond, dim * 2) if dim_cond is not None else None
+        self.gamma = nn.Parameter(torch.ones(dim)) if scale else None
+
+
+class _Attention(nn.Module):                               # NS2:1029-1053
+    def __init__(self, dim, dim_head, heads, dim_context=None):
+        super().__init__()
+        inner = dim_head * heads
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_kv = nn.Linear(dim_context or dim, inner * 2, bias=False)
+        self.to_out = nn.Linear(inner, dim, bias=False)
+
+
+def _feedforward(dim, mult, causal_conv):                  # NS2:1009-1025
+    inner = int(dim * mult * 2 / 3)
+    conv = _seq(_NoParams(), nn.Conv1d(inner, inner, 3), _NoParams()) if causal_conv else None
+    return _seq(nn.Linear(dim, inner * 2), _NoParams(), conv, nn.Linear(inner, dim))
+
+
+class _WavenetBlock(nn.Module):                            # NS2:597-620
+    def __init__(self, dim, dilation, skip, dim_cond_mult):
+        super().__init__()
+        self.to_time_cond = nn.Linear(dim * dim_cond_mult, dim * 2)
+        self.conv = nn.Conv1d(dim, dim, 3, dilation=dilation)
+        self.res_conv = nn.Conv1d(dim, dim, 1)
+        self.skip_conv = nn.Conv1d(dim, dim, 1) if skip else None
+
+
+class _NativeState:
+    """ctypes handle + caches; never copied (a deep copy re-packs lazily from its own parameters)."""
+
+    def __init__(self):
+        self.handle = None
+        self.sig = None
+        self.ws = None
+        self.cond_cache = {}
+        self.keepalive = None
+
+    def __deepcopy__(self, memo):
+        return _NativeState()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
+    def release(self):
+        if self.handle is not None:
+            try:
+                _lib.load().ns2_model_destroy(self.handle)
+            except Exception:
+                pass
+        self.handle = None
+        self.cond_cache = {}
+
+    def __del__(self):
+        self.release()
+
+
+# ------------------------------------------------------------------------------------------ Model
+class Model(nn.Module):
+    def __init__(
+        self,
+        dim,
+        *,
+        depth,
+        dim_head=64,
+        heads=8,
+        ff_mult=4,
+        wavenet_layers=8,
+        wavenet_stacks=4,
+        dim_cond_mult=4,
+        use_flash_attn=True,
+        dim_prompt=None,
+        num_latents_m=32,
+        resampler_depth=2,
+        cond_drop_prob=0.,
+        condition_on_prompt=False,
+        precision="exact",
+    ):
+        super().__init__()
+        assert precision in ("exact", "fast")
+        self.dim = dim
+        self.depth = depth
+        self.dim_head, self.heads, self.ff_mult = dim_head, heads, ff_mult
+        self.wavenet_layers, self.wavenet_stacks, self.dim_cond_mult_base = wavenet_layers, wavenet_stacks, dim_cond_mult
+        self.use_flash_attn = use_flash_attn          # accepted for signature parity; the HIP attention is always fused
+        self.dim_prompt = dim_prompt
+        self.num_latents_m, self.resampler_depth = num_latents_m, resampler_depth
+        self.cond_drop_prob = cond_drop_prob
+        self.condition_on_prompt = condition_on_prompt
+        self.precision = precision
+
+        dim_time = dim * dim_cond_mult
+        self.to_time_cond = _seq(_SinusoidalWeights(dim), nn.Linear(dim + 1, dim_time), _NoParams())
+
+        self.to_prompt_cond = None
+        self.null_cond = None
+        self.cond_to_model_dim = None
+        if condition_on_prompt:
+            assert dim_prompt is not None, "dim_prompt is required when condition_on_prompt=True"
+            self.null_prompt_cond = nn.Parameter(torch.randn(dim_time))
+            self.null_prompt_tokens = nn.Parameter(torch.randn(num_latents_m, dim))
+            nn.init.normal_(self.null_prompt_cond, std=0.02)
+            nn.init.normal_(self.null_prompt_tokens, std=0.02)
+            self.to_prompt_cond = _seq(_NoParams(), nn.Linear(dim_prompt, dim_time), _NoParams())
+            pr = _Holder()
+            if dim_prompt != dim:
+                pr.proj_context = nn.Linear(dim_prompt, dim)
+            pr.latents = nn.Parameter(torch.randn(num_latents_m, dim))
+            nn.init.normal_(pr.latents, std=0.02)
+            pr.layers = nn.ModuleList([
+                nn.ModuleList([_Attention(dim, dim_head, heads), _feedforward(dim, ff_mult, False)])
+                for _ in range(resampler_depth)])
+            pr.norm = _RMSNorm(dim)
+            self.perceiver_resampler = pr
+            self.cond_to_model_dim = nn.Conv1d(dim_prompt, dim, 1)
+            self.null_cond = nn.Parameter(torch.zeros(dim, 1))
+
+        cm = dim_cond_mult * (2 if condition_on_prompt else 1)      # NS2:884
+        wn = _Holder()
+        wn.init_conv = nn.Conv1d(dim, dim, 3)
+        wn.stacks = nn.ModuleList()
+        for s in range(wavenet_stacks):
+            st = _Holder()
+            st.blocks = nn.ModuleList([
+                _WavenetBlock(dim, 2 ** i, skip=(s == wavenet_stacks - 1), dim_cond_mult=cm) for i in range(wavenet_layers)])
+            wn.stacks.append(st)
+        wn.final_conv = nn.Conv1d(dim, dim, 1)
+        self.wavenet = wn
+
+        tr = _Holder()
+        tr.layers = nn.ModuleList()
+        for _ in range(depth):
+            layer = _Holder()
+            mods = [
+                _RMSNorm(dim, scale=False, dim_cond=dim * cm),
+                _Attention(dim, dim_head, heads),
+                _RMSNorm(dim, scale=False, dim_cond=dim * cm) if condition_on_prompt else None,
+                _Attention(dim, dim_head, heads) if condition_on_prompt else None,
+                _RMSNorm(dim, scale=False, dim_cond=dim * cm),
+                _feedforward(dim, ff_mult, True),
+            ]
+            for i, mod in enumerate(mods):                          # reference mlist keeps the None slots' indices
+                if mod is not None:
+                    layer.add_module(str(i), mod)
+            tr.layers.append(layer)
+        tr.to_pred = _seq(_RMSNorm(dim), nn.Linear(dim, dim, bias=False))
+        self.transformer = tr
+
+        self._native = _NativeState()
+
+    # ------------------------------------------------------------------ reference attribute surface
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    # ------------------------------------------------------------------ native plumbing
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.precision,)
+
+    def _ensure_native(self):
+        ns = self._native
+        sig = self._signature()
+        if ns.handle is not None and ns.sig == sig:
+            return ns
+        dev = self.device
+        if dev.type != "cuda":
+            raise _lib.Ns2Error("Model parameters must live on an MI355X (cuda) device: the HIP path has no CPU fallback")
+        lib = _lib.load()
+        ns.release()
+        cfg = ModelConfig(
+            dim=self.dim, depth=self.depth, dim_head=self.dim_head, heads=self.heads, ff_mult=self.ff_mult,
+            wavenet_layers=self.wavenet_layers, wavenet_stacks=self.wavenet_stacks, dim_cond_mult=self.dim_cond_mult_base,
+            condition_on_prompt=int(self.condition_on_prompt), dim_prompt=int(self.dim_prompt or 0),
+            num_latents_m=self.num_latents_m, resampler_depth=self.resampler_depth,
+            precision=3 if self.precision == "exact" else 1)
+        h = ctypes.c_void_p()
+        check(lib.ns2_model_create(ctypes.byref(cfg), ctypes.byref(h)), "ns2_model_create")
+        ns.handle = h
+        keep = []
+        with torch.cuda.device(dev):
+            for name, p in self.state_dict().items():
+                t = p.detach()
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    t = t.float().contiguous()
+                keep.append(t)
+                dims = (ctypes.c_int64 * t.ndim)(*t.shape)
+                check(lib.ns2_model_set_param(h, name.encode(), t.data_ptr(), t.ndim, dims), f"set_param {name}")
+            check(lib.ns2_model_finalize(h, torch.cuda.current_stream().cuda_stream), "ns2_model_finalize")
+        ns.keepalive = keep           # small vectors (biases, gammas, freqs) are read in place by the executor
+        ns.sig = sig
+        ns.cond_cache = {}
+        return ns
+
+    def _workspace(self, ns, B, N, n_prompt, n_cond):
+        need = _lib.load().ns2_model_workspace_bytes(ns.handle, B, N, n_prompt, n_cond)
+        if ns.ws is None or ns.ws.numel() < need or ns.ws.device != self.device:
+            ns.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ns.ws
+
+    def _cond_state(self, ns, prompt, cond, drop, B, N):
+        key = (prompt.data_ptr(), prompt._version, tuple(prompt.shape), cond.data_ptr(), cond._version, tuple(cond.shape),
+               bool(drop), B, N)
+        hit = ns.cond_cache.get(bool(drop))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        lib = _lib.load()
+        n_p, n_c = prompt.shape[1], cond.shape[2]
+        nbytes = lib.ns2_model_cond_bytes(ns.handle, B, N, n_p, n_c)
+        state = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        ws = self._workspace(ns, B, N, n_p, n_c)
+        check(lib.ns2_model_prepare_cond(ns.handle, prompt.data_ptr(), n_p, cond.data_ptr(), n_c, int(drop), B, N,
+                                         state.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+              "ns2_model_prepare_cond")
+        ns.cond_cache[bool(drop)] = (key, state, prompt, cond)     # keep the inputs alive with the cache entry
+        return state
+
+    # ------------------------------------------------------------------ forward (NS2:929-1000)
+    def forward(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .autograd_path import model_forward_autograd
+            return model_forward_autograd(self, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)
+        return self._forward_hip(x, times, prompt, prompt_mask, cond, cond_drop_prob)
+
+    @torch.no_grad()
+    def _forward_hip(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, out=None):
+        if prompt_mask is not None:
+            raise NotImplementedError("prompt_mask: no reference caller passes one (NS2:1333, 1410, 1635)")
+        p = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
+        if p not in (0, 0., 1, 1.):
+            raise NotImplementedError("the HIP inference path supports cond_drop_prob 0 or 1 (what forward_with_cond_scale uses); "
+                                      "stochastic conditioning dropout is a training-time feature (autograd path)")
+        ns = self._ensure_native()
+        assert x.ndim == 3 and x.shape[-1] == self.dim, f"x must be [b, n, {self.dim}]"
+        B, N, _ = x.shape
+        xin = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+        t = times.to(device=xin.device, dtype=torch.float32).contiguous()
+        assert t.shape == (B,)
+        out = torch.empty_like(xin) if out is None else out
+        state_ptr, n_c = None, 0
+        if self.condition_on_prompt:
+            assert prompt is not None and cond is not None, "conditional model needs prompt [b, n_p, dim_prompt] and cond [b, dim_prompt, n_c]"
+            pr = prompt if (prompt.dtype == torch.float32 and prompt.is_contiguous()) else prompt.float().contiguous()
+            cd = cond if (cond.dtype == torch.float32 and cond.is_contiguous()) else cond.float().contiguous()
+            state = self._cond_state(ns, pr, cd, p == 1, B, N)
+            state_ptr, n_c = state.data_ptr(), cd.shape[2]
+            ws = self._workspace(ns, B, N, pr.shape[1], n_c)
+        else:
+            ws = self._workspace(ns, B, N, 0, 0)
+        check(_lib.load().ns2_model_forward(ns.handle, xin.data_ptr(), t.data_ptr(), state_ptr, n_c, out.data_ptr(), B, N,
+                                            ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "ns2_model_forward")
+        return out if out.dtype == x.dtype else out.to(x.dtype)
+
+    def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
+        """NS2:914-927."""
+        logits = self.forward(*args, cond_drop_prob=0., **kwargs)
+        if cond_scale == 1.:
+            return logits
+        null_logits = self.forward(*args, cond_drop_prob=1., **kwargs)
+        if logits.is_cuda and not torch.is_grad_enabled():
+            from . import ops
+            return ops.cfg_mix(logits, null_logits, cond_scale)
+        return null_logits + (logits - null_logits) * cond_scale
+
+    # ------------------------------------------------------------------ parity-test taps
+    def debug_forward(self, x, times, taps, prompt=None, cond=None, drop=False):
+        """forward + fp32 copies of intermediate buffers; taps: {name: numel}. Test-only helper."""
+        ns = self._ensure_native()
+        lib = _lib.load()
+        bufs = {k: torch.zeros(n, dtype=torch.float32, device=self.device) for k, n in taps.items()}
+        for k, b in bufs.items():
+            check(lib.ns2_model_debug_tap(ns.handle, k.encode(), b.data_ptr(), b.numel()), "debug_tap")
+        try:
+            ns.cond_cache = {}
+            out = self._forward_hip(x, times, prompt=prompt, cond=cond, cond_drop_prob=1. if drop else 0.)
+            torch.cuda.synchronize()
+        finally:
+            for k in bufs:
+                lib.ns2_model_debug_tap(ns.handle, k.encode(), None, 0)
+        return out, bufs

@@ -1,0 +1,249 @@
+"""Thin torch-tensor wrappers over the op-level C ABI of libns2hip (include/ns2hip.h).
+
+PyTorch is plumbing here: device memory and the current HIP stream.  Every function launches hand-written HIP
+kernels through ctypes; nothing in this module computes with torch ops.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+Planes = Tuple[torch.Tensor, Optional[torch.Tensor]]     # (hi, lo) bf16 tensors of identical shape
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "expected a contiguous fp32 CUDA tensor"
+    return t
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def empty_planes(rows: int, cols: int, device, lo: bool = True) -> Planes:
+    hi = torch.empty(rows, cols, dtype=torch.bfloat16, device=device)
+    return hi, (torch.empty_like(hi) if lo else None)
+
+
+def split(x: torch.Tensor, ldo: Optional[int] = None, lo: bool = True) -> Planes:
+    """fp32 [M, d] -> bf16 split planes [M, ldo] (zero padded)."""
+    x = _f32(x)
+    M, d = x.shape
+    ldo = ldo or round_up(d, 32)
+    out = empty_planes(M, ldo, x.device, lo)
+    check(_lib.load().ns2_split_f32(x.data_ptr(), d, M, d, out[0].data_ptr(), _p(out[1]), ldo, _stream()), "ns2_split_f32")
+    return out
+
+
+def join(p: Planes, d: Optional[int] = None) -> torch.Tensor:
+    hi, lo = p
+    M, ld = hi.shape
+    d = d or ld
+    out = torch.empty(M, d, dtype=torch.float32, device=hi.device)
+    check(_lib.load().ns2_join_f32(hi.data_ptr(), _p(lo), ld, out.data_ptr(), d, M, d, _stream()), "ns2_join_f32")
+    return out
+
+
+class PackedWeight:
+    """Library-owned packed weight (ns2_weight)."""
+
+    def __init__(self, w: torch.Tensor, geglu: bool = False, extra1x1: Optional[torch.Tensor] = None):
+        import ctypes
+        w = _f32(w)
+        self.rows, self.cols = w.shape[0], w.shape[1]
+        self.taps = w.shape[2] if w.ndim == 3 else 1
+        self.geglu = geglu
+        self.has_extra = extra1x1 is not None
+        self.cols_p = round_up(self.cols, 32)
+        h = ctypes.c_void_p()
+        ex = _f32(extra1x1) if extra1x1 is not None else None
+        check(_lib.load().ns2_weight_pack(w.data_ptr(), self.rows, self.cols, self.taps, int(geglu), _p(ex), ctypes.byref(h),
+                                          _stream()), "ns2_weight_pack")
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().ns2_weight_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def linear_f32(w: PackedWeight, a: Planes, M: Optional[int] = None, bias=None, resid=None, conv_taps=0, dilation=1,
+               seq_len=0, precision=3) -> torch.Tensor:
+    hi, lo = a
+    M = M or hi.shape[0]
+    out = torch.empty(M, w.rows, dtype=torch.float32, device=hi.device)
+    check(_lib.load().ns2_linear_f32(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, conv_taps, dilation, seq_len, _p(bias),
+                                     _p(resid), w.rows, out.data_ptr(), w.rows, precision, _stream()), "ns2_linear_f32")
+    return out
+
+
+def linear_split(w: PackedWeight, a: Planes, bias=None, conv_taps=0, dilation=1, seq_len=0, precision=3, ldo=None) -> Planes:
+    hi, lo = a
+    M = hi.shape[0]
+    ldo = ldo or round_up(w.rows, 32)
+    out = empty_planes(M, ldo, hi.device)
+    check(_lib.load().ns2_linear_split(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, conv_taps, dilation, seq_len, _p(bias),
+                                       out[0].data_ptr(), out[1].data_ptr(), ldo, precision, _stream()), "ns2_linear_split")
+    return out
+
+
+def geglu_pack_bias(bias: torch.Tensor, f: int) -> torch.Tensor:
+    n = round_up(2 * round_up(f, 32), 128)
+    out = torch.empty(n, dtype=torch.float32, device=bias.device)
+    check(_lib.load().ns2_geglu_pack_bias(_f32(bias).data_ptr(), f, out.data_ptr(), n, _stream()), "ns2_geglu_pack_bias")
+    return out
+
+
+def linear_geglu(w: PackedWeight, a: Planes, packed_bias: torch.Tensor, precision=3) -> Planes:
+    hi, lo = a
+    M = hi.shape[0]
+    f = w.rows // 2
+    ldo = round_up(f, 32)
+    out = empty_planes(M, ldo, hi.device)
+    check(_lib.load().ns2_linear_geglu(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, packed_bias.data_ptr(), out[0].data_ptr(),
+                                       out[1].data_ptr(), ldo, precision, _stream()), "ns2_linear_geglu")
+    return out
+
+
+def linear_qkv(w: PackedWeight, a: Planes, seq_len: int, split_col: int, precision=3):
+    """returns (row-major planes [M, split_col], transposed planes [B, rows - split_col, vt_ld])."""
+    hi, lo = a
+    M = hi.shape[0]
+    B = M // seq_len
+    vt_ld = round_up(seq_len, 8)
+    out = empty_planes(M, split_col, hi.device)
+    vt_rows = w.rows - split_col
+    vt_hi = torch.zeros(B, vt_rows, vt_ld, dtype=torch.bfloat16, device=hi.device)
+    vt_lo = torch.zeros_like(vt_hi)
+    check(_lib.load().ns2_linear_qkv(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, seq_len, split_col, out[0].data_ptr(),
+                                     out[1].data_ptr(), split_col, vt_hi.data_ptr(), vt_lo.data_ptr(), vt_ld, precision, _stream()),
+          "ns2_linear_qkv")
+    return out, (vt_hi, vt_lo)
+
+
+def wavenet_block(w: PackedWeight, a: Planes, seq_len: int, dilation: int, conv_bias, res_bias, film: torch.Tensor,
+                  precision=3) -> Planes:
+    hi, lo = a
+    M = hi.shape[0]
+    ldo = round_up(w.rows, 32)
+    out = empty_planes(M, ldo, hi.device)
+    check(_lib.load().ns2_wavenet_block(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, seq_len, dilation, conv_bias.data_ptr(),
+                                        res_bias.data_ptr(), _f32(film).data_ptr(), film.shape[1], out[0].data_ptr(),
+                                        out[1].data_ptr(), ldo, precision, _stream()), "ns2_wavenet_block")
+    return out
+
+
+def attention(q: Planes, k: Planes, vt: Planes, B: int, H: int, Nq: int, Nk: int, q_col0=0, k_col0=0, scale=0.125,
+              precision=3) -> Planes:
+    out = empty_planes(B * Nq, H * 64, q[0].device)
+    check(_lib.load().ns2_attention(q[0].data_ptr(), _p(q[1]), q[0].shape[1], q_col0, k[0].data_ptr(), _p(k[1]), k[0].shape[1],
+                                    k_col0, vt[0].data_ptr(), _p(vt[1]), vt[0].shape[-1], out[0].data_ptr(), out[1].data_ptr(),
+                                    H * 64, B, H, Nq, Nk, scale, precision, _stream()), "ns2_attention")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, seq_len: int = 0, gamma=None, cond=None, want_f32=False):
+    x = _f32(x)
+    M, d = x.shape
+    ldo = round_up(d, 32)
+    out = empty_planes(M, ldo, x.device)
+    of = torch.empty(M, d, dtype=torch.float32, device=x.device) if want_f32 else None
+    check(_lib.load().ns2_rmsnorm(x.data_ptr(), d, M, d, seq_len, _p(gamma), _p(cond), cond.shape[1] if cond is not None else 0,
+                                  out[0].data_ptr(), out[1].data_ptr(), ldo, _p(of), d, _stream()), "ns2_rmsnorm")
+    return (out, of) if want_f32 else out
+
+
+def skinny_linear(x: torch.Tensor, wt: torch.Tensor, bias=None, act=0) -> torch.Tensor:
+    """x [B, K] @ wt [K, J] (+bias) ; act 1 = SiLU."""
+    x, wt = _f32(x), _f32(wt)
+    B, K = x.shape
+    J = wt.shape[1]
+    out = torch.empty(B, J, dtype=torch.float32, device=x.device)
+    check(_lib.load().ns2_skinny_linear(x.data_ptr(), K, wt.data_ptr(), _p(bias), out.data_ptr(), J, B, K, J, act, _stream()),
+          "ns2_skinny_linear")
+    return out
+
+
+def time_embed(times: torch.Tensor, freqs: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    B = times.shape[0]
+    dim = freqs.shape[0] * 2
+    dt = wt.shape[1]
+    feat = torch.empty(B, dim + 1, dtype=torch.float32, device=times.device)
+    out = torch.empty(B, dt, dtype=torch.float32, device=times.device)
+    check(_lib.load().ns2_time_embed(_f32(times).data_ptr(), _f32(freqs).data_ptr(), _f32(wt).data_ptr(), _f32(bias).data_ptr(),
+                                     feat.data_ptr(), out.data_ptr(), dt, B, dim, dt, _stream()), "ns2_time_embed")
+    return out
+
+
+OBJECTIVES = {"v": 0, "eps": 1, "x0": 2}
+SCHEDULES = {"sigmoid": 0, "cosine": 1, "linear": 2}
+
+
+def ddim_step(audio, model_out, times, times_next, objective="v", schedule="sigmoid", scale=1.0, out=None):
+    audio, model_out = _f32(audio), _f32(model_out)
+    B = audio.shape[0]
+    per = audio.numel() // B
+    out = torch.empty_like(audio) if out is None else out
+    check(_lib.load().ns2_ddim_step(audio.data_ptr(), model_out.data_ptr(), out.data_ptr(), _f32(times).data_ptr(),
+                                    _f32(times_next).data_ptr(), B, per, OBJECTIVES[objective], SCHEDULES[schedule], float(scale),
+                                    _stream()), "ns2_ddim_step")
+    return out
+
+
+def cfg_mix(cond_out, null_out, cond_scale: float, out=None):
+    out = torch.empty_like(cond_out) if out is None else out
+    check(_lib.load().ns2_cfg_mix(_f32(cond_out).data_ptr(), _f32(null_out).data_ptr(), out.data_ptr(), cond_out.numel(),
+                                  float(cond_scale), _stream()), "ns2_cfg_mix")
+    return out
+
+
+def rvq_prepare(codebooks: torch.Tensor) -> torch.Tensor:
+    cb = _f32(codebooks)
+    Q, C, D = cb.shape
+    out = torch.empty(Q, C, dtype=torch.float32, device=cb.device)
+    check(_lib.load().ns2_rvq_prepare(cb.data_ptr(), out.data_ptr(), Q, C, D, _stream()), "ns2_rvq_prepare")
+    return out
+
+
+def rvq_encode(x: torch.Tensor, codebooks: torch.Tensor, cb_norm: Optional[torch.Tensor] = None, tie_eps: float = 1e-4,
+               want_residual=False, count_ties=False):
+    """x [M, 128] fp32, codebooks [Q, C, 128] -> codes [M, Q] int64, emb [M, 128] (, residual, n_near_ties)."""
+    x, cb = _f32(x), _f32(codebooks)
+    M, D = x.shape
+    Q, C, _ = cb.shape
+    cb_norm = rvq_prepare(cb) if cb_norm is None else cb_norm
+    codes = torch.empty(M, Q, dtype=torch.int64, device=x.device)
+    emb = torch.empty(M, D, dtype=torch.float32, device=x.device)
+    resid = torch.empty(M, D, dtype=torch.float32, device=x.device) if want_residual else None
+    ties = torch.zeros(1, dtype=torch.int32, device=x.device) if count_ties else None
+    check(_lib.load().ns2_rvq_encode(x.data_ptr(), cb.data_ptr(), cb_norm.data_ptr(), codes.data_ptr(), emb.data_ptr(), _p(resid),
+                                     _p(ties), M, Q, C, D, float(tie_eps), _stream()), "ns2_rvq_encode")
+    res = [codes, emb]
+    if want_residual:
+        res.append(resid)
+    if count_ties:
+        res.append(ties)
+    return tuple(res)
+
+
+def rvq_decode(codes: torch.Tensor, codebooks: torch.Tensor) -> torch.Tensor:
+    cb = _f32(codebooks)
+    Q, C, D = cb.shape
+    M = codes.shape[0]
+    emb = torch.empty(M, D, dtype=torch.float32, device=cb.device)
+    check(_lib.load().ns2_rvq_decode(codes.contiguous().data_ptr(), cb.data_ptr(), emb.data_ptr(), M, Q, C, D, _stream()),
+          "ns2_rvq_decode")
+    return emb
