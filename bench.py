@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): denoise steps/sec for Model(dim=512, depth=12) on 32 x 1024 codec-latent frames.
+
+One step = Model.forward_with_cond_scale (cond_scale 1 -> one Model.forward, NS2:914-927) + the DDIM update
+(NS2:1396-1430) on one batch of 32 synthetic utterances, inputs resident in HBM.  N GPUs = N data-parallel
+replicas each denoising its own 32-utterance shard (weak scaling; no data-path collective inside the loop; the
+path's single RCCL all-gather of the generated latents runs once after the K steps and is inside the timed region).
+
+    python bench.py [--gpus N --steps K --warmup W] [--precision exact|fast] [--graph]
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events recorded by the executor on the
+launch stream around every launch of the dominant kernel symbol (gemm_kernel<NSPLIT, EPI_SPLIT>: the 12 FF causal
+convs + wavenet init conv + skip GEMM); `cpu_baseline` times the CPU oracle (a port of the reference path) on a
+bounded sample.  See DESIGN.md §Measurement.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md (spec; 2495 measured)
+UTT_GFLOP = 316.37                 # algorithmic GFLOP per 1024-frame utterance, d512/L12 unconditioned
+
+
+def dominant_flops(B, N, dim, depth, ff_mult, wn_layers):
+    """algorithmic FLOPs (2*MAC) of the launches of gemm_kernel<*, EPI_SPLIT> in one step, and their count."""
+    M = B * N
+    f = int(dim * ff_mult * 2 / 3)
+    ffconv = 2.0 * M * f * (3 * f)                 # CausalConv1d(f, f, 3)  NS2:1016
+    init = 2.0 * M * dim * (3 * dim)               # wavenet.init_conv      NS2:701
+    skip = 2.0 * M * dim * (wn_layers * dim)       # 8 skip convs summed    NS2:639-640, 725
+    return depth * ffconv + init + skip, depth + 2
+
+
+def cpu_baseline(dim, depth, n, threads_note=""):
+    """CPU oracle (port of NS2:929-1000) on a bounded sample: batch 4 of the same workload, all host threads."""
+    from oracle import ns2_oracle as O
+    from naturalspeech2_pytorch_amd import Model
+    torch.manual_seed(0)
+    m = Model(dim=dim, depth=depth)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    b = 4
+    x = torch.randn(b, n, dim)
+    t = torch.rand(b)
+    with torch.no_grad():
+        O.model_forward(sd, x, t)                   # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            O.model_forward(sd, x, t)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > 12.0 or reps >= 8:
+                break
+    per_fwd = el / reps
+    steps_per_s = (b / 32.0) / per_fwd              # one step = 32 utterances
+    return dict(value=round(steps_per_s, 5), unit="steps/s (32x1024-latent batch equivalent)", cores=torch.get_num_threads(),
+                kind="port", sample=f"oracle Model.forward fp32, batch {b} x {n} frames, {reps} timed forwards after 1 warm-up "
+                                    f"({per_fwd:.3f} s each); steps/s scaled by {b}/32")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph (no live per-kernel events)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from naturalspeech2_pytorch_amd import Model, _lib, ops
+    from naturalspeech2_pytorch_amd import distributed as D
+    import torch.distributed as dist
+
+    rank, local, world = D.init_from_env()
+    if args.gpus != world:
+        assert world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        assert args.gpus == 1, "for N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ..."
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    B, N, dim, depth = args.batch, args.frames, args.dim, args.depth
+    torch.manual_seed(1234)                          # same random-init weights on every rank
+    model = Model(dim=dim, depth=depth, precision=args.precision).to(dev).eval()
+    g = torch.Generator().manual_seed(100 + rank)
+    audio = torch.randn(B, N, dim, generator=g).to(dev)
+    n_total = args.warmup + args.steps
+    ts = torch.linspace(1.0, 0.0, n_total + 1)
+    t_dev = [ts[i].expand(B).contiguous().to(dev) for i in range(n_total + 1)]
+    lib = _lib.load()
+
+    t_cur, t_nxt = t_dev[0].clone(), t_dev[1].clone()
+
+    def step():
+        out = model.forward_with_cond_scale(audio, t_cur, cond_scale=1.0)
+        ops.ddim_step(audio, out, t_cur, t_nxt, "v", "sigmoid", 1.0, out=audio)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        graph = None
+        for i in range(args.warmup):
+            t_cur.copy_(t_dev[i]); t_nxt.copy_(t_dev[i + 1])
+            step()
+        if args.graph:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            keep = audio.clone()
+            with torch.cuda.graph(graph):
+                step()
+            audio.copy_(keep)
+        ns = model._ensure_native()
+        prof_mask = 0 if args.graph else (1 << 1)    # gemm_kernel<*, EPI_SPLIT>
+        barrier()
+        if prof_mask:
+            lib.ns2_model_profile_begin(ns.handle, prof_mask)
+        t0 = time.perf_counter()
+        for i in range(args.warmup, n_total):
+            t_cur.copy_(t_dev[i]); t_nxt.copy_(t_dev[i + 1])
+            if graph is not None:
+                graph.replay()
+            else:
+                step()
+        if world > 1:                                # the sharded sampler's single collective
+            bufs = [torch.empty_like(audio) for _ in range(world)]
+            dist.all_gather(bufs, audio)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kern_ms, kern_n = ctypes.c_double(0), ctypes.c_int64(0)
+        if prof_mask:
+            _lib.check(lib.ns2_model_profile_end(ns.handle, ctypes.byref(kern_ms), ctypes.byref(kern_n)), "profile_end")
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = el.item()
+    assert torch.isfinite(audio).all()
+
+    if rank == 0:
+        steps_per_s = world * args.steps / elapsed
+        fl, nl = dominant_flops(B, N, dim, depth, 4, 8)
+        roof = None
+        if kern_n.value:
+            avg_ms = kern_ms.value / kern_n.value
+            ach = (fl / nl) / (avg_ms * 1e-3) / 1e12
+            traffic = None
+            pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(pj):
+                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+            roof = dict(bound="mfma", kernel="ns2::gemm_kernel<%d, EPI_SPLIT> (FF causal conv k3 x%d, wavenet init conv, skip-sum GEMM)"
+                        % (3 if args.precision == "exact" else 1, depth),
+                        achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                        traffic=traffic, avg_launch_ms=round(avg_ms, 4), launches=kern_n.value,
+                        algorithmic_gflop_per_launch=round(fl / nl / 1e9, 2),
+                        mfma_flops_per_algorithmic_flop=3 if args.precision == "exact" else 1)
+        whole = None
+        if dim == 512 and depth == 12 and N == 1024:
+            whole = round(UTT_GFLOP * B * 1e9 / (elapsed / args.steps) / 1e12, 2)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(dim, depth, N)
+        line = {
+            "metric": "denoise steps/sec (dim=512 depth=12, B=32x1024 latents)", "value": round(steps_per_s, 3), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3 split operands on bf16 MFMA, fp32 accumulate (fp32-class, <=1e-3 vs fp32 reference)"
+                     if args.precision == "exact" else "bf16 operands, fp32 accumulate",
+            "data": "synthetic (randn codec latents, random-init weights)",
+            "config": {"workload": f"Model(dim={dim}, depth={depth}) unconditional, batch {B} x {N} latent frames per GPU, "
+                                   f"forward_with_cond_scale(cond_scale=1) + DDIM update", "precision": args.precision,
+                       "global_batch": B * world, "parallelism": f"dp{world}", "graph_replay": bool(args.graph)},
+            "whole_step_algorithmic_tflops_per_gpu": whole,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["gpu_over_cpu"] = round(steps_per_s / cpu["value"], 1)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

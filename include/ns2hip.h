@@ -132,6 +132,11 @@ int ns2_model_forward(ns2_model* m, const float* x, const float* times, const vo
 /* optional intermediate taps for parity tests (fp32 copies made during forward / prepare_cond): "t", "c",
  * "wavenet.init", "wavenet.stack<s>", "wavenet.out", "layer<i>.attn", "layer<i>"; dst = null unregisters */
 int ns2_model_debug_tap(ns2_model* m, const char* name, float* dst, int64_t dst_elems);
+/* live kernel timing with HIP events on the caller's stream (bench.py roofline): category bits
+ * 0 gemm<f32 epilogue> 1 gemm<split epilogue> 2 gemm<qkv> 3 gemm<geglu> 4 gemm<wavenet> 5 attention 6 rmsnorm.
+ * _end synchronises on the recorded events and returns the summed kernel time and the number of launches. */
+int ns2_model_profile_begin(ns2_model* m, unsigned category_mask);
+int ns2_model_profile_end(ns2_model* m, double* total_ms, int64_t* launches);
 void ns2_model_destroy(ns2_model* m);
 
 #ifdef __cplusplus

@@ -58,6 +58,8 @@ SIGNATURES = {
     "ns2_model_prepare_cond": (I, [P, P, I, P, I, I, I, I, P, P, L, P]),
     "ns2_model_forward": (I, [P, P, P, P, I, P, I, I, P, L, P]),
     "ns2_model_debug_tap": (I, [P, c_char_p, P, L]),
+    "ns2_model_profile_begin": (I, [P, ctypes.c_uint]),
+    "ns2_model_profile_end": (I, [P, POINTER(ctypes.c_double), POINTER(c_int64)]),
     "ns2_model_destroy": (None, [P]),
 }
 

@@ -38,6 +38,9 @@ namespace ns2 {
     if (_r != NS2_OK) return _r;     \
   } while (0)
 
+// kernel categories for ns2_model_profile_* (== kernel symbols in a rocprofv3 trace)
+enum { PC_GEMM_F32 = 0, PC_GEMM_SPLIT = 1, PC_GEMM_QKV = 2, PC_GEMM_GEGLU = 3, PC_GEMM_WAVENET = 4, PC_ATTENTION = 5, PC_NORM = 6 };
+
 static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t rup64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -78,6 +81,9 @@ struct ns2_model {
   const float* g_resampler;
   // debug taps
   std::map<std::string, std::pair<float*, int64_t>> taps;
+  // live kernel timing (bench.py roofline): HIP events around the launches of the selected kernel categories
+  unsigned prof_mask = 0; size_t prof_used = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 };
 
 namespace ns2 {
@@ -273,6 +279,7 @@ extern "C" int ns2_model_set_param(ns2_model* m, const char* name, const float* 
 
 extern "C" void ns2_model_destroy(ns2_model* m) {
   if (!m) return;
+  for (auto& e : m->prof_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   for (void* p : m->owned) hipFree(p);
   delete m;
 }
@@ -634,6 +641,53 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
   return NS2_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ live profiling
+static int prof_start(ns2_model* m, int cat, hipStream_t s) {
+  if (!(m->prof_mask & (1u << cat))) return NS2_OK;
+  if (m->prof_used == m->prof_events.size()) {
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    m->prof_events.push_back(std::make_pair(a, b));
+  }
+  HIPCHK(hipEventRecord(m->prof_events[m->prof_used].first, s));
+  return NS2_OK;
+}
+static int prof_stop(ns2_model* m, int cat, hipStream_t s) {
+  if (!(m->prof_mask & (1u << cat))) return NS2_OK;
+  HIPCHK(hipEventRecord(m->prof_events[m->prof_used].second, s));
+  m->prof_used++;
+  return NS2_OK;
+}
+#define PROF(cat, call)                 \
+  do {                                  \
+    NSCHK(prof_start(m, cat, s));       \
+    NSCHK(call);                        \
+    NSCHK(prof_stop(m, cat, s));        \
+  } while (0)
+
+extern "C" int ns2_model_profile_begin(ns2_model* m, unsigned category_mask) {
+  if (!m) return NS2_ERR_ARG;
+  m->prof_mask = category_mask;
+  m->prof_used = 0;
+  return NS2_OK;
+}
+extern "C" int ns2_model_profile_end(ns2_model* m, double* total_ms, int64_t* launches) {
+  if (!m || !total_ms || !launches) return NS2_ERR_ARG;
+  double tot = 0.0;
+  for (size_t i = 0; i < m->prof_used; ++i) {
+    HIPCHK(hipEventSynchronize(m->prof_events[i].second));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, m->prof_events[i].first, m->prof_events[i].second));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)m->prof_used;
+  m->prof_mask = 0;
+  m->prof_used = 0;
+  return NS2_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* times, const void* cond_state, int n_cond, float* out,
                                  int B, int N, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -665,7 +719,7 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
   HIPCHK(launch_split(x, dim, cond ? cs.condadd : nullptr, dim, n_cond, cond ? cs.n_cond_valid : 0, w.xs.hi, w.xs.lo, dp, M, dim, N, s));
 
   // ---- wavenet (NS2:718-725)
-  NSCHK(gemm_split(m->w_init, w.xs.hi, w.xs.lo, dp, M, 3, 1, N, m->b_init, w.h0.hi, w.h0.lo, dp, prec, s));
+  PROF(PC_GEMM_SPLIT, gemm_split(m->w_init, w.xs.hi, w.xs.lo, dp, M, 3, 1, N, m->b_init, w.h0.hi, w.h0.lo, dp, prec, s));
   NSCHK(tap_planes(m, "wavenet.init", w.h0, dp, M, dim, s));
   Planes cur = w.wA, prev = w.wB;
   for (int st = 0; st < S; ++st) {
@@ -673,15 +727,15 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
     const bf16_t* a_lo = (st == 0) ? w.h0.lo : prev.lo;
     const int lda = (st == 0) ? dp : L * dp;
     const long a_zs = (st == 0) ? 0 : dp;
-    NSCHK(gemm_wavenet(m->w_wn[st], a_hi, a_lo, lda, a_zs, M, N, /*dil=*/1, /*dil_z=*/1, /*nz=*/L, m->b_wn_conv[st], m->b_wn_res[st],
+    PROF(PC_GEMM_WAVENET, gemm_wavenet(m->w_wn[st], a_hi, a_lo, lda, a_zs, M, N, /*dil=*/1, /*dil_z=*/1, /*nz=*/L, m->b_wn_conv[st], m->b_wn_res[st],
                        dim, w.condall + (size_t)st * L * 2 * dim, Jtot, 2 * dim, cur.hi, cur.lo, L * dp, dp, dp, prec, s));
     snprintf(name, sizeof name, "wavenet.stack%d", st);
     NSCHK(tap_planes(m, name, cur, L * dp, M, L * dp, s));
     Planes tmp = prev; prev = cur; cur = tmp;
   }
   // sum of the 8 skip convs == one GEMM over the concatenated columns (NS2:639-640, 685-686, 725), then final_conv
-  NSCHK(gemm_split(m->w_skip, prev.hi, prev.lo, L * dp, M, 0, 1, 0, m->b_skip, w.ssum.hi, w.ssum.lo, dp, prec, s));
-  NSCHK(gemm_f32(m->w_final, w.ssum.hi, w.ssum.lo, dp, M, 0, 1, 0, m->b_final, nullptr, 0, w.xres, dim, prec, s));
+  PROF(PC_GEMM_SPLIT, gemm_split(m->w_skip, prev.hi, prev.lo, L * dp, M, 0, 1, 0, m->b_skip, w.ssum.hi, w.ssum.lo, dp, prec, s));
+  PROF(PC_GEMM_F32, gemm_f32(m->w_final, w.ssum.hi, w.ssum.lo, dp, M, 0, 1, 0, m->b_final, nullptr, 0, w.xres, dim, prec, s));
   NSCHK(tap_f32(m, "wavenet.out", w.xres, (int64_t)M * dim, s));
 
   // ---- transformer (NS2:786-809)
@@ -690,28 +744,28 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
     const ns2_model::Layer& ly = m->layers[l];
     const float* cn = cbase + (size_t)l * m->nnorm * 2 * dim;
     // self attention
-    NSCHK(norm_call(w.xres, dim, M, dim, N, nullptr, cn, Jtot, w.xn, dp, nullptr, 0, s));
-    NSCHK(gemm_qkv(ly.qkv, w.xn.hi, w.xn.lo, dp, M, N, 2 * a, w.qk.hi, w.qk.lo, 2 * a, w.vt.hi, w.vt.lo, w.Nkp, prec, s));
-    NSCHK(attention_call(w.qk.hi, w.qk.lo, 2 * a, 0, w.qk.hi, w.qk.lo, 2 * a, a, w.vt, w.Nkp, w.o, a, B, H, N, N, prec, s));
-    NSCHK(gemm_f32(ly.out, w.o.hi, w.o.lo, a, M, 0, 1, 0, nullptr, w.xres, dim, w.xres, dim, prec, s));
+    PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn, Jtot, w.xn, dp, nullptr, 0, s));
+    PROF(PC_GEMM_QKV, gemm_qkv(ly.qkv, w.xn.hi, w.xn.lo, dp, M, N, 2 * a, w.qk.hi, w.qk.lo, 2 * a, w.vt.hi, w.vt.lo, w.Nkp, prec, s));
+    PROF(PC_ATTENTION, attention_call(w.qk.hi, w.qk.lo, 2 * a, 0, w.qk.hi, w.qk.lo, 2 * a, a, w.vt, w.Nkp, w.o, a, B, H, N, N, prec, s));
+    PROF(PC_GEMM_F32, gemm_f32(ly.out, w.o.hi, w.o.lo, a, M, 0, 1, 0, nullptr, w.xres, dim, w.xres, dim, prec, s));
     snprintf(name, sizeof name, "layer%d.attn", l);
     NSCHK(tap_f32(m, name, w.xres, (int64_t)M * dim, s));
     if (cond) {   // cross attention to the resampled prompt tokens (NS2:799-803)
-      NSCHK(norm_call(w.xres, dim, M, dim, N, nullptr, cn + 2 * dim, Jtot, w.xn, dp, nullptr, 0, s));
-      NSCHK(gemm_split(ly.cq, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, w.qk.hi, w.qk.lo, a, prec, s));
-      NSCHK(attention_call(w.qk.hi, w.qk.lo, a, 0, cs.ck[l].hi, cs.ck[l].lo, a, 0, cs.cvt[l], cs.Lmp, w.o, a, B, H, N, Lm, prec, s));
-      NSCHK(gemm_f32(ly.cout, w.o.hi, w.o.lo, a, M, 0, 1, 0, nullptr, w.xres, dim, w.xres, dim, prec, s));
+      PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + 2 * dim, Jtot, w.xn, dp, nullptr, 0, s));
+      PROF(PC_GEMM_SPLIT, gemm_split(ly.cq, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, w.qk.hi, w.qk.lo, a, prec, s));
+      PROF(PC_ATTENTION, attention_call(w.qk.hi, w.qk.lo, a, 0, cs.ck[l].hi, cs.ck[l].lo, a, 0, cs.cvt[l], cs.Lmp, w.o, a, B, H, N, Lm, prec, s));
+      PROF(PC_GEMM_F32, gemm_f32(ly.cout, w.o.hi, w.o.lo, a, M, 0, 1, 0, nullptr, w.xres, dim, w.xres, dim, prec, s));
     }
     // feedforward: Linear -> GEGLU -> causal conv k3 -> Linear (NS2:1009-1025)
-    NSCHK(norm_call(w.xres, dim, M, dim, N, nullptr, cn + (size_t)(m->nnorm - 1) * 2 * dim, Jtot, w.xn, dp, nullptr, 0, s));
-    NSCHK(gemm_geglu(ly.ffin, w.xn.hi, w.xn.lo, dp, M, ly.b_ffin, w.ffh.hi, w.ffh.lo, fp, prec, s));
-    NSCHK(gemm_split(ly.conv, w.ffh.hi, w.ffh.lo, fp, M, 3, 1, N, ly.b_conv, w.ffc.hi, w.ffc.lo, fp, prec, s));
-    NSCHK(gemm_f32(ly.ffout, w.ffc.hi, w.ffc.lo, fp, M, 0, 1, 0, ly.b_ffout, w.xres, dim, w.xres, dim, prec, s));
+    PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + (size_t)(m->nnorm - 1) * 2 * dim, Jtot, w.xn, dp, nullptr, 0, s));
+    PROF(PC_GEMM_GEGLU, gemm_geglu(ly.ffin, w.xn.hi, w.xn.lo, dp, M, ly.b_ffin, w.ffh.hi, w.ffh.lo, fp, prec, s));
+    PROF(PC_GEMM_SPLIT, gemm_split(ly.conv, w.ffh.hi, w.ffh.lo, fp, M, 3, 1, N, ly.b_conv, w.ffc.hi, w.ffc.lo, fp, prec, s));
+    PROF(PC_GEMM_F32, gemm_f32(ly.ffout, w.ffc.hi, w.ffc.lo, fp, M, 0, 1, 0, ly.b_ffout, w.xres, dim, w.xres, dim, prec, s));
     snprintf(name, sizeof name, "layer%d", l);
     NSCHK(tap_f32(m, name, w.xres, (int64_t)M * dim, s));
   }
   // to_pred: RMSNorm -> Linear (NS2:781-784)
-  NSCHK(norm_call(w.xres, dim, M, dim, N, m->g_pred, nullptr, 0, w.xn, dp, nullptr, 0, s));
-  NSCHK(gemm_f32(m->w_pred, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, nullptr, 0, out, dim, prec, s));
+  PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, m->g_pred, nullptr, 0, w.xn, dp, nullptr, 0, s));
+  PROF(PC_GEMM_F32, gemm_f32(m->w_pred, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, nullptr, 0, out, dim, prec, s));
   return NS2_OK;
 }
