@@ -29,6 +29,8 @@ extern "C" {
 
 const char* ns2_last_error(void);
 int ns2_version(void);
+/* test hook: force the GEMM kernel variant (0 = dispatch by shape, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA) */
+int ns2_debug_force_gemm(int kernel);
 
 /* ------------------------------------------------------------------ packed weights (library-owned) */
 typedef struct ns2_weight ns2_weight;

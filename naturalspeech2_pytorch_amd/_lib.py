@@ -30,6 +30,7 @@ L = c_int64
 SIGNATURES = {
     "ns2_last_error": (c_char_p, []),
     "ns2_version": (I, []),
+    "ns2_debug_force_gemm": (I, [I]),
     "ns2_weight_pack": (I, [P, I, I, I, I, P, POINTER(c_void_p), P]),
     "ns2_weight_free": (None, [P]),
     "ns2_split_f32": (I, [P, I, I, I, P, P, I, P]),

@@ -42,7 +42,12 @@ using namespace ns2;
 static inline int prec_ok(int p) { return p == 1 || p == 3; }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 100; }
+extern "C" int ns2_version(void) { return 101; }
+extern "C" int ns2_debug_force_gemm(int kernel) {
+  ARGCHK(kernel >= 0 && kernel <= 2, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
+  force_gemm_kernel(kernel);
+  return NS2_OK;
+}
 
 extern "C" int ns2_weight_pack(const float* w, int rows, int cols, int taps, int geglu, const float* extra1x1, ns2_weight** out,
                                void* stream) {
@@ -96,7 +101,7 @@ extern "C" int ns2_linear_geglu(const ns2_weight* w, const uint16_t* a_hi, const
 }
 extern "C" int ns2_geglu_pack_bias(const float* bias, int f, float* packed, int packed_len, void* stream) {
   ARGCHK(bias && packed && f > 0, "ns2_geglu_pack_bias: bad arguments");
-  const int rows_p = ((2 * ((f + 31) / 32 * 32)) + 127) / 128 * 128;
+  const int rows_p = ((2 * ((f + 31) / 32 * 32)) + 255) / 256 * 256;
   ARGCHK(packed_len >= rows_p, "ns2_geglu_pack_bias: packed_len too small");
   std::vector<float> hb(2 * f), pb(packed_len, 0.f);
   HIPRET(hipMemcpy(hb.data(), bias, 2 * f * sizeof(float), hipMemcpyDeviceToHost));

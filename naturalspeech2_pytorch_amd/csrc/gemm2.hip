@@ -1,0 +1,246 @@
+// Large-tile GEMM / causal-conv kernel for gfx950: same contract and epilogues as gemm.hip (see there), built for the
+// big token-major contractions of the denoiser (M = B*N = 32 768 rows).
+//
+// Why a second kernel: the 128x128 register-staged kernel measured 33 % of the bf16 MFMA peak and was bound by
+// (a) L2->LDS traffic (every CU re-reads 40 KB of split-plane operands per 3.1 MFLOP) and (b) exposed load latency
+// (one K-tile of look-ahead, ~770 MFMA cycles per wave to cover a ~2k-cycle load).  This kernel:
+//   * 256x256 block tile, 8 waves (2 x 4), wave tile 128x64 = 4x2 v_mfma_f32_32x32x16_bf16 accumulators:
+//     half the operand bytes per FLOP and twice the MFMA work per K-tile (48 MFMAs/wave in exact mode);
+//   * operands go global -> LDS by **LDS-DMA** (`global_load_lds_dwordx4`, 1 KiB per wave-instruction), no VGPR staging,
+//     no ds_write pass; two 64 KiB stages (128 KiB of the 160 KiB LDS), the next K-tile's DMA is issued before the
+//     current tile's MFMAs and has a full iteration (>= 3k cycles at 2 waves/SIMD) to land;
+//   * LDS image is lane-linear per DMA instruction, so bank conflicts are removed by an XOR swizzle applied to the
+//     per-lane SOURCE address and to the fragment read address (guide rule 21): 16-B chunk c of row r is stored at
+//     chunk c ^ ((r>>2)&3) (64-B rows, exact mode, BK=32) or c ^ ((r>>1)&7) (128-B rows, fast mode, BK=64);
+//   * causal-conv zero fill (rows before the utterance start) and M-edge rows are lanes whose source pointer is
+//     redirected to a 16-B zero page -- the DMA needs no predication.
+#include <cstdlib>
+
+#include "gemm_epi.h"
+
+namespace ns2 {
+
+constexpr int G2_BM = 256, G2_BN = 256;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+NS2_DEVINL void glds16(const void* gsrc, unsigned char* ldst) {
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)ldst, 16, 0, 0);
+}
+
+template <int NSPLIT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const bf16_t* __restrict__ zero_page) {
+  constexpr int NP = (NSPLIT == 3) ? 2 : 1;          // planes per operand
+  constexpr int BK = (NSPLIT == 3) ? 32 : 64;        // K-tile depth (elements)
+  constexpr int RB = BK * 2;                         // LDS row bytes (64 / 128)
+  constexpr int CPR = RB / 16;                       // 16-B chunks per row (4 / 8)
+  constexpr int RPI = 64 / CPR;                      // tile rows moved by one DMA wave-instruction (16 / 8)
+  constexpr int PLANE = G2_BM * RB;                  // 16 KiB / 32 KiB
+  constexpr int STAGE = 2 * NP * PLANE;              // 64 KiB
+  constexpr int KCH = BK / 16;                       // 16-deep MFMA K chunks per tile (2 / 4)
+  constexpr int IPP = G2_BM / RPI;                   // DMA instructions per plane (16 / 32)
+  static_assert(2 * NP * IPP == 64, "8 waves x 8 DMA instructions per K-tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const int ntn = (g.N + G2_BN - 1) / G2_BN;
+  const int ntm = (g.M + G2_BM - 1) / G2_BM;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % ntn;
+  bid /= ntn;
+  const int tm = bid % ntm;
+  const int z = bid / ntm;
+  const int dil = g.dil_z ? (g.dil << z) : g.dil;
+
+  // ---- DMA roles: instruction j = wave*8 + i ; waves 0-3 stream A, waves 4-7 stream W
+  const bool a_wave = wave < 4;
+  const int lrow = lane / CPR, pchunk = lane % CPR;
+  const bf16_t* src[8];        // per-instruction source pointer at K offset 0 (A: unshifted row)
+  int nseq[8];                 // A only: position inside the utterance (for the causal zero fill); -1 = row >= M
+  int ldst[8];                 // LDS byte offset inside a stage (wave-uniform)
+  bool lchunk_hi[8];           // this lane fetches one of the upper 32 columns of a 64-deep tile
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = (wave & 3) * 8 + i;                // instruction index inside this operand: [0, NP*IPP)
+    const int plane = j / IPP, rg = j % IPP;
+    const int row = rg * RPI + lrow;                 // tile row
+    const int swz = (NSPLIT == 3) ? ((row >> 2) & 3) : ((row >> 1) & 7);
+    const int lchunk = pchunk ^ swz;                 // logical 16-B chunk this lane fetches
+    ldst[i] = (a_wave ? 0 : NP * PLANE) + plane * PLANE + rg * 1024;
+    lchunk_hi[i] = lchunk >= 4;
+    if (a_wave) {
+      const long m = (long)tm * G2_BM + row;
+      const bf16_t* base = (plane == 0 ? g.a_hi : g.a_lo) + (long)z * g.a_zs;
+      src[i] = base + m * g.lda + lchunk * 8;
+      nseq[i] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -1;
+    } else {
+      const bf16_t* base = (plane == 0 ? g.w_hi : g.w_lo) + (long)z * g.w_zs;
+      src[i] = base + ((long)tn * G2_BN + row) * g.ldw + lchunk * 8;
+      nseq[i] = 0;
+    }
+  }
+
+  // K tiling in BK units: every tap spans tpt tiles; with BK = 64 an odd 32-multiple tap ends in a half tile whose
+  // upper 32 columns are zero-filled (A and W lanes of those chunks read the zero page)
+  const int tap_k = g.kt_per_tap * 32;                        // elements per tap
+  const int tpt = (tap_k + BK - 1) / BK;
+  const bool half_tail = (NSPLIT != 3) && (g.kt_per_tap & 1);
+  const int ntaps = g.nkt / g.kt_per_tap;
+  const int ntiles = ntaps * tpt;
+  const int mid_tile = (g.mid_kt > 0) ? (g.mid_kt / g.kt_per_tap) * tpt : 0;
+
+  auto issue_tile = [&](int kt, int stage) {
+    unsigned char* sbase = smem + stage * STAGE;
+    const int tap = kt / tpt;
+    const int it = kt - tap * tpt;
+    const bool half = half_tail && (it == tpt - 1);
+    if (a_wave) {
+      const int shift = (tap < g.conv_taps) ? (g.conv_taps - 1 - tap) * dil : 0;
+      const long off = (long)it * BK - (long)shift * g.lda;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool ok = (nseq[i] >= shift) && !(half && lchunk_hi[i]);
+        const bf16_t* p = ok ? (src[i] + off) : zero_page;
+        glds16(p, sbase + ldst[i]);
+      }
+    } else {
+      const long off = (long)tap * tap_k + (long)it * BK;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16_t* p = (half && lchunk_hi[i]) ? zero_page : (src[i] + off);
+        glds16(p, sbase + ldst[i]);
+      }
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int row_base = tm * G2_BM + wm * 128;
+  const int col_base = tn * G2_BN + wn * 64;
+
+  // fragment read addressing: row = wave base + 32*i + l31 ; physical chunk = (2*kc + hi) ^ swz(row), swz depends on l31 only
+  const int fswz = (NSPLIT == 3) ? ((l31 >> 2) & 3) : ((l31 >> 1) & 7);
+  const int a_row_off = (wm * 128 + l31) * RB;
+  const int w_row_off = NP * PLANE + (wn * 64 + l31) * RB;
+
+  auto run_k = [&](const int kt0, const int kt1) {
+    issue_tile(kt0, kt0 & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // tile kt0 landed for every wave
+    for (int kt = kt0; kt < kt1; ++kt) {
+      if (kt + 1 < kt1) issue_tile(kt + 1, (kt + 1) & 1);
+      const unsigned char* sb = smem + (kt & 1) * STAGE;
+#pragma unroll
+      for (int kc = 0; kc < KCH; ++kc) {
+        const int coff = ((2 * kc + hi) ^ fswz) * 16;
+        bf16x8 af[NP][4], wf[NP][2];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            af[p][i] = *reinterpret_cast<const bf16x8*>(sb + p * PLANE + a_row_off + i * 32 * RB + coff);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            wf[p][i] = *reinterpret_cast<const bf16x8*>(sb + p * PLANE + w_row_off + i * 32 * RB + coff);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            if constexpr (NSPLIT == 3) {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], wf[0][ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], wf[1][ni], acc[mi][ni], 0, 0, 0);
+            }
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], wf[0][ni], acc[mi][ni], 0, 0, 0);
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile has landed
+      __syncthreads();                                // ... everybody's has, and this stage is free to overwrite
+    }
+  };
+
+  if constexpr (EPI == EPI_WAVENET) {
+    run_k(0, mid_tile);
+    wavenet_midgate<4, 2>(acc, g, z, row_base, col_base, l31, hi);
+    run_k(mid_tile, ntiles);
+  } else {
+    run_k(0, ntiles);
+  }
+  gemm_epilogue<EPI, 4, 2>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane);
+}
+
+static const bf16_t* zero_page() {
+  static bf16_t* p = nullptr;
+  if (!p) {
+    if (hipMalloc((void**)&p, 256) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, 256);
+  }
+  return p;
+}
+
+template <int NSPLIT, int EPI>
+static hipError_t launch2_one(const GemmArgs& g, hipStream_t s) {
+  const int ntn = (g.N + G2_BN - 1) / G2_BN, ntm = (g.M + G2_BM - 1) / G2_BM;
+  const int nz = g.nz > 0 ? g.nz : 1;
+  const size_t lds = 2 * 65536;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const bf16_t* zp = zero_page();
+  if (!zp) return hipErrorOutOfMemory;
+  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI>), dim3(ntn * ntm * nz), dim3(512), lds, s, g, zp);
+  return hipGetLastError();
+}
+
+template <int NSPLIT>
+static hipError_t launch2_epi(const GemmArgs& g, hipStream_t s) {
+  switch (g.epi) {
+    case EPI_F32: return launch2_one<NSPLIT, EPI_F32>(g, s);
+    case EPI_SPLIT: return launch2_one<NSPLIT, EPI_SPLIT>(g, s);
+    case EPI_QKV: return launch2_one<NSPLIT, EPI_QKV>(g, s);
+    case EPI_GEGLU: return launch2_one<NSPLIT, EPI_GEGLU>(g, s);
+    case EPI_WAVENET: return launch2_one<NSPLIT, EPI_WAVENET>(g, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemm1(const GemmArgs& g, int nsplit, hipStream_t s);   // gemm.hip (128x128 register-staged kernel)
+
+static int g_forced_kernel = -1;     // -1: read NS2_GEMM once; 0 auto; 1 / 2 force a kernel (tests exercise both)
+void force_gemm_kernel(int k) { g_forced_kernel = k; }
+static int forced_kernel() {
+  if (g_forced_kernel < 0) {
+    const char* e = getenv("NS2_GEMM");
+    g_forced_kernel = e ? atoi(e) : 0;
+  }
+  return g_forced_kernel;
+}
+
+// Dispatch: the 256x256 LDS-DMA kernel for wide outputs, the 128x128 kernel when N <= 128 (half of a 256-wide tile
+// would be padding, e.g. the dim=128 model's d x d projections).  W rows are padded to 256 by the packers.
+hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0 || g.nkt <= 0 || g.kt_per_tap <= 0 || (g.nkt % g.kt_per_tap)) return hipErrorInvalidValue;
+  if (nsplit == 3 && (!g.a_lo || !g.w_lo)) return hipErrorInvalidValue;
+  const int f = forced_kernel();
+  const bool big = (f == 2) || (f != 1 && g.N > 128);
+  if (!big) return launch_gemm1(g, nsplit, s);
+  return nsplit == 3 ? launch2_epi<3>(g, s) : launch2_epi<1>(g, s);
+}
+
+}  // namespace ns2

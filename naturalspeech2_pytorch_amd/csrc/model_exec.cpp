@@ -98,7 +98,7 @@ static int dev_alloc(std::vector<void*>* owned, void** p, size_t bytes) {
 // allocate a packed weight of rows_p x ldk (zero-filled)
 static int alloc_packed(std::vector<void*>* owned, PackedW* w, int N, int ldk, int kt_per_tap) {
   w->N = N;
-  w->rows_p = rup(N, 128);
+  w->rows_p = rup(N, 256);
   w->ldk = ldk;
   w->nkt = ldk / 32;
   w->kt_per_tap = kt_per_tap;
@@ -333,7 +333,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
   for (int st = 0; st < S; ++st) {
     PackedW& W = m->w_wn[st];
     // batched: L matrices of [rows_p, 4*dp] back to back
-    W.N = dim; W.rows_p = rup(dim, 128); W.ldk = 4 * m->dp; W.nkt = W.ldk / 32; W.kt_per_tap = m->dp / 32;
+    W.N = dim; W.rows_p = rup(dim, 256); W.ldk = 4 * m->dp; W.nkt = W.ldk / 32; W.kt_per_tap = m->dp / 32;
     const size_t per = (size_t)W.rows_p * W.ldk;
     NSCHK(dev_alloc(&m->owned, (void**)&W.hi, per * L * sizeof(bf16_t)));
     NSCHK(dev_alloc(&m->owned, (void**)&W.lo, per * L * sizeof(bf16_t)));

@@ -40,7 +40,8 @@ struct GemmArgs {
   int nz; long a_zs, w_zs, bias_zs, film_zs, out_zs;
 };
 
-hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s);
+hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s);   // dispatches gemm.hip / gemm2.hip by shape
+void force_gemm_kernel(int k);                                          // 0 auto, 1 = 128x128, 2 = 256x256 (test hook)
 
 // flash attention forward, head dim 64, non-causal (ATT:77-155 hot path)
 struct AttnArgs {

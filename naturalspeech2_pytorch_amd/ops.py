@@ -101,7 +101,7 @@ def linear_split(w: PackedWeight, a: Planes, bias=None, conv_taps=0, dilation=1,
 
 
 def geglu_pack_bias(bias: torch.Tensor, f: int) -> torch.Tensor:
-    n = round_up(2 * round_up(f, 32), 128)
+    n = round_up(2 * round_up(f, 32), 256)
     out = torch.empty(n, dtype=torch.float32, device=bias.device)
     check(_lib.load().ns2_geglu_pack_bias(_f32(bias).data_ptr(), f, out.data_ptr(), n, _stream()), "ns2_geglu_pack_bias")
     return out

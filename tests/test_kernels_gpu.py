@@ -37,6 +37,15 @@ def exact(p):        # value the kernels see for a split operand
     return ops.join(p).double()
 
 
+@pytest.fixture(params=[1, 2], ids=["gemm128", "gemm256"])
+def gemm_kernel(request):
+    """run every GEMM-family test on both kernels (gemm.hip 128x128 register-staged, gemm2.hip 256x256 LDS-DMA)."""
+    from naturalspeech2_pytorch_amd import _lib
+    _lib.check(_lib.load().ns2_debug_force_gemm(request.param))
+    yield request.param
+    _lib.load().ns2_debug_force_gemm(0)
+
+
 def test_split_join_roundtrip():
     x = rnd(300, 100, seed=1, scale=3.0)
     p = ops.split(x)
@@ -50,8 +59,8 @@ def test_split_join_roundtrip():
 
 
 @pytest.mark.parametrize("prec", [3, 1])
-@pytest.mark.parametrize("M,K,N", [(300, 96, 200), (1024, 512, 512), (128, 64, 64), (4096, 352, 128), (77, 1376, 512)])
-def test_linear_f32(M, K, N, prec):
+@pytest.mark.parametrize("M,K,N", [(300, 96, 200), (1024, 512, 512), (128, 64, 64), (4096, 352, 128), (77, 1376, 512), (600, 1376, 300), (512, 96, 1365)])
+def test_linear_f32(M, K, N, prec, gemm_kernel):
     x = rnd(M, K, seed=2)
     w = rnd(N, K, seed=3, scale=1 / math.sqrt(K))
     b = rnd(N, seed=4)
@@ -76,7 +85,7 @@ def conv_ref(x_bnc, w, b, dil):
 
 @pytest.mark.parametrize("prec", [3, 1])
 @pytest.mark.parametrize("B,N,Cin,Cout,dil", [(3, 200, 96, 80, 1), (2, 300, 100, 100, 4), (2, 1024, 64, 64, 128), (1, 50, 170, 170, 1)])
-def test_causal_conv(B, N, Cin, Cout, dil, prec):
+def test_causal_conv(B, N, Cin, Cout, dil, prec, gemm_kernel):
     x = rnd(B * N, Cin, seed=6)
     w = rnd(Cout, Cin, 3, seed=7, scale=1 / math.sqrt(3 * Cin))
     b = rnd(Cout, seed=8)
@@ -93,7 +102,7 @@ def test_causal_conv(B, N, Cin, Cout, dil, prec):
 
 @pytest.mark.parametrize("prec", [3, 1])
 @pytest.mark.parametrize("M,K,f", [(256, 64, 170), (500, 128, 341), (1024, 512, 1365)])
-def test_geglu(M, K, f, prec):
+def test_geglu(M, K, f, prec, gemm_kernel):
     x = rnd(M, K, seed=9)
     w = rnd(2 * f, K, seed=10, scale=1 / math.sqrt(K))
     b = rnd(2 * f, seed=11)
@@ -111,7 +120,7 @@ def test_geglu(M, K, f, prec):
 
 @pytest.mark.parametrize("prec", [3, 1])
 @pytest.mark.parametrize("B,N,K", [(2, 200, 64), (3, 135, 128), (2, 1024, 512)])
-def test_qkv(B, N, K, prec):
+def test_qkv(B, N, K, prec, gemm_kernel):
     a_dim = 512
     x = rnd(B * N, K, seed=12)
     w = rnd(3 * a_dim, K, seed=13, scale=1 / math.sqrt(K))
@@ -127,7 +136,7 @@ def test_qkv(B, N, K, prec):
 
 @pytest.mark.parametrize("prec", [3, 1])
 @pytest.mark.parametrize("B,N,C,dil", [(2, 200, 64, 2), (2, 300, 128, 64), (1, 1024, 512, 128)])
-def test_wavenet_block(B, N, C, dil, prec):
+def test_wavenet_block(B, N, C, dil, prec, gemm_kernel):
     x = rnd(B * N, C, seed=14)
     wc = rnd(C, C, 3, seed=15, scale=1 / math.sqrt(3 * C))
     wr = rnd(C, C, 1, seed=16, scale=1 / math.sqrt(C))
