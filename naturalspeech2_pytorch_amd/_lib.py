@@ -8,7 +8,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libns2hip.so")
+LIB_PATH = os.environ.get("NS2_LIB", os.path.join(_HERE, "libns2hip.so"))   # NS2_LIB: experiment builds (tools/)
 
 
 class Ns2Error(RuntimeError):

@@ -193,12 +193,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
 #pragma unroll
       for (int g1 = 0; g1 < 2; ++g1) {
         bf16x8 pf[NP];
+        {
+          uint32_t ph[4], pl[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float p = st[js][8 * g1 + e];
-          const bf16_t ph = f2bf(p);
-          pf[0][e] = (short)ph;
-          if constexpr (NSPLIT == 3) pf[1][e] = (short)f2bf(p - bf2f(ph));
+          for (int e = 0; e < 4; ++e) split2(st[js][8 * g1 + 2 * e], st[js][8 * g1 + 2 * e + 1], ph[e], pl[e]);
+          const uint4 uh = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+          pf[0] = *reinterpret_cast<const bf16x8*>(&uh);
+          if constexpr (NSPLIT == 3) {
+            const uint4 ul = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            pf[1] = *reinterpret_cast<const bf16x8*>(&ul);
+          }
         }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -228,12 +232,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        bf16_t hh[4], ll[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split_bf16(ot[dt][4 * gq + e] * inv, hh[e], ll[e]);
+        uint32_t h01, l01, h23, l23;
+        split2(ot[dt][4 * gq + 0] * inv, ot[dt][4 * gq + 1] * inv, h01, l01);
+        split2(ot[dt][4 * gq + 2] * inv, ot[dt][4 * gq + 3] * inv, h23, l23);
         const long o = obase + 32 * dt + 8 * gq + 4 * hi;
-        *reinterpret_cast<uint2*>(a.o_hi + o) = make_uint2(pack2(hh[0], hh[1]), pack2(hh[2], hh[3]));
-        if (a.o_lo) *reinterpret_cast<uint2*>(a.o_lo + o) = make_uint2(pack2(ll[0], ll[1]), pack2(ll[2], ll[3]));
+        *reinterpret_cast<uint2*>(a.o_hi + o) = make_uint2(h01, h23);
+        if (a.o_lo) *reinterpret_cast<uint2*>(a.o_lo + o) = make_uint2(l01, l23);
       }
   }
 }

@@ -36,12 +36,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const NormArgs a) {
         o[e] = t;
       }
     }
-    bf16_t h[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split_bf16(o[e], h[e], l[e]);
+    uint32_t h01, l01, h23, l23;
+    split2(o[0], o[1], h01, l01);
+    split2(o[2], o[3], h23, l23);
     if (a.out_hi) {
-      *reinterpret_cast<uint2*>(a.out_hi + row * a.ldo + c) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-      if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + row * a.ldo + c) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+      *reinterpret_cast<uint2*>(a.out_hi + row * a.ldo + c) = make_uint2(h01, h23);
+      if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + row * a.ldo + c) = make_uint2(l01, l23);
     }
     if (a.out_f && c < a.d) *reinterpret_cast<float4*>(a.out_f + row * a.ldo_f + c) = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -83,11 +83,11 @@ __global__ __launch_bounds__(256) void split_kernel(const float* x, int ldx, con
       }
     }
   }
-  bf16_t h[4], l[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) split_bf16(o[e], h[e], l[e]);
-  *reinterpret_cast<uint2*>(out_hi + row * ldo + c) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-  if (out_lo) *reinterpret_cast<uint2*>(out_lo + row * ldo + c) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+  uint32_t h01, l01, h23, l23;
+  split2(o[0], o[1], h01, l01);
+  split2(o[2], o[3], h23, l23);
+  *reinterpret_cast<uint2*>(out_hi + row * ldo + c) = make_uint2(h01, h23);
+  if (out_lo) *reinterpret_cast<uint2*>(out_lo + row * ldo + c) = make_uint2(l01, l23);
 }
 
 hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, int add_rows_per_batch, int add_valid_rows,

@@ -140,7 +140,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                  // tile kt0 landed for every wave
     for (int kt = kt0; kt < kt1; ++kt) {
+#ifdef NS2_ABLATE
+      if (kt + 1 < kt1 && !(g.dbg & 1)) issue_tile(kt + 1, (kt + 1) & 1);
+#else
       if (kt + 1 < kt1) issue_tile(kt + 1, (kt + 1) & 1);
+#endif
       const unsigned char* sb = smem + (kt & 1) * STAGE;
 #pragma unroll
       for (int kc = 0; kc < KCH; ++kc) {
@@ -155,6 +159,18 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
           for (int i = 0; i < 2; ++i)
             wf[p][i] = *reinterpret_cast<const bf16x8*>(sb + p * PLANE + w_row_off + i * 32 * RB + coff);
         }
+#ifdef NS2_ABLATE
+        if (g.dbg & 2) {                              // keep the fragment reads alive, skip the MFMAs
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[p][i]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(wf[p][i]));
+          }
+          continue;
+        }
+#endif
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -178,6 +194,22 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
   } else {
     run_k(0, ntiles);
   }
+  // all waves are past the K loop's last barrier: the LDS ring is free, every wave takes a private 18 KiB region
+#ifdef NS2_ABLATE
+  if (g.dbg & 4) {                                   // no epilogue: keep the accumulators alive, store nothing
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+    return;
+  }
+#endif
+  if constexpr (EPI == EPI_F32) {
+    if (epi_lds_supported<EPI>(g, row_base)) {
+      gemm_epilogue_lds<EPI>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane, smem + wave * EPI_LDS_WAVE_BYTES);
+      return;
+    }
+  }
   gemm_epilogue<EPI, 4, 2>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane);
 }
 
@@ -194,7 +226,7 @@ template <int NSPLIT, int EPI>
 static hipError_t launch2_one(const GemmArgs& g, hipStream_t s) {
   const int ntn = (g.N + G2_BN - 1) / G2_BN, ntm = (g.M + G2_BM - 1) / G2_BM;
   const int nz = g.nz > 0 ? g.nz : 1;
-  const size_t lds = 2 * 65536;
+  const size_t lds = 8 * EPI_LDS_WAVE_BYTES;          // 144 KiB: 2 x 64 KiB K stages, reused as 8 x 18 KiB epilogue regions
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI>),

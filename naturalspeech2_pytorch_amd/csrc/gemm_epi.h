@@ -90,12 +90,11 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
         const int row = row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const int col = ocol & ~1;
         if (row < g.M && col < g.out_ncols) {
-          bf16_t h0, l0, h1, l1;
-          split_bf16(c_lo, h0, l0);
-          split_bf16(c_hi, h1, l1);
+          uint32_t ph, pl;
+          split2(c_lo, c_hi, ph, pl);
           const long o = (long)row * g.ldo_s + col;
-          *reinterpret_cast<uint32_t*>(g.out_hi + o) = pack2(h0, h1);
-          if (g.out_lo) *reinterpret_cast<uint32_t*>(g.out_lo + o) = pack2(l0, l1);
+          *reinterpret_cast<uint32_t*>(g.out_hi + o) = ph;
+          if (g.out_lo) *reinterpret_cast<uint32_t*>(g.out_lo + o) = pl;
         }
       }
     }
@@ -126,12 +125,11 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
             if (row < g.M && c0 < g.out_ncols) {
               if (c0 >= g.N) c_lo = 0.f;             // zero the K-padding columns of the next GEMM's operand
               if (c0 + 1 >= g.N) c_hi = 0.f;
-              bf16_t h0, l0, h1, l1;
-              split_bf16(c_lo, h0, l0);
-              split_bf16(c_hi, h1, l1);
+              uint32_t ph, pl;
+              split2(c_lo, c_hi, ph, pl);
               const long o = (long)row * g.ldo_s + c0;
-              *reinterpret_cast<uint32_t*>(out_hi + o) = pack2(h0, h1);
-              if (out_lo) *reinterpret_cast<uint32_t*>(out_lo + o) = pack2(l0, l1);
+              *reinterpret_cast<uint32_t*>(out_hi + o) = ph;
+              if (out_lo) *reinterpret_cast<uint32_t*>(out_lo + o) = pl;
             }
           }
         } else {
@@ -143,13 +141,15 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
               const int row0 = row_base + mi * 32 + 8 * gq + 4 * hi;
               if (row0 >= g.M) continue;
               const int b = row0 / g.seq_len, n0 = row0 - b * g.seq_len;
-              bf16_t h[4], l[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) split_bf16(acc[mi][ni][4 * gq + e] + bc, h[e], l[e]);
+              uint32_t h01, l01, h23, l23;
+              split2(acc[mi][ni][4 * gq + 0] + bc, acc[mi][ni][4 * gq + 1] + bc, h01, l01);
+              split2(acc[mi][ni][4 * gq + 2] + bc, acc[mi][ni][4 * gq + 3] + bc, h23, l23);
+              const bf16_t h[4] = {(bf16_t)(h01 & 0xffffu), (bf16_t)(h01 >> 16), (bf16_t)(h23 & 0xffffu), (bf16_t)(h23 >> 16)};
+              const bf16_t l[4] = {(bf16_t)(l01 & 0xffffu), (bf16_t)(l01 >> 16), (bf16_t)(l23 & 0xffffu), (bf16_t)(l23 >> 16)};
               const long o = ((long)b * g.vt_rows + feat) * g.vt_ld + n0;
               if ((g.seq_len & 3) == 0) {            // 4 tokens stay inside one utterance and are 8-B aligned
-                *reinterpret_cast<uint2*>(g.vt_hi + o) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
-                if (g.vt_lo) *reinterpret_cast<uint2*>(g.vt_lo + o) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+                *reinterpret_cast<uint2*>(g.vt_hi + o) = make_uint2(h01, h23);
+                if (g.vt_lo) *reinterpret_cast<uint2*>(g.vt_lo + o) = make_uint2(l01, l23);
               } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -166,6 +166,187 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
           }
         }
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-staged epilogue for the 256x256 kernel (wave tile 128x64, MI = 4, NI = 2).  The direct epilogue above issues one
+// 4-byte store per lane per two accumulator registers (64-B row segments): on short-K GEMMs (QKV, FF-in, out-proj) it
+// measured ~100 us of a 145 us launch.  Here every wave transposes its tile through a private 18 KiB LDS region
+// (free after the K loop) and writes full rows with 16-B stores per lane (128-B / 256-B contiguous segments).
+constexpr int EPI_LDS_WAVE_BYTES = 18432;     // 128 rows x (128 B + 16 B pad)
+
+NS2_DEVINL uint32_t pk2(float a, float b) { return cvt2(a, b); }
+
+// returns false when the tile needs the generic path (ragged utterances for the transposed V store)
+// Measured (MI355X, M = 32768): the fp32 + residual epilogue gains 1.45x-1.65x on the whole launch (FF-out 218 -> 150 us),
+// the bf16 split-plane epilogues are neutral (their cost is the store burst itself, not store issue), and the GEGLU
+// variant would spill.  Only EPI_F32 therefore takes the LDS path.
+template <int EPI>
+NS2_DEVINL bool epi_lds_supported(const GemmArgs& g, int row_base) {
+  if constexpr (EPI != EPI_F32) return false;
+  if constexpr (EPI == EPI_QKV) {
+    if ((g.split_col & 63) || (g.seq_len & 127) || row_base + 128 > g.M) return false;
+  }
+  return true;
+}
+
+template <int EPI>
+NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][2], const GemmArgs& g, int z, int row_base, int col_base, int ocol_base,
+                                  int lane, unsigned char* wbuf) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  const bool odd = lane & 1;
+
+  if constexpr (EPI == EPI_F32) {
+    // two halves of 64 rows x 64 cols fp32, LDS rows of 272 B
+    constexpr int RS = 272;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int col = col_base + ni * 32 + l31;
+          const float bc = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lr = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            *reinterpret_cast<float*>(wbuf + lr * RS + (ni * 32 + l31) * 4) = acc[half * 2 + mh][ni][r] + bc;
+          }
+        }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int lr = it * 4 + (lane >> 4), ch = lane & 15;
+        const int row = row_base + half * 64 + lr, col = col_base + ch * 4;
+        const float4 v = *reinterpret_cast<const float4*>(wbuf + lr * RS + ch * 16);
+        if (row < g.M && col < g.N) {
+          float o[4] = {v.x, v.y, v.z, v.w};
+          if (col + 3 < g.N) {
+            if (g.resid) {
+              const float4 rr = *reinterpret_cast<const float4*>(g.resid + (long)row * g.ldr + col);
+              o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w;
+            }
+            *reinterpret_cast<float4*>(g.out_f + (long)row * g.ldo_f + col) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < g.N) {
+                float t = o[e];
+                if (g.resid) t += g.resid[(long)row * g.ldr + col + e];
+                g.out_f[(long)row * g.ldo_f + col + e] = t;
+              }
+          }
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_GEGLU) {
+    // out tile 128 rows x 32 cols per plane, LDS rows of 80 B
+    constexpr int RS = 80;
+    const int cx = col_base + l31, cg = col_base + 32 + l31;
+    const float bx = g.bias[cx], bg = g.bias[cg];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)                   // result overwrites the x accumulators (no extra registers)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][0][r] = gelu_erf(acc[mi][1][r] + bg) * (acc[mi][0][r] + bx);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      bf16_t* outp = pl ? g.out_lo : g.out_hi;
+      if (!outp) break;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+          float v0 = acc[mi][0][2 * rp], v1 = acc[mi][0][2 * rp + 1];
+          if (pl) { v0 -= bf2f(f2bf(v0)); v1 -= bf2f(f2bf(v1)); }
+          const float send = odd ? v0 : v1;
+          const float recv = __shfl_xor(send, 1, 64);
+          const float c_lo = odd ? recv : v0, c_hi = odd ? v1 : recv;
+          const int r = 2 * rp + (odd ? 1 : 0);
+          const int lr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          *reinterpret_cast<uint32_t*>(wbuf + lr * RS + (l31 & ~1) * 2) = pk2(c_lo, c_hi);
+        }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int lr = it * 16 + (lane >> 2), ch = lane & 3;
+        const int row = row_base + lr, col = ocol_base + ch * 8;
+        const uint4 d = *reinterpret_cast<const uint4*>(wbuf + lr * RS + ch * 16);
+        if (row < g.M && col < g.out_ncols) *reinterpret_cast<uint4*>(outp + (long)row * g.ldo_s + col) = d;
+      }
+    }
+  } else {
+    // EPI_SPLIT / EPI_WAVENET / EPI_QKV
+    const float* bias = g.bias ? g.bias + (long)z * g.bias_zs : nullptr;
+    const bool transposed = (EPI == EPI_QKV) && (col_base >= g.split_col);       // wave-uniform (split_col % 64 == 0)
+    float bc[2] = {0.f, 0.f};
+    if constexpr (EPI != EPI_WAVENET) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = col_base + ni * 32 + l31;
+        bc[ni] = (bias && col < g.N) ? bias[col] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      if (!transposed) {
+        constexpr int RS = 144;                      // 128 rows x 64 cols bf16
+        bf16_t* outp = (pl ? g.out_lo : g.out_hi);
+        if (!outp) break;
+        outp += (long)z * g.out_zs;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const int col = col_base + ni * 32 + l31;
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+              float v0 = acc[mi][ni][2 * rp] + bc[ni], v1 = acc[mi][ni][2 * rp + 1] + bc[ni];
+              if (col >= g.N) { v0 = 0.f; v1 = 0.f; }                 // zero the K padding of the next GEMM's operand
+              if (pl) { v0 -= bf2f(f2bf(v0)); v1 -= bf2f(f2bf(v1)); }
+              const float send = odd ? v0 : v1;
+              const float recv = __shfl_xor(send, 1, 64);
+              const float c_lo = odd ? recv : v0, c_hi = odd ? v1 : recv;
+              const int r = 2 * rp + (odd ? 1 : 0);
+              const int lr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+              *reinterpret_cast<uint32_t*>(wbuf + lr * RS + (ni * 32 + (l31 & ~1)) * 2) = pk2(c_lo, c_hi);
+            }
+          }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int lr = it * 8 + (lane >> 3), ch = lane & 7;
+          const int row = row_base + lr, col = col_base + ch * 8;
+          const uint4 d = *reinterpret_cast<const uint4*>(wbuf + lr * RS + ch * 16);
+          if (row < g.M && col < g.out_ncols) *reinterpret_cast<uint4*>(outp + (long)row * g.ldo_s + col) = d;
+        }
+      } else {
+        constexpr int RS = 272;                      // 64 features x 128 tokens bf16
+        bf16_t* outp = pl ? g.vt_lo : g.vt_hi;
+        if (!outp) break;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              float t[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                t[e] = acc[mi][ni][4 * gq + e] + bc[ni];
+                if (pl) t[e] -= bf2f(f2bf(t[e]));
+              }
+              *reinterpret_cast<uint2*>(wbuf + (ni * 32 + l31) * RS + (mi * 32 + 8 * gq + 4 * hi) * 2) =
+                  make_uint2(pk2(t[0], t[1]), pk2(t[2], t[3]));
+            }
+        const int b = row_base / g.seq_len, n0 = row_base - b * g.seq_len;       // 128 tokens inside one utterance
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int lf = it * 4 + (lane >> 4), ch = lane & 15;
+          const int feat = col_base - g.split_col + lf;
+          const uint4 d = *reinterpret_cast<const uint4*>(wbuf + lf * RS + ch * 16);
+          if (col_base + lf < g.N)
+            *reinterpret_cast<uint4*>(outp + ((long)b * g.vt_rows + feat) * g.vt_ld + n0 + ch * 8) = d;
+        }
+      }
+    }
   }
 }
 

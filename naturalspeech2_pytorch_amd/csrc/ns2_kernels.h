@@ -38,6 +38,7 @@ struct GemmArgs {
   bf16_t* vt_hi; bf16_t* vt_lo; int vt_ld; int vt_rows; int split_col;
   // batching over blockIdx-z (wavenet columns): element offsets per z
   int nz; long a_zs, w_zs, bias_zs, film_zs, out_zs;
+  int dbg;           // ablation switches (only honoured by -DNS2_ABLATE builds): 1 = no DMA after the first tile, 2 = no MFMA
 };
 
 hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s);   // dispatches gemm.hip / gemm2.hip by shape
