@@ -7,32 +7,55 @@
 namespace ns2 {
 
 // ---------------------------------------------------------------- RMSNorm (NS2:727-746)
-// one wave per row; two passes over the row (the second hits L1/L2), fp32 math, split-plane output.
+// one wave per row, the row lives in registers (CH float4 per lane, d <= 1024*CH/4... ), fp32 math, split-plane output;
+// all loads/stores are 16 B (x, gamma, adaptive gamma/beta) or 8 B (bf16 planes) per lane.
+template <int CH>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const NormArgs a) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.M) return;
   const float* x = a.x + row * a.ldx;
+  float4 v[CH];
   float ss = 0.f;
-  for (int c = lane * 4; c < a.d; c += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(x + c);
-    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int c = lane * 4 + 256 * j;
+    v[j] = (c < a.d) ? *reinterpret_cast<const float4*>(x + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
   }
   ss = wave_sum(ss);
   const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);     // F.normalize eps
   const float scale = sqrtf((float)a.d);
   const int b = a.seq_len > 0 ? (int)(row / a.seq_len) : 0;
   const float* gc = a.cond ? a.cond + (long)b * a.cond_ld : nullptr;
-  for (int c = lane * 4; c < a.ldo; c += 256) {
+  const bool vec_cond = gc && ((a.cond_ld | a.d) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.cond) & 15) == 0);
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int c = lane * 4 + 256 * j;
+    if (c >= a.ldo) continue;
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < a.d) {
-      const float4 v = *reinterpret_cast<const float4*>(x + c);
-      const float xv[4] = {v.x, v.y, v.z, v.w};
+      const float xv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+      float gm[4] = {1.f, 1.f, 1.f, 1.f}, gg[4] = {1.f, 1.f, 1.f, 1.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.gamma) {
+        const float4 t = *reinterpret_cast<const float4*>(a.gamma + c);
+        gm[0] = t.x; gm[1] = t.y; gm[2] = t.z; gm[3] = t.w;
+      }
+      if (gc) {
+        if (vec_cond) {
+          const float4 t = *reinterpret_cast<const float4*>(gc + c), u = *reinterpret_cast<const float4*>(gc + a.d + c);
+          gg[0] = t.x; gg[1] = t.y; gg[2] = t.z; gg[3] = t.w;
+          bb[0] = u.x; bb[1] = u.y; bb[2] = u.z; bb[3] = u.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { gg[e] = gc[c + e]; bb[e] = gc[a.d + c + e]; }
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = xv[e] * inv * scale;
-        if (a.gamma) t *= a.gamma[c + e];
-        if (gc) t = t * gc[c + e] + gc[a.d + c + e];
+        if (a.gamma) t *= gm[e];
+        if (gc) t = t * gg[e] + bb[e];
         o[e] = t;
       }
     }
@@ -48,8 +71,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const NormArgs a) {
 }
 
 hipError_t launch_rmsnorm(const NormArgs& a, hipStream_t s) {
-  if (a.M <= 0 || (a.d & 3) || (a.ldo & 3)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
+  if (a.M <= 0 || (a.d & 3) || (a.ldo & 3) || (a.ldx & 3) || a.ldo > 2048 || a.d > 2048) return hipErrorInvalidValue;
+  const dim3 grid((a.M + 3) / 4), block(256);
+  const int width = a.ldo > a.d ? a.ldo : a.d;
+  if (width <= 256) hipLaunchKernelGGL(rmsnorm_kernel<1>, grid, block, 0, s, a);
+  else if (width <= 512) hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, block, 0, s, a);
+  else if (width <= 1024) hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, block, 0, s, a);
   return hipGetLastError();
 }
 
@@ -100,61 +128,111 @@ hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, in
 }
 
 // ---------------------------------------------------------------- skinny linear: out[b,j] = act(in[b,:] . wt[:,j] + bias[j])
-// M = batch rows (<= 32 per pass), weight stored K-major so a wave streams it fully coalesced; the 32 batch
-// rows of the activation chunk sit transposed in LDS and are read as broadcast ds_read_b128.  Weight-bandwidth
-// bound: this is how all 56-68 time/prompt conditioning projections of one denoising step are produced at once.
+// M = batch rows (<= 32 per pass), weight stored K-major so a wave streams it fully coalesced; the 32 batch rows of the
+// activation chunk sit in LDS and are read as broadcast ds_read_b128.  Weight-bandwidth bound: this is how all 56-68
+// time/prompt conditioning projections of one denoising step are produced at once (470 MB of fp32 weights at d=512).
+// To keep ~10 MB of loads in flight the K range is split over blockIdx.z (deterministic two-pass reduction, no atomics)
+// and 8 weight rows are fetched per lane before their FMAs.
 constexpr int SK_KC = 128;
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* in, int ld_in, const float* wt, const float* bias,
-                                                            float* out, int ld_out, int B, int K, int J, int act) {
+                                                            float* out, int ld_out, int B, int K, int J, int act,
+                                                            int k_per_split, float* partial) {
   __shared__ __attribute__((aligned(16))) float s_in[32][SK_KC + 4];
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int b0 = blockIdx.y * 32;
   const int nb = min(32, B - b0);
   const bool jok = j < J;
+  const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
   float acc[32];
 #pragma unroll
   for (int b = 0; b < 32; ++b) acc[b] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += SK_KC) {
+  for (int k0 = kbeg; k0 < kend; k0 += SK_KC) {
     __syncthreads();
     for (int i = threadIdx.x; i < SK_KC * 32; i += 256) {
       const int b = i / SK_KC, k = i - b * SK_KC;          // coalesced along k, conflict-free LDS writes
       float v = 0.f;
-      if (b < nb && k0 + k < K) v = in[(long)(b0 + b) * ld_in + k0 + k];
+      if (b < nb && k0 + k < kend) v = in[(long)(b0 + b) * ld_in + k0 + k];
       s_in[b][k] = v;
     }
     __syncthreads();
-#pragma unroll 2
-    for (int k = 0; k < SK_KC; k += 4) {
-      float w[4];
+#pragma unroll 1
+    for (int k = 0; k < SK_KC; k += 8) {
+      float w[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = (jok && k0 + k + e < K) ? wt[(long)(k0 + k + e) * J + j] : 0.f;
+      for (int e = 0; e < 8; ++e) w[e] = (jok && k0 + k + e < kend) ? wt[(long)(k0 + k + e) * J + j] : 0.f;
 #pragma unroll
       for (int b = 0; b < 32; ++b) {
-        const float4 t = *reinterpret_cast<const float4*>(&s_in[b][k]);   // wave-uniform address: LDS broadcast
+        const float4 t = *reinterpret_cast<const float4*>(&s_in[b][k]);       // wave-uniform address: LDS broadcast
+        const float4 u = *reinterpret_cast<const float4*>(&s_in[b][k + 4]);
         acc[b] = fmaf(t.x, w[0], acc[b]);
         acc[b] = fmaf(t.y, w[1], acc[b]);
         acc[b] = fmaf(t.z, w[2], acc[b]);
         acc[b] = fmaf(t.w, w[3], acc[b]);
+        acc[b] = fmaf(u.x, w[4], acc[b]);
+        acc[b] = fmaf(u.y, w[5], acc[b]);
+        acc[b] = fmaf(u.z, w[6], acc[b]);
+        acc[b] = fmaf(u.w, w[7], acc[b]);
       }
     }
   }
-  if (jok) {
-    const float bj = bias ? bias[j] : 0.f;
+  if (!jok) return;
+  if (partial) {                                            // [split][B][J]
 #pragma unroll
     for (int b = 0; b < 32; ++b)
-      if (b < nb) {
-        float v = acc[b] + bj;
-        if (act == 1) v = siluf(v);
-        out[(long)(b0 + b) * ld_out + j] = v;
-      }
+      if (b < nb) partial[((long)blockIdx.z * B + b0 + b) * J + j] = acc[b];
+    return;
   }
+  const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+  for (int b = 0; b < 32; ++b)
+    if (b < nb) {
+      float v = acc[b] + bj;
+      if (act == 1) v = siluf(v);
+      out[(long)(b0 + b) * ld_out + j] = v;
+    }
 }
+
+__global__ void skinny_reduce_kernel(const float* partial, int nsplit, const float* bias, float* out, int ld_out, int B, int J,
+                                     int act) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * J) return;
+  const int b = (int)(i / J), j = (int)(i - (long)b * J);
+  float v = 0.f;
+  for (int s = 0; s < nsplit; ++s) v += partial[((long)s * B + b) * J + j];      // fixed order: deterministic
+  v += bias ? bias[j] : 0.f;
+  if (act == 1) v = siluf(v);
+  out[(long)b * ld_out + j] = v;
+}
+
+static float* g_skinny_ws = nullptr;
+static size_t g_skinny_ws_bytes = 0;
 
 hipError_t launch_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out,
                                 int B, int K, int J, int act, hipStream_t s) {
   if (B <= 0 || K <= 0 || J <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(skinny_linear_kernel, dim3((J + 255) / 256, (B + 31) / 32), dim3(256), 0, s, in, ld_in, wt, bias,
-                     out, ld_out, B, K, J, act);
+  // split K only for the big weight-streaming case (>= 64 MB of weights); the scratch for the partial sums is a
+  // library-owned buffer grown on first use (never during graph capture: the first call is a warm-up)
+  int nsplit = 1;
+  if ((size_t)K * J * 4 >= (size_t)(64u << 20) && K >= 8 * SK_KC) nsplit = 8;
+  const int kps = ((K + nsplit - 1) / nsplit + SK_KC - 1) / SK_KC * SK_KC;
+  nsplit = (K + kps - 1) / kps;
+  float* partial = nullptr;
+  if (nsplit > 1) {
+    const size_t need = (size_t)nsplit * B * J * sizeof(float);
+    if (need > g_skinny_ws_bytes) {
+      if (g_skinny_ws) (void)hipFree(g_skinny_ws);
+      if (hipMalloc((void**)&g_skinny_ws, need) != hipSuccess) { g_skinny_ws = nullptr; g_skinny_ws_bytes = 0; return hipErrorOutOfMemory; }
+      g_skinny_ws_bytes = need;
+    }
+    partial = g_skinny_ws;
+  }
+  hipLaunchKernelGGL(skinny_linear_kernel, dim3((J + 255) / 256, (B + 31) / 32, nsplit), dim3(256), 0, s, in, ld_in, wt, bias,
+                     out, ld_out, B, K, J, act, kps, partial);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || nsplit == 1) return e;
+  const long n = (long)B * J;
+  hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partial, nsplit, bias, out, ld_out,
+                     B, J, act);
   return hipGetLastError();
 }
 

@@ -31,8 +31,8 @@ NS2_DEVINL void wavenet_midgate(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z,
           const float gam = film[(long)b * g.film_ld + col];
           const float bet = film[(long)b * g.film_ld + g.N + col];
           const float h = (acc[mi][ni][r] + bc) * gam + bet;
-          const float u = expf(-fabsf(h));
-          const float t = (1.f - u) * (h < 0.f ? u : 1.f) * __frcp_rn(1.f + u * u);
+          const float u = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(h));     // v_exp_f32: <= 1 ulp, |arg| error ~1e-7*|h|
+          const float t = (1.f - u) * (h < 0.f ? u : 1.f) * __builtin_amdgcn_rcpf(1.f + u * u);
           v = copysignf(t, h) + b2;
         }
         acc[mi][ni][r] = v;
