@@ -45,8 +45,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+  // 1-D grid, XCD-aware: the query tiles of one (batch, head) get consecutive remapped ids and therefore share one
+  // XCD's L2 for their K / V^T re-reads (rocprofv3 FETCH_SIZE showed ~3x over-fetch with the default round-robin).
+  const int nqt = (a.Nq + 127) / 128;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = bid % nqt;
+  bid /= nqt;
+  const int h = bid % a.H, b = bid / a.H;
+  const int qrow = qt * 128 + wave * 32 + l31;
   const bool q_ok = qrow < a.Nq;
 
   const bf16_t* q_pl[2] = {a.q_hi, a.q_lo};
@@ -252,7 +258,7 @@ static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid((a.Nq + 127) / 128, a.H, a.B);
+  dim3 grid(((a.Nq + 127) / 128) * a.H * a.B);
   hipLaunchKernelGGL((attn_kernel<NSPLIT>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
