@@ -89,8 +89,9 @@ def main():
         assert world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
         assert args.gpus == 1, "for N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ..."
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    local_dev = local % torch.cuda.device_count()       # ranks > devices only in the gloo functional test of this script
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
 
     B, N, dim, depth = args.batch, args.frames, args.dim, args.depth
     torch.manual_seed(1234)                          # same random-init weights on every rank
