@@ -165,7 +165,7 @@ def main():
             pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
             if os.path.exists(pj):
                 traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
-            roof = dict(bound="mfma", kernel="ns2::gemm_kernel<%d, EPI_SPLIT> (FF causal conv k3 x%d, wavenet init conv, skip-sum GEMM)"
+            roof = dict(bound="mfma", kernel="ns2::gemm2_kernel<%d, 1> = EPI_SPLIT (FF causal conv k3 x%d, wavenet init conv, skip-sum GEMM)"
                         % (3 if args.precision == "exact" else 1, depth),
                         achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
                         traffic=traffic, avg_launch_ms=round(avg_ms, 4), launches=kern_n.value,
