@@ -62,7 +62,7 @@ extern "C" int ns2_weight_pack(const float* w, int rows, int cols, int taps, int
 }
 extern "C" void ns2_weight_free(ns2_weight* w) {
   if (!w) return;
-  for (void* p : w->owned) hipFree(p);
+  for (void* p : w->owned) (void)hipFree(p);
   delete w;
 }
 

@@ -121,7 +121,7 @@ static int pack_into(PackedW* w, const float* src, int C, int T, int Cp, const s
   hipError_t e = launch_pack_weight(src, C, T, Cp, d_map, (int)row_map.size(), w->hi + (size_t)row0 * w->ldk,
                                     w->lo + (size_t)row0 * w->ldk, w->ldk, k_off, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  hipFree(d_map);
+  (void)hipFree(d_map);
   HIPCHK(e);
   return NS2_OK;
 }
@@ -281,8 +281,8 @@ extern "C" int ns2_model_set_param(ns2_model* m, const char* name, const float* 
 
 extern "C" void ns2_model_destroy(ns2_model* m) {
   if (!m) return;
-  for (auto& e : m->prof_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-  for (void* p : m->owned) hipFree(p);
+  for (auto& e : m->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (void* p : m->owned) (void)hipFree(p);
   delete m;
 }
 
