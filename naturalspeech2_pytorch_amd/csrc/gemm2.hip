@@ -46,7 +46,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  // wave -> (row half, column quarter): waves w and w+4 share a SIMD (dispatch order 0,2,1,3,0,2,1,3), so column
+  // quarters {0,1} and {2,3} are paired on every SIMD: when the last column tile is at most half valid (FF conv:
+  // N = 1365 = 5.33 tiles) the idle quarters leave each SIMD's MFMA pipe to one active wave instead of idling two SIMDs.
+  const int wm = wave & 1, wn = wave >> 1;
   const int l31 = lane & 31, hi = lane >> 5;
 
   const int ntn = (g.N + G2_BN - 1) / G2_BN;
@@ -129,6 +132,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
 
   const int row_base = tm * G2_BM + wm * 128;
   const int col_base = tn * G2_BN + wn * 64;
+  // nothing to compute or store for this wave (it still streams its share of the operands and joins the barriers)
+  const int ncols_needed = (EPI == EPI_GEGLU || EPI == EPI_F32 || EPI == EPI_QKV) ? g.N : max(g.N, g.out_ncols);
+  const bool wave_active = col_base < ncols_needed;
 
   // fragment read addressing: row = wave base + 32*i + l31 ; physical chunk = (2*kc + hi) ^ swz(row), swz depends on l31 only
   const int fswz = (NSPLIT == 3) ? ((l31 >> 2) & 3) : ((l31 >> 1) & 7);
@@ -146,6 +152,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
       if (kt + 1 < kt1) issue_tile(kt + 1, (kt + 1) & 1);
 #endif
       const unsigned char* sb = smem + (kt & 1) * STAGE;
+      if (wave_active) {
 #pragma unroll
       for (int kc = 0; kc < KCH; ++kc) {
         const int coff = ((2 * kc + hi) ^ fswz) * 16;
@@ -182,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], wf[0][ni], acc[mi][ni], 0, 0, 0);
           }
       }
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile has landed
       __syncthreads();                                // ... everybody's has, and this stage is free to overwrite
     }
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
   } else {
     run_k(0, ntiles);
   }
+  if (!wave_active) return;
   // all waves are past the K loop's last barrier: the LDS ring is free, every wave takes a private 18 KiB region
 #ifdef NS2_ABLATE
   if (g.dbg & 4) {                                   // no epilogue: keep the accumulators alive, store nothing
