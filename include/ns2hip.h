@@ -75,11 +75,12 @@ int ns2_wavenet_block(const ns2_weight* w, const uint16_t* a_hi, const uint16_t*
                       int dilation, const float* conv_bias, const float* res_bias, const float* film, int film_ld,
                       uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream);
 
-/* Attend.forward (ATT:77-155), non-causal, head dim 64: o = softmax(q k^T * scale) v */
+/* Attend.forward (ATT:77-155), non-causal, head dim 64: o = softmax(q k^T * scale) v.
+ * key_mask (may be null): key-padding mask [B, Nk] bytes, 1 = attend (ATT:92-94 / 136-138) */
 int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi,
                   const uint16_t* k_lo, int ldk, int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld,
-                  uint16_t* o_hi, uint16_t* o_lo, int ldo, int B, int H, int Nq, int Nk, float scale, int precision,
-                  void* stream);
+                  uint16_t* o_hi, uint16_t* o_lo, int ldo, int B, int H, int Nq, int Nk, float scale,
+                  const uint8_t* key_mask, int precision, void* stream);
 
 /* RMSNorm.forward (NS2:727-746).  gamma may be null; cond (may be null) holds [gamma_c | beta_c] per batch row */
 int ns2_rmsnorm(const float* x, int ldx, int M, int d, int seq_len, const float* gamma, const float* cond, int cond_ld,

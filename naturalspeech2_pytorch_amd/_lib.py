@@ -41,7 +41,7 @@ SIGNATURES = {
     "ns2_geglu_pack_bias": (I, [P, I, P, I, P]),
     "ns2_linear_qkv": (I, [P, P, P, I, I, I, I, P, P, I, P, P, I, I, P]),
     "ns2_wavenet_block": (I, [P, P, P, I, I, I, I, P, P, P, I, P, P, I, I, P]),
-    "ns2_attention": (I, [P, P, I, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, F, I, P]),
+    "ns2_attention": (I, [P, P, I, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, F, P, I, P]),
     "ns2_rmsnorm": (I, [P, I, I, I, I, P, P, I, P, P, I, P, I, P]),
     "ns2_skinny_linear": (I, [P, I, P, P, P, I, I, I, I, I, P]),
     "ns2_time_embed": (I, [P, P, P, P, P, P, I, I, I, I, P]),

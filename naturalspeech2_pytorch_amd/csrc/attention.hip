@@ -161,15 +161,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
 
     // ---- online softmax for query l31; register r of sub-tile js is key key0 + 32js + 16(r>>3) + 8hi + (r&7)
     const bool tail = key0 + 64 > a.Nk;
+    const unsigned char* km = a.kmask ? a.kmask + (long)b * a.Nk : nullptr;
     float mx = -INFINITY;
 #pragma unroll
     for (int js = 0; js < 2; ++js)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float s = st[js][r] * sl2;
-        if (tail) {
+        if (tail || km) {
           const int key = key0 + 32 * js + 16 * (r >> 3) + 8 * hi + (r & 7);
           if (key >= a.Nk) s = -INFINITY;
+          else if (km && !km[key]) s = -3.0e38f;      // ATT:136-138 masked_fill(~mask, -finfo.max): finite, like the reference
         }
         st[js][r] = s;
         mx = fmaxf(mx, s);

@@ -131,15 +131,15 @@ extern "C" int ns2_wavenet_block(const ns2_weight* w, const uint16_t* a_hi, cons
 
 extern "C" int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi,
                              const uint16_t* k_lo, int ldk, int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld,
-                             uint16_t* o_hi, uint16_t* o_lo, int ldo, int B, int H, int Nq, int Nk, float scale, int precision,
-                             void* stream) {
+                             uint16_t* o_hi, uint16_t* o_lo, int ldo, int B, int H, int Nq, int Nk, float scale,
+                             const uint8_t* key_mask, int precision, void* stream) {
   ARGCHK(q_hi && k_hi && vt_hi && o_hi && prec_ok(precision), "ns2_attention: bad arguments");
   AttnArgs a;
   a.q_hi = q_hi; a.q_lo = q_lo; a.ldq = ldq; a.q_col0 = q_col0;
   a.k_hi = k_hi; a.k_lo = k_lo; a.ldk = ldk; a.k_col0 = k_col0;
   a.vt_hi = vt_hi; a.vt_lo = vt_lo; a.vt_ld = vt_ld;
   a.o_hi = o_hi; a.o_lo = o_lo; a.ldo = ldo;
-  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale; a.kmask = key_mask;
   HIPRET(launch_attention(a, precision, (hipStream_t)stream));
   return NS2_OK;
 }

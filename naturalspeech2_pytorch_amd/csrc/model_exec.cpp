@@ -561,6 +561,7 @@ static int attention_call(const bf16_t* q_hi, const bf16_t* q_lo, int ldq, int q
   a.vt_hi = vt.hi; a.vt_lo = vt.lo; a.vt_ld = vt_ld;
   a.o_hi = o.hi; a.o_lo = o.lo; a.ldo = ldo;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = 0.125f;       // dim_head ** -0.5  (ATT:128 / SDPA default)
+  a.kmask = nullptr;
   HIPCHK(launch_attention(a, prec, s));
   return NS2_OK;
 }

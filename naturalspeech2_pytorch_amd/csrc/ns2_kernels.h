@@ -53,6 +53,7 @@ struct AttnArgs {
   int q_col0, k_col0;
   int B, H, Nq, Nk;
   float scale;
+  const unsigned char* kmask;                            // optional key-padding mask [B, Nk], 1 = attend (ATT:92-94, 136-138)
 };
 hipError_t launch_attention(const AttnArgs& a, int nsplit, hipStream_t s);
 

@@ -147,11 +147,16 @@ def wavenet_block(w: PackedWeight, a: Planes, seq_len: int, dilation: int, conv_
 
 
 def attention(q: Planes, k: Planes, vt: Planes, B: int, H: int, Nq: int, Nk: int, q_col0=0, k_col0=0, scale=0.125,
-              precision=3) -> Planes:
+              precision=3, key_mask: Optional[torch.Tensor] = None) -> Planes:
+    """key_mask: optional bool/uint8 [B, Nk], True = attend (key-padding mask of ATT:92-94)."""
     out = empty_planes(B * Nq, H * 64, q[0].device)
+    km = None
+    if key_mask is not None:
+        km = key_mask.to(torch.uint8).contiguous()
+        assert km.shape == (B, Nk)
     check(_lib.load().ns2_attention(q[0].data_ptr(), _p(q[1]), q[0].shape[1], q_col0, k[0].data_ptr(), _p(k[1]), k[0].shape[1],
                                     k_col0, vt[0].data_ptr(), _p(vt[1]), vt[0].shape[-1], out[0].data_ptr(), out[1].data_ptr(),
-                                    H * 64, B, H, Nq, Nk, scale, precision, _stream()), "ns2_attention")
+                                    H * 64, B, H, Nq, Nk, scale, _p(km), precision, _stream()), "ns2_attention")
     return out
 
 

@@ -1,0 +1,66 @@
+"""`Transformer` — the reference's plain pre-norm encoder (NS2:1073-1115: RMSNorm -> Attention -> RMSNorm -> FeedForward
+without conv, optional key-padding mask), the block `PhonemeEncoder` / `SpeechPromptEncoder` are built from.  It is not on
+the per-step path; it shares the hot path's HIP kernels and is composed here from the op-level C ABI.
+Same constructor keywords and state_dict keys as the reference class.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .model import _Attention, _RMSNorm, _feedforward
+
+
+class Transformer(nn.Module):
+    def __init__(self, dim, *, depth, causal=False, dim_head=64, heads=8, use_flash=False, dropout=0., ff_mult=4,
+                 final_norm=False, precision="exact"):
+        super().__init__()
+        assert dim_head == 64, "the HIP attention kernel is specialised for dim_head 64 (the reference default)"
+        self.dim, self.depth, self.heads, self.causal, self.dropout = dim, depth, heads, causal, dropout
+        self.precision = precision
+        self.layers = nn.ModuleList([
+            nn.ModuleList([_RMSNorm(dim), _Attention(dim, dim_head, heads), _RMSNorm(dim), _feedforward(dim, ff_mult, False)])
+            for _ in range(depth)])
+        self.norm = _RMSNorm(dim) if final_norm else nn.Identity()
+        self._packed = None
+        self._sig = None
+
+    def _pack(self):
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is not None and self._sig == sig:
+            return self._packed
+        packed = []
+        for norm1, attn, norm2, ff in self.layers:
+            wqkv = torch.cat((attn.to_q.weight, attn.to_kv.weight), dim=0).detach().float().contiguous()
+            w1, w2 = getattr(ff, "0"), getattr(ff, "2")
+            f = w1.weight.shape[0] // 2
+            packed.append(dict(
+                g1=norm1.gamma.detach().float().contiguous(), g2=norm2.gamma.detach().float().contiguous(),
+                qkv=ops.PackedWeight(wqkv), out=ops.PackedWeight(attn.to_out.weight.detach().float().contiguous()),
+                w1=ops.PackedWeight(w1.weight.detach().float().contiguous(), geglu=True),
+                b1=ops.geglu_pack_bias(w1.bias.detach().float().contiguous(), f),
+                w2=ops.PackedWeight(w2.weight.detach().float().contiguous()), b2=w2.bias.detach().float().contiguous()))
+        self._packed, self._sig = packed, sig
+        return packed
+
+    @torch.no_grad()
+    def forward(self, x, mask=None):
+        """x [b, n, dim]; mask: optional bool [b, n] key-padding mask (True = attend)."""
+        if self.causal:
+            raise NotImplementedError("causal=True is not used by any reference caller of Transformer (NS2:252, 315)")
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("attention dropout is a training-time feature; the HIP path is inference-only")
+        b, n, d = x.shape
+        prec = 3 if self.precision == "exact" else 1
+        a = self.heads * 64
+        h = x.reshape(b * n, d).float().contiguous()
+        for pk in self._pack():
+            xn = ops.rmsnorm(h, gamma=pk["g1"])
+            qk, vt = ops.linear_qkv(pk["qkv"], xn, seq_len=n, split_col=2 * a, precision=prec)
+            o = ops.attention(qk, qk, vt, b, self.heads, n, n, q_col0=0, k_col0=a, precision=prec, key_mask=mask)
+            h = ops.linear_f32(pk["out"], o, resid=h, precision=prec)
+            xn = ops.rmsnorm(h, gamma=pk["g2"])
+            ffh = ops.linear_geglu(pk["w1"], xn, pk["b1"], precision=prec)
+            h = ops.linear_f32(pk["w2"], ffh, bias=pk["b2"], resid=h, precision=prec)
+        if isinstance(self.norm, _RMSNorm):
+            _, h = ops.rmsnorm(h, gamma=self.norm.gamma.detach().float().contiguous(), want_f32=True)
+        return h.reshape(b, n, d).to(x.dtype)

@@ -127,9 +127,28 @@ def gen_rvq():
         print(name, tuple(fix["indices"].shape), tuple(fix["emb"].shape))
 
 
+def gen_transformer(ns2):
+    """plain Transformer (NS2:1073-1115) with a key-padding mask, as PhonemeEncoder / SpeechPromptEncoder use it."""
+    kw = dict(dim=64, depth=2, final_norm=True)
+    m = ns2.Transformer(**kw).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(make_weights(shapes, seed=21))
+    x = make_input("x", (3, 50, 64), seed=22)
+    lens = torch.tensor([50, 17, 33])
+    mask = torch.arange(50)[None] < lens[:, None]
+    with torch.no_grad():
+        y_mask = m(x, mask=mask)
+        y_nomask = m(x)
+    torch.save(dict(kind="transformer", kwargs=kw, shapes=shapes, weight_seed=21, input_seed=22, lens=lens,
+                    out_masked=y_mask, out_unmasked=y_nomask, torch_version=torch.__version__),
+               os.path.join(OUT, "transformer_d64.pt"))
+    print("transformer", tuple(y_mask.shape))
+
+
 if __name__ == "__main__":
     gen_rvq()                     # before the reference stubs shadow torchaudio (transformers probes it)
     ns2 = load_reference()
     for name, spec in MODEL_CASES.items():
         gen_model_case(ns2, name, spec)
     gen_ddim(ns2)
+    gen_transformer(ns2)

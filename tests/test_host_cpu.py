@@ -42,6 +42,13 @@ def test_state_dict_contract_matches_reference(path):
     assert own == ref                                    # same keys, same order, same shapes as the reference Model
 
 
+def test_transformer_state_dict_contract():
+    from naturalspeech2_pytorch_amd import Transformer
+    fix = torch.load(os.path.join(GOLD, "transformer_d64.pt"), weights_only=False)
+    m = Transformer(**fix["kwargs"])
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(v)) for k, v in fix["shapes"].items()]
+
+
 def test_default_init_matches_reference_distributions():
     m = Model(dim=64, depth=1, dim_prompt=64, condition_on_prompt=True)
     assert m.null_cond.abs().sum() == 0                                  # NS2:881

@@ -187,6 +187,62 @@ def test_attention(B, H, Nq, Nk, prec):
     assert e < (3e-5 if prec == 3 else 2e-2), f"rel err {e}"
 
 
+def test_attention_key_padding_mask():
+    """ATT:136-138: masked keys get -finfo.max before the softmax (also when they are the first / middle keys)."""
+    B, H, Nq, Nk = 2, 2, 70, 150
+    a_dim = H * 64
+    q, k, v = rnd(B * Nq, a_dim, seed=60), rnd(B * Nk, a_dim, seed=61), rnd(B * Nk, a_dim, seed=62)
+    mask = torch.rand(B, Nk, generator=torch.Generator().manual_seed(63)) > 0.4
+    mask[0, :5] = False
+    mask = mask.to(DEV)
+    qp, kp = ops.split(q), ops.split(k)
+    vt_ld = ops.round_up(Nk, 8)
+    vt_f = torch.zeros(B, a_dim, vt_ld, device=DEV)
+    vt_f[:, :, :Nk] = v.reshape(B, Nk, a_dim).transpose(1, 2)
+    vp = ops.split(vt_f.reshape(B * a_dim, vt_ld), ldo=vt_ld)
+    vt = (vp[0].reshape(B, a_dim, vt_ld), vp[1].reshape(B, a_dim, vt_ld))
+    o = ops.attention(qp, kp, vt, B, H, Nq, Nk, key_mask=mask)
+
+    def heads(p, n):
+        return exact(p).reshape(B, n, H, 64).permute(0, 2, 1, 3)
+    ve = (vt[0].double() + vt[1].double())[:, :, :Nk].reshape(B, H, 64, Nk).transpose(2, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", heads(qp, Nq), heads(kp, Nk)) * 0.125
+    sim = sim.masked_fill(~mask[:, None, None, :], -torch.finfo(torch.float32).max)
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), ve).permute(0, 2, 1, 3).reshape(B * Nq, a_dim)
+    assert rel(ops.join(o), ref) < 3e-5
+
+
+def test_gemm_linearity_at_full_size():
+    """size-independent property at the headline GEMM shape: f(a x + b y) == a f(x) + b f(y) for the causal conv."""
+    B, N, C = 32, 1024, 512
+    w = rnd(C, C, 3, seed=70, scale=0.03)
+    pw = ops.PackedWeight(w)
+    x, y = rnd(B * N, C, seed=71), rnd(B * N, C, seed=72)
+    f = lambda t: ops.linear_f32(pw, ops.split(t), conv_taps=3, dilation=64, seq_len=N)   # noqa: E731
+    lhs = f(2.0 * x - 0.5 * y)
+    rhs = 2.0 * f(x) - 0.5 * f(y)
+    assert rel(lhs, rhs) < 5e-5
+    # causality: output at frame n depends only on frames <= n of the same utterance
+    x2 = x.clone().reshape(B, N, C)
+    x2[:, 700:] += 1.0
+    d = (f(x2.reshape(B * N, C)) - f(x)).reshape(B, N, C)
+    assert d[:, :700].abs().max().item() == 0.0 and d[:, 700:].abs().max().item() > 0.0
+
+
+def test_rvq_roundtrip_full_size():
+    """BASELINE config 4 size: residual + sum of selected codes reconstructs the latents; decode(codes) == emb."""
+    cb = make_input("codebooks", (8, 1024, 128), seed=81).to(DEV)
+    x = make_input("latents", (32 * 1024, 128), seed=82).to(DEV)
+    codes, emb, resid = ops.rvq_encode(x, cb, want_residual=True)
+    assert codes.min().item() >= 0 and codes.max().item() < 1024
+    assert torch.equal(ops.rvq_decode(codes, cb), emb)
+    assert (emb + resid - x).abs().max().item() < 1e-4
+    # each stage picks the nearest code: re-encoding the residual-free reconstruction of stage 0 is idempotent
+    c0 = cb[0][codes[:, 0]]
+    codes2, _ = ops.rvq_encode(c0.contiguous(), cb[:1].contiguous())
+    assert torch.equal(codes2[:, 0], codes[:, 0])
+
+
 def test_attention_spiked_softmax():
     """online-softmax rescale path: one key dominates late in the sequence (guide rule 26)."""
     B, H, Nq, Nk = 1, 1, 64, 256

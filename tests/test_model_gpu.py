@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 if not torch.cuda.is_available():
     pytest.skip("needs an MI355X", allow_module_level=True)
 
-from naturalspeech2_pytorch_amd import Model, NaturalSpeech2  # noqa: E402
+from naturalspeech2_pytorch_amd import Model, NaturalSpeech2, Transformer  # noqa: E402
 from oracle import ns2_oracle as O  # noqa: E402
 from tests.golden.gen import make_weights, make_input  # noqa: E402
 
@@ -196,3 +196,28 @@ def test_training_path_autograd():
     loss = d(audio)
     loss.backward()
     assert torch.isfinite(loss) and getattr(m.transformer.to_pred, "1").weight.grad is not None
+
+
+def test_plain_transformer_matches_reference_golden():
+    """NS2:1073-1115 with and without the key-padding mask (the block of PhonemeEncoder / SpeechPromptEncoder)."""
+    fix = torch.load(os.path.join(GOLD, "transformer_d64.pt"), weights_only=False)
+    m = Transformer(**fix["kwargs"])
+    own = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert own == {k: tuple(v) for k, v in fix["shapes"].items()}
+    m.load_state_dict(make_weights(own, seed=fix["weight_seed"]))
+    m = m.to(DEV).eval()
+    x = make_input("x", (3, 50, 64), seed=fix["input_seed"]).to(DEV)
+    mask = (torch.arange(50)[None] < fix["lens"][:, None]).to(DEV)
+    assert rel(m(x, mask=mask), fix["out_masked"]) < 1e-4
+    assert rel(m(x), fix["out_unmasked"]) < 1e-4
+
+
+def test_sharded_sampler_matches_single_batch():
+    """SURVEY §8e criterion on one GPU: 2 sequential shards of the sampler == one batch, same per-utterance noise."""
+    from naturalspeech2_pytorch_amd import distributed as D
+    m, _ = build(dict(dim=64, depth=1), seed=18)
+    d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=3)
+    fn = lambda noise: d.ddim_sample(tuple(noise.shape), noise=noise)   # noqa: E731
+    full = fn(D.utterance_noise(0, 6, 32, 64, seed=9, device=DEV))
+    parts = [fn(D.utterance_noise(*D.shard_range(6, r, 2), 32, 64, seed=9, device=DEV)) for r in range(2)]
+    assert rel(torch.cat(parts), full) < 1e-6
