@@ -50,15 +50,17 @@ int ns2_split_f32(const float* x, int ldx, int M, int d, uint16_t* out_hi, uint1
 int ns2_join_f32(const uint16_t* hi, const uint16_t* lo, int ld, float* out, int ldo, int64_t M, int d, void* stream);
 
 /* nn.Linear / CausalConv1d as one GEMM (NS2:1051-1069, 1021-1024, 583-595).
- * conv_taps = 0 for a Linear, 3 for CausalConv1d(k=3) with `dilation`; seq_len = tokens per utterance.
- * out = A W^T + bias (+ resid), fp32 */
+ * conv_taps = 0 for a Linear, k for a Conv1d(kernel k) with `dilation`; seq_len = tokens per utterance (rows never read
+ * across utterances); pad_left = zero frames in front of the sequence: -1 = causal (k-1, CausalConv1d NS2:583-595),
+ * (k-1)/2 = the "same" padding of SpeechPromptEncoder's convs (NS2:316).  act: 0 none, 1 SiLU after the bias.
+ * out = act(A W^T + bias) (+ resid), fp32 */
 int ns2_linear_f32(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
                    int dilation, int seq_len, const float* bias, const float* resid, int ldr, float* out, int ldo,
-                   int precision, void* stream);
+                   int pad_left, int act, int precision, void* stream);
 /* same, output as split planes [M, ldo] */
 int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
                      int dilation, int seq_len, const float* bias, uint16_t* out_hi, uint16_t* out_lo, int ldo,
-                     int precision, void* stream);
+                     int pad_left, int act, int precision, void* stream);
 /* FeedForward first half: GEGLU(Linear(x)) (NS2:1004-1007, 1021); w packed with geglu=1; packed_bias from
  * ns2_geglu_pack_bias; out planes [M, ldo] with ldo = round_up(f, 32) */
 int ns2_linear_geglu(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M,
@@ -93,6 +95,8 @@ int ns2_skinny_linear(const float* in, int ld_in, const float* wt, const float* 
 int ns2_time_embed(const float* times, const float* freqs, const float* wt, const float* bias, float* feat_ws, float* out,
                    int ld_out, int B, int dim, int dt, void* stream);
 int ns2_transpose_f32(const float* in, int batch, int R, int C, float* out, void* stream);
+/* nn.Embedding gather, ids < 0 -> pad_id (PhonemeEncoder NS2:281-284) */
+int ns2_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int dim, int64_t pad_id, void* stream);
 
 /* one DDIM update (NS2:1396-1430): audio <- f(audio, model_out, times, times_next).  objective 0 'v', 1 'eps', 2 'x0';
  * schedule 0 sigmoid, 1 cosine, 2 linear (NS2:1133-1148) */

@@ -35,8 +35,8 @@ SIGNATURES = {
     "ns2_weight_free": (None, [P]),
     "ns2_split_f32": (I, [P, I, I, I, P, P, I, P]),
     "ns2_join_f32": (I, [P, P, I, P, I, L, I, P]),
-    "ns2_linear_f32": (I, [P, P, P, I, I, I, I, I, P, P, I, P, I, I, P]),
-    "ns2_linear_split": (I, [P, P, P, I, I, I, I, I, P, P, P, I, I, P]),
+    "ns2_linear_f32": (I, [P, P, P, I, I, I, I, I, P, P, I, P, I, I, I, I, P]),
+    "ns2_linear_split": (I, [P, P, P, I, I, I, I, I, P, P, P, I, I, I, I, P]),
     "ns2_linear_geglu": (I, [P, P, P, I, I, P, P, P, I, I, P]),
     "ns2_geglu_pack_bias": (I, [P, I, P, I, P]),
     "ns2_linear_qkv": (I, [P, P, P, I, I, I, I, P, P, I, P, P, I, I, P]),
@@ -46,6 +46,7 @@ SIGNATURES = {
     "ns2_skinny_linear": (I, [P, I, P, P, P, I, I, I, I, I, P]),
     "ns2_time_embed": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "ns2_transpose_f32": (I, [P, I, I, I, P, P]),
+    "ns2_embedding": (I, [P, P, P, L, I, L, P]),
     "ns2_ddim_step": (I, [P, P, P, P, P, I, L, I, I, F, P]),
     "ns2_cfg_mix": (I, [P, P, P, L, F, P]),
     "ns2_rvq_prepare": (I, [P, P, I, I, I, P]),

@@ -79,19 +79,23 @@ extern "C" int ns2_join_f32(const uint16_t* hi, const uint16_t* lo, int ld, floa
 
 extern "C" int ns2_linear_f32(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
                               int dilation, int seq_len, const float* bias, const float* resid, int ldr, float* out, int ldo,
-                              int precision, void* stream) {
+                              int pad_left, int act, int precision, void* stream) {
   ARGCHK(w && a_hi && out && prec_ok(precision), "ns2_linear_f32: bad arguments");
   ARGCHK(!w->geglu && !w->has_extra && (conv_taps == 0 ? w->taps == 1 : w->taps == conv_taps), "ns2_linear_f32: weight packing does not match");
   ARGCHK(lda >= w->cols_p, "ns2_linear_f32: lda smaller than the padded K");
-  return gemm_f32(w->w, a_hi, a_lo, lda, M, conv_taps, dilation, seq_len, bias, resid, ldr, out, ldo, precision, (hipStream_t)stream);
+  ARGCHK(pad_left >= -1 && pad_left < (conv_taps > 0 ? conv_taps : 1) && (act == 0 || act == 1), "ns2_linear_f32: bad pad_left / act");
+  return gemm_f32(w->w, a_hi, a_lo, lda, M, conv_taps, dilation, seq_len, bias, resid, ldr, out, ldo, precision, (hipStream_t)stream,
+                  pad_left, act);
 }
 extern "C" int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
                                 int dilation, int seq_len, const float* bias, uint16_t* out_hi, uint16_t* out_lo, int ldo,
-                                int precision, void* stream) {
+                                int pad_left, int act, int precision, void* stream) {
   ARGCHK(w && a_hi && out_hi && prec_ok(precision), "ns2_linear_split: bad arguments");
   ARGCHK(!w->geglu && !w->has_extra && (conv_taps == 0 ? w->taps == 1 : w->taps == conv_taps), "ns2_linear_split: weight packing does not match");
   ARGCHK(lda >= w->cols_p && (ldo & 1) == 0, "ns2_linear_split: bad leading dimensions");
-  return gemm_split(w->w, a_hi, a_lo, lda, M, conv_taps, dilation, seq_len, bias, out_hi, out_lo, ldo, precision, (hipStream_t)stream);
+  ARGCHK(pad_left >= -1 && pad_left < (conv_taps > 0 ? conv_taps : 1) && (act == 0 || act == 1), "ns2_linear_split: bad pad_left / act");
+  return gemm_split(w->w, a_hi, a_lo, lda, M, conv_taps, dilation, seq_len, bias, out_hi, out_lo, ldo, precision, (hipStream_t)stream,
+                    pad_left, act);
 }
 extern "C" int ns2_linear_geglu(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M,
                                 const float* packed_bias, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream) {
@@ -166,6 +170,11 @@ extern "C" int ns2_time_embed(const float* times, const float* freqs, const floa
                               float* out, int ld_out, int B, int dim, int dt, void* stream) {
   ARGCHK(times && freqs && wt && feat_ws && out, "ns2_time_embed: null pointer");
   HIPRET(launch_time_embed(times, freqs, wt, bias, feat_ws, out, ld_out, B, dim, dt, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int dim, int64_t pad_id, void* stream) {
+  ARGCHK(ids && table && out && n > 0 && dim > 0, "ns2_embedding: bad arguments");
+  HIPRET(launch_embedding(ids, table, out, (long)n, dim, (long)pad_id, (hipStream_t)stream));
   return NS2_OK;
 }
 extern "C" int ns2_transpose_f32(const float* in, int batch, int R, int C, float* out, void* stream) {

@@ -308,6 +308,22 @@ hipError_t launch_bcast_rows(const float* src, float* out, int B, long row_elems
   return hipGetLastError();
 }
 
+// nn.Embedding gather with the reference's padding rule (NS2:281-282: ids < 0 -> pad_id)
+__global__ void embedding_kernel(const int64_t* ids, const float* table, float* out, long n, int dim, long pad_id) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * dim) return;
+  const long r = i / dim;
+  const int c = (int)(i - r * dim);
+  long id = ids[r];
+  if (id < 0) id = pad_id;
+  out[i] = table[id * dim + c];
+}
+hipError_t launch_embedding(const int64_t* ids, const float* table, float* out, long n, int dim, long pad_id, hipStream_t s) {
+  const long tot = n * dim;
+  hipLaunchKernelGGL(embedding_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ids, table, out, n, dim, pad_id);
+  return hipGetLastError();
+}
+
 // dst[c * ld_dst + col_off + r] = src[r * C + c]   (nn.Linear weight [R=out, C=in] -> K-major slice of a wider matrix)
 __global__ void transpose_into_kernel(const float* src, int R, int C, float* dst, long ld_dst, long col_off) {
   __shared__ float tile[32][33];

@@ -72,17 +72,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     skc[i] = c & 3;
     int m = tm * BM + srow[i];
     arow_ok[i] = m < g.M;
-    nseq[i] = (g.seq_len > 0) ? (m % g.seq_len) : 0x3fffffff;
+    nseq[i] = (g.seq_len > 0) ? (m % g.seq_len) : 0x3fffffff;   // 0x3fffffff: no sequence structure, never shifted
   }
 
   auto load_stage = [&](Stage<NSPLIT>& st, int kt) {
     const int tap = kt / g.kt_per_tap;
     const int kcol = (kt - tap * g.kt_per_tap) * BK;
-    const int shift = (tap < g.conv_taps) ? (g.conv_taps - 1 - tap) * dil : 0;
+    const int pl = g.pad_left < 0 ? g.conv_taps - 1 : g.pad_left;        // causal: all padding on the left (NS2:583-595)
+    const int shift = (tap < g.conv_taps) ? (pl - tap) * dil : 0;
+    const unsigned slim = g.seq_len > 0 ? (unsigned)g.seq_len : 0x7fffffffu;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const long m = (long)tm * BM + srow[i];
-      const bool ok = arow_ok[i] && (nseq[i] >= shift);
+      const bool ok = arow_ok[i] && ((unsigned)(nseq[i] - shift) < slim);   // source row inside the same utterance
       const long aoff = (m - shift) * (long)g.lda + kcol + skc[i] * 8;
       const long woff = ((long)tn * BN + srow[i]) * (long)g.ldw + (long)kt * BK + skc[i] * 8;
 #pragma unroll

@@ -104,11 +104,13 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
     const int it = kt - tap * tpt;
     const bool half = half_tail && (it == tpt - 1);
     if (a_wave) {
-      const int shift = (tap < g.conv_taps) ? (g.conv_taps - 1 - tap) * dil : 0;
+      const int pl = g.pad_left < 0 ? g.conv_taps - 1 : g.pad_left;      // causal: all padding on the left (NS2:583-595)
+      const int shift = (tap < g.conv_taps) ? (pl - tap) * dil : 0;
+      const unsigned slim = g.seq_len > 0 ? (unsigned)g.seq_len : 0x7fffffffu;
       const long off = (long)it * BK - (long)shift * g.lda;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const bool ok = (nseq[i] >= shift) && !(half && lchunk_hi[i]);
+        const bool ok = ((unsigned)(nseq[i] - shift) < slim) && !(half && lchunk_hi[i]);   // nseq = -1 marks rows >= M
         const bf16_t* p = ok ? (src[i] + off) : zero_page;
         glds16(p, sbase + ldst[i]);
       }

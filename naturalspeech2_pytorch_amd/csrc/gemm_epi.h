@@ -61,6 +61,7 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
           const int row = row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           if (row >= g.M) continue;
           float v = acc[mi][ni][r] + bc;
+          if (g.act == 1) v = siluf(v);
           if (g.resid) v += g.resid[(long)row * g.ldr + col];
           g.out_f[(long)row * g.ldo_f + col] = v;
         }
@@ -114,7 +115,8 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
         if (!transposed) {
 #pragma unroll
           for (int rp = 0; rp < 8; ++rp) {
-            const float v0 = acc[mi][ni][2 * rp] + bc, v1 = acc[mi][ni][2 * rp + 1] + bc;
+            float v0 = acc[mi][ni][2 * rp] + bc, v1 = acc[mi][ni][2 * rp + 1] + bc;
+            if (EPI == EPI_SPLIT && g.act == 1) { v0 = siluf(v0); v1 = siluf(v1); }
             const float send = odd ? v0 : v1;
             const float recv = __shfl_xor(send, 1, 64);
             // columns (col&~1, col|1): even lane holds its own col then the neighbour's, odd lane the reverse
@@ -211,7 +213,9 @@ NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][2], const GemmArgs& g, int z,
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int lr = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            *reinterpret_cast<float*>(wbuf + lr * RS + (ni * 32 + l31) * 4) = acc[half * 2 + mh][ni][r] + bc;
+            float t = acc[half * 2 + mh][ni][r] + bc;
+            if (g.act == 1) t = siluf(t);
+            *reinterpret_cast<float*>(wbuf + lr * RS + (ni * 32 + l31) * 4) = t;
           }
         }
 #pragma unroll

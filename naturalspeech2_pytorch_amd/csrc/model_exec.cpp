@@ -185,7 +185,7 @@ static GemmArgs base_args(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_
   g.a_hi = a_hi; g.a_lo = a_lo; g.lda = lda;
   g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk;
   g.M = M; g.N = w.N; g.nkt = w.nkt; g.kt_per_tap = w.nkt; g.conv_taps = 0; g.dil = 1; g.mid_kt = -1;
-  g.nz = 1;
+  g.nz = 1; g.pad_left = -1; g.act = 0;
   { const char* e = getenv("NS2_DBG"); g.dbg = e ? atoi(e) : 0; }
   return g;
 }
@@ -194,17 +194,19 @@ static void set_conv(GemmArgs& g, const PackedW& w, int taps, int dil, int seq_l
 }
 
 int gemm_f32(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
-             const float* bias, const float* resid, int ldr, float* out, int ldo, int prec, hipStream_t s) {
+             const float* bias, const float* resid, int ldr, float* out, int ldo, int prec, hipStream_t s, int pad_left, int act) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
   if (conv_taps) set_conv(g, w, conv_taps, dil, seq_len);
+  g.pad_left = pad_left; g.act = act;
   g.epi = EPI_F32; g.bias = bias; g.resid = resid; g.ldr = ldr; g.out_f = out; g.ldo_f = ldo;
   HIPCHK(launch_gemm(g, prec, s));
   return NS2_OK;
 }
 int gemm_split(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
-               const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s) {
+               const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left, int act) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
   if (conv_taps) set_conv(g, w, conv_taps, dil, seq_len);
+  g.pad_left = pad_left; g.act = act;
   g.epi = EPI_SPLIT; g.bias = bias; g.out_hi = o_hi; g.out_lo = o_lo; g.ldo_s = ldo; g.out_ncols = ldo;
   HIPCHK(launch_gemm(g, prec, s));
   return NS2_OK;

@@ -38,6 +38,8 @@ struct GemmArgs {
   bf16_t* vt_hi; bf16_t* vt_lo; int vt_ld; int vt_rows; int split_col;
   // batching over blockIdx-z (wavenet columns): element offsets per z
   int nz; long a_zs, w_zs, bias_zs, film_zs, out_zs;
+  int pad_left;      // conv: zero rows in front of the sequence (-1 = causal: conv_taps-1); k=9 'same' padding = 4
+  int act;           // 1 = SiLU after the bias (EPI_F32 / EPI_SPLIT)
   int dbg;           // ablation switches (only honoured by -DNS2_ABLATE builds): 1 = no DMA after the first tile, 2 = no MFMA
 };
 
@@ -90,6 +92,7 @@ hipError_t launch_mean_rows(const float* in, int B, int n, int d, float* out, hi
 // out[b*ld_out + e] = src[e] for e < row_elems (broadcast a parameter row over the batch)
 hipError_t launch_bcast_rows(const float* src, float* out, int B, long row_elems, long ld_out, hipStream_t s);
 
+hipError_t launch_embedding(const int64_t* ids, const float* table, float* out, long n, int dim, long pad_id, hipStream_t s);
 hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s);
 hipError_t launch_transpose_into(const float* src, int R, int C, float* dst, long ld_dst, long col_off, hipStream_t s);
 

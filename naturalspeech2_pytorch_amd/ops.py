@@ -81,22 +81,23 @@ class PackedWeight:
 
 
 def linear_f32(w: PackedWeight, a: Planes, M: Optional[int] = None, bias=None, resid=None, conv_taps=0, dilation=1,
-               seq_len=0, precision=3) -> torch.Tensor:
+               seq_len=0, precision=3, pad_left=-1, act=0) -> torch.Tensor:
     hi, lo = a
     M = M or hi.shape[0]
     out = torch.empty(M, w.rows, dtype=torch.float32, device=hi.device)
     check(_lib.load().ns2_linear_f32(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, conv_taps, dilation, seq_len, _p(bias),
-                                     _p(resid), w.rows, out.data_ptr(), w.rows, precision, _stream()), "ns2_linear_f32")
+                                     _p(resid), w.rows, out.data_ptr(), w.rows, pad_left, act, precision, _stream()), "ns2_linear_f32")
     return out
 
 
-def linear_split(w: PackedWeight, a: Planes, bias=None, conv_taps=0, dilation=1, seq_len=0, precision=3, ldo=None) -> Planes:
+def linear_split(w: PackedWeight, a: Planes, bias=None, conv_taps=0, dilation=1, seq_len=0, precision=3, ldo=None, pad_left=-1,
+                 act=0) -> Planes:
     hi, lo = a
     M = hi.shape[0]
     ldo = ldo or round_up(w.rows, 32)
     out = empty_planes(M, ldo, hi.device)
     check(_lib.load().ns2_linear_split(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, conv_taps, dilation, seq_len, _p(bias),
-                                       out[0].data_ptr(), out[1].data_ptr(), ldo, precision, _stream()), "ns2_linear_split")
+                                       out[0].data_ptr(), out[1].data_ptr(), ldo, pad_left, act, precision, _stream()), "ns2_linear_split")
     return out
 
 
@@ -169,6 +170,15 @@ def rmsnorm(x: torch.Tensor, seq_len: int = 0, gamma=None, cond=None, want_f32=F
     check(_lib.load().ns2_rmsnorm(x.data_ptr(), d, M, d, seq_len, _p(gamma), _p(cond), cond.shape[1] if cond is not None else 0,
                                   out[0].data_ptr(), out[1].data_ptr(), ldo, _p(of), d, _stream()), "ns2_rmsnorm")
     return (out, of) if want_f32 else out
+
+
+def embedding(ids: torch.Tensor, table: torch.Tensor, pad_id: int) -> torch.Tensor:
+    """ids [..] int64 (negative = padding -> pad_id), table [V, dim] -> [.., dim] fp32."""
+    ids = ids.contiguous().to(torch.int64)
+    out = torch.empty(*ids.shape, table.shape[1], dtype=torch.float32, device=table.device)
+    check(_lib.load().ns2_embedding(ids.data_ptr(), _f32(table).data_ptr(), out.data_ptr(), ids.numel(), table.shape[1], pad_id,
+                                    _stream()), "ns2_embedding")
+    return out
 
 
 def skinny_linear(x: torch.Tensor, wt: torch.Tensor, bias=None, act=0) -> torch.Tensor:

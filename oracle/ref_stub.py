@@ -50,7 +50,9 @@ def _install_stubs():
         bt = _mod("beartype", beartype=lambda f: f)
         bt.typing = _mod("beartype.typing", **{k: getattr(typing, k) for k in
                                                ("Tuple", "Union", "Optional", "List", "Dict", "Callable", "Any")})
-        bt.door = _mod("beartype.door", is_bearable=lambda obj, hint: True)
+        def _is_bearable(obj, hint):            # only use in the reference: is_bearable(x, List[str]) at NS2:277
+            return isinstance(obj, (list, tuple)) and all(isinstance(e, str) for e in obj)
+        bt.door = _mod("beartype.door", is_bearable=_is_bearable)
     if "ema_pytorch" not in sys.modules:
         _mod("ema_pytorch", EMA=_Dummy)
     for name in ("pyworld", "inflect", "num2words", "num_to_words"):

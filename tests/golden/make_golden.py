@@ -145,6 +145,32 @@ def gen_transformer(ns2):
     print("transformer", tuple(y_mask.shape))
 
 
+def gen_encoders(ns2):
+    """SpeechPromptEncoder (NS2:289-341) and PhonemeEncoder (NS2:228-287) at reduced widths."""
+    kw = dict(dim_codebook=128, dims=(64, 96, 64), depth=2)
+    m = ns2.SpeechPromptEncoder(**kw).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(make_weights(shapes, seed=31))
+    x = make_input("prompt", (2, 37, 128), seed=32)
+    with torch.no_grad():
+        y = m(x)
+    torch.save(dict(kind="speech_prompt_encoder", kwargs=kw, shapes=shapes, weight_seed=31, input_seed=32, out=y,
+                    torch_version=torch.__version__), os.path.join(OUT, "speech_prompt_encoder.pt"))
+    kw = dict(num_tokens=50, dim=64, dim_hidden=96, depth=2)
+    m = ns2.PhonemeEncoder(**kw).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(make_weights(shapes, seed=33))
+    ids = torch.randint(0, 50, (3, 29), generator=torch.Generator().manual_seed(34))
+    lens = torch.tensor([29, 11, 20])
+    ids = torch.where(torch.arange(29)[None] < lens[:, None], ids, torch.full_like(ids, -1))   # negative = padding (NS2:281)
+    mask = torch.arange(29)[None] < lens[:, None]
+    with torch.no_grad():
+        y = m(ids, mask=mask)
+    torch.save(dict(kind="phoneme_encoder", kwargs=kw, shapes=shapes, weight_seed=33, ids=ids, lens=lens, out=y,
+                    torch_version=torch.__version__), os.path.join(OUT, "phoneme_encoder.pt"))
+    print("encoders ok")
+
+
 if __name__ == "__main__":
     gen_rvq()                     # before the reference stubs shadow torchaudio (transformers probes it)
     ns2 = load_reference()
@@ -152,3 +178,4 @@ if __name__ == "__main__":
         gen_model_case(ns2, name, spec)
     gen_ddim(ns2)
     gen_transformer(ns2)
+    gen_encoders(ns2)

@@ -100,6 +100,33 @@ def test_causal_conv(B, N, Cin, Cout, dil, prec, gemm_kernel):
     assert ops.join(ys)[:, Cout:].abs().sum().item() == 0.0
 
 
+@pytest.mark.parametrize("B,N,Cin,Cout,k,pad", [(2, 100, 64, 96, 9, 4), (3, 37, 128, 300, 9, 4), (2, 60, 96, 64, 9, -1), (1, 5, 64, 64, 9, 4)])
+def test_conv_k9_same_padding_silu(B, N, Cin, Cout, k, pad, gemm_kernel):
+    """SpeechPromptEncoder convs (NS2:316: Conv1d(k=9, padding=4) + SiLU) and PhonemeEncoder's causal k=9 conv."""
+    x = rnd(B * N, Cin, seed=90)
+    w = rnd(Cout, Cin, k, seed=91, scale=1 / math.sqrt(k * Cin))
+    b = rnd(Cout, seed=92)
+    pw = ops.PackedWeight(w)
+    a = ops.split(x)
+    xe = exact(a)[:, :Cin].reshape(B, N, Cin).transpose(1, 2)
+    if pad < 0:
+        ref = F.conv1d(F.pad(xe, (k - 1, 0)), w.double(), b.double())
+    else:
+        ref = F.conv1d(xe, w.double(), b.double(), padding=pad)
+    ref = F.silu(ref).transpose(1, 2).reshape(B * N, Cout)
+    y = ops.linear_f32(pw, a, bias=b, conv_taps=k, seq_len=N, pad_left=pad, act=1)
+    assert rel(y, ref) < 2e-5
+    ys = ops.linear_split(pw, a, bias=b, conv_taps=k, seq_len=N, pad_left=pad, act=1)
+    assert rel(ops.join(ys, Cout), ref) < 3e-5
+
+
+def test_embedding_padding_ids():
+    table = rnd(11, 32, seed=93)
+    ids = torch.tensor([[0, 5, -1, 9], [-3, 10, 2, 2]], device=DEV)
+    out = ops.embedding(ids, table, pad_id=10)
+    assert torch.equal(out, table[ids.masked_fill(ids < 0, 10)])
+
+
 @pytest.mark.parametrize("prec", [3, 1])
 @pytest.mark.parametrize("M,K,f", [(256, 64, 170), (500, 128, 341), (1024, 512, 1365)])
 def test_geglu(M, K, f, prec, gemm_kernel):

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 if not torch.cuda.is_available():
     pytest.skip("needs an MI355X", allow_module_level=True)
 
-from naturalspeech2_pytorch_amd import Model, NaturalSpeech2, Transformer  # noqa: E402
+from naturalspeech2_pytorch_amd import Model, NaturalSpeech2, Transformer, PhonemeEncoder, SpeechPromptEncoder  # noqa: E402
 from oracle import ns2_oracle as O  # noqa: E402
 from tests.golden.gen import make_weights, make_input  # noqa: E402
 
@@ -221,3 +221,24 @@ def test_sharded_sampler_matches_single_batch():
     full = fn(D.utterance_noise(0, 6, 32, 64, seed=9, device=DEV))
     parts = [fn(D.utterance_noise(*D.shard_range(6, r, 2), 32, 64, seed=9, device=DEV)) for r in range(2)]
     assert rel(torch.cat(parts), full) < 1e-6
+
+
+def test_encoders_match_reference_golden():
+    """SpeechPromptEncoder (k=9 'same' convs + SiLU) and PhonemeEncoder (embedding, causal k=9 conv, mask)."""
+    fix = torch.load(os.path.join(GOLD, "speech_prompt_encoder.pt"), weights_only=False)
+    m = SpeechPromptEncoder(**fix["kwargs"])
+    own = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert own == {k: tuple(v) for k, v in fix["shapes"].items()}
+    m.load_state_dict(make_weights(own, seed=fix["weight_seed"]))
+    m = m.to(DEV).eval()
+    x = make_input("prompt", (2, 37, 128), seed=fix["input_seed"]).to(DEV)
+    assert rel(m(x), fix["out"]) < 1e-4
+
+    fix = torch.load(os.path.join(GOLD, "phoneme_encoder.pt"), weights_only=False)
+    m = PhonemeEncoder(**fix["kwargs"])
+    own = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert own == {k: tuple(v) for k, v in fix["shapes"].items()}
+    m.load_state_dict(make_weights(own, seed=fix["weight_seed"]))
+    m = m.to(DEV).eval()
+    mask = (torch.arange(29)[None] < fix["lens"][:, None]).to(DEV)
+    assert rel(m(fix["ids"].to(DEV), mask=mask), fix["out"]) < 1e-4
