@@ -112,6 +112,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
       for (int i = 0; i < 8; ++i) {
         const bool ok = ((unsigned)(nseq[i] - shift) < slim) && !(half && lchunk_hi[i]);   // nseq = -1 marks rows >= M
         const bf16_t* p = ok ? (src[i] + off) : zero_page;
+#ifdef G2_CONTIG
+        p = g.a_hi + (long)tm * 256 * g.lda + (((kt * 64 + (wave & 3) * 8 + i) * 512) & 0x3ffff) + lane * 8;
+#endif
         glds16(p, sbase + ldst[i]);
       }
     } else {
@@ -119,6 +122,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bf16_t* p = (half && lchunk_hi[i]) ? zero_page : (src[i] + off);
+#ifdef G2_CONTIG
+        p = g.w_hi + (long)tn * 256 * g.ldw + (((kt * 64 + (wave & 3) * 8 + i) * 512) & 0x3ffff) + lane * 8;
+#endif
         glds16(p, sbase + ldst[i]);
       }
     }
@@ -148,11 +154,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                  // tile kt0 landed for every wave
     for (int kt = kt0; kt < kt1; ++kt) {
-#ifdef NS2_ABLATE
-      if (kt + 1 < kt1 && !(g.dbg & 1)) issue_tile(kt + 1, (kt + 1) & 1);
-#else
-      if (kt + 1 < kt1) issue_tile(kt + 1, (kt + 1) & 1);
-#endif
+      // Anti-phase DMA issue: an LDS-DMA instruction blocks its wave for ~60-180 clocks at issue.  The A-streaming
+      // waves 0-3 (one per SIMD) issue theirs now, while their SIMD partners 4-7 already run MFMAs; waves 4-7 issue
+      // the W half after their first K step, when waves 0-3 are in their MFMA phase (measured +5 % on the FF conv).
+      if (kt + 1 < kt1 && a_wave) issue_tile(kt + 1, (kt + 1) & 1);
       const unsigned char* sb = smem + (kt & 1) * STAGE;
       if (wave_active) {
 #pragma unroll
@@ -190,7 +195,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
             }
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], wf[0][ni], acc[mi][ni], 0, 0, 0);
           }
+        if (kc == 0 && kt + 1 < kt1 && !a_wave) issue_tile(kt + 1, (kt + 1) & 1);
       }
+      } else if (kt + 1 < kt1 && !a_wave) {
+        issue_tile(kt + 1, (kt + 1) & 1);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile has landed
       __syncthreads();                                // ... everybody's has, and this stage is free to overwrite
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
 #endif
   if constexpr (EPI == EPI_F32) {
     if (epi_lds_supported<EPI>(g, row_base)) {
-      gemm_epilogue_lds<EPI>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane, smem + wave * EPI_LDS_WAVE_BYTES);
+      gemm_epilogue_lds<EPI, 2, 0>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane, smem + wave * EPI_LDS_WAVE_BYTES);
       return;
     }
   }
@@ -232,6 +240,8 @@ static const bf16_t* zero_page() {
   }
   return p;
 }
+
+const bf16_t* gemm_zero_page() { return zero_page(); }
 
 template <int NSPLIT, int EPI>
 static hipError_t launch2_one(const GemmArgs& g, hipStream_t s) {
@@ -264,6 +274,7 @@ static hipError_t launch2_epi(const GemmArgs& g, hipStream_t s) {
 }
 
 hipError_t launch_gemm1(const GemmArgs& g, int nsplit, hipStream_t s);   // gemm.hip (128x128 register-staged kernel)
+hipError_t launch_gemm3(const GemmArgs& g, int nsplit, hipStream_t s);   // gemm3.hip (256x256, 4 waves, software-pipelined)
 
 static int g_forced_kernel = -1;     // -1: read NS2_GEMM once; 0 auto; 1 / 2 force a kernel (tests exercise both)
 void force_gemm_kernel(int k) { g_forced_kernel = k; }
@@ -281,8 +292,9 @@ hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.nkt <= 0 || g.kt_per_tap <= 0 || (g.nkt % g.kt_per_tap)) return hipErrorInvalidValue;
   if (nsplit == 3 && (!g.a_lo || !g.w_lo)) return hipErrorInvalidValue;
   const int f = forced_kernel();
-  const bool big = (f == 2) || (f != 1 && g.N > 128);
+  const bool big = (f >= 2) || (f != 1 && g.N > 128);
   if (!big) return launch_gemm1(g, nsplit, s);
+  if (f == 3) return launch_gemm3(g, nsplit, s);
   return nsplit == 3 ? launch2_epi<3>(g, s) : launch2_epi<1>(g, s);
 }
 

@@ -67,10 +67,12 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
         }
       }
   } else if constexpr (EPI == EPI_GEGLU) {
-    // wave tile = [x(32 cols) | gate(32 cols)] ; out[:, ocol] = gelu(gate) * x   (NS2:1006-1007)
-    static_assert(EPI != EPI_GEGLU || NI == 2, "GEGLU needs a 64-column wave tile");
-    const int ocol = ocol_base + l31;
-    const int cx = col_base + l31, cg = col_base + 32 + l31;
+    // wave tile = NI/2 x [x(32 cols) | gate(32 cols)] ; out[:, ocol] = gelu(gate) * x   (NS2:1006-1007)
+    static_assert(EPI != EPI_GEGLU || (NI % 2) == 0, "GEGLU needs 64-column [x|gate] groups");
+#pragma unroll
+    for (int np = 0; np < NI / 2; ++np) {
+    const int ocol = ocol_base + np * 32 + l31;
+    const int cx = col_base + np * 64 + l31, cg = cx + 32;
     const float bx = g.bias[cx], bg = g.bias[cg];      // packed (padded) bias: always in range
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -78,8 +80,8 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
       for (int rp = 0; rp < 8; ++rp) {
         float v0, v1;
         {
-          const float x0 = acc[mi][0][2 * rp] + bx, g0 = acc[mi][1][2 * rp] + bg;
-          const float x1 = acc[mi][0][2 * rp + 1] + bx, g1 = acc[mi][1][2 * rp + 1] + bg;
+          const float x0 = acc[mi][2 * np][2 * rp] + bx, g0 = acc[mi][2 * np + 1][2 * rp] + bg;
+          const float x1 = acc[mi][2 * np][2 * rp + 1] + bx, g1 = acc[mi][2 * np + 1][2 * rp + 1] + bg;
           v0 = gelu_erf(g0) * x0;
           v1 = gelu_erf(g1) * x1;
         }
@@ -98,6 +100,7 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
           if (g.out_lo) *reinterpret_cast<uint32_t*>(g.out_lo + o) = pl;
         }
       }
+    }
     }
   } else {
     // EPI_SPLIT / EPI_QKV / EPI_WAVENET: split planes, optionally the tail columns transposed (V^T for attention)
@@ -193,8 +196,9 @@ NS2_DEVINL bool epi_lds_supported(const GemmArgs& g, int row_base) {
   return true;
 }
 
-template <int EPI>
-NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][2], const GemmArgs& g, int z, int row_base, int col_base, int ocol_base,
+// NIT = accumulator column tiles of the wave, NI0 = first of the two column tiles this call stores
+template <int EPI, int NIT, int NI0>
+NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][NIT], const GemmArgs& g, int z, int row_base, int col_base, int ocol_base,
                                   int lane, unsigned char* wbuf) {
   const int l31 = lane & 31, hi = lane >> 5;
   const bool odd = lane & 1;
@@ -213,7 +217,7 @@ NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][2], const GemmArgs& g, int z,
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int lr = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float t = acc[half * 2 + mh][ni][r] + bc;
+            float t = acc[half * 2 + mh][NI0 + ni][r] + bc;
             if (g.act == 1) t = siluf(t);
             *reinterpret_cast<float*>(wbuf + lr * RS + (ni * 32 + l31) * 4) = t;
           }
@@ -251,7 +255,7 @@ NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][2], const GemmArgs& g, int z,
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)                   // result overwrites the x accumulators (no extra registers)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][0][r] = gelu_erf(acc[mi][1][r] + bg) * (acc[mi][0][r] + bx);
+      for (int r = 0; r < 16; ++r) acc[mi][NI0][r] = gelu_erf(acc[mi][NI0 + 1][r] + bg) * (acc[mi][NI0][r] + bx);
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
       bf16_t* outp = pl ? g.out_lo : g.out_hi;
@@ -260,7 +264,7 @@ NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][2], const GemmArgs& g, int z,
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int rp = 0; rp < 8; ++rp) {
-          float v0 = acc[mi][0][2 * rp], v1 = acc[mi][0][2 * rp + 1];
+          float v0 = acc[mi][NI0][2 * rp], v1 = acc[mi][NI0][2 * rp + 1];
           if (pl) { v0 -= bf2f(f2bf(v0)); v1 -= bf2f(f2bf(v1)); }
           const float send = odd ? v0 : v1;
           const float recv = __shfl_xor(send, 1, 64);
@@ -303,7 +307,7 @@ NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][2], const GemmArgs& g, int z,
             const int col = col_base + ni * 32 + l31;
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp) {
-              float v0 = acc[mi][ni][2 * rp] + bc[ni], v1 = acc[mi][ni][2 * rp + 1] + bc[ni];
+              float v0 = acc[mi][NI0 + ni][2 * rp] + bc[ni], v1 = acc[mi][NI0 + ni][2 * rp + 1] + bc[ni];
               if (col >= g.N) { v0 = 0.f; v1 = 0.f; }                 // zero the K padding of the next GEMM's operand
               if (pl) { v0 -= bf2f(f2bf(v0)); v1 -= bf2f(f2bf(v1)); }
               const float send = odd ? v0 : v1;
@@ -334,7 +338,7 @@ NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][2], const GemmArgs& g, int z,
               float t[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                t[e] = acc[mi][ni][4 * gq + e] + bc[ni];
+                t[e] = acc[mi][NI0 + ni][4 * gq + e] + bc[ni];
                 if (pl) t[e] -= bf2f(f2bf(t[e]));
               }
               *reinterpret_cast<uint2*>(wbuf + (ni * 32 + l31) * RS + (mi * 32 + 8 * gq + 4 * hi) * 2) =

@@ -37,7 +37,7 @@ def exact(p):        # value the kernels see for a split operand
     return ops.join(p).double()
 
 
-@pytest.fixture(params=[1, 2], ids=["gemm128", "gemm256"])
+@pytest.fixture(params=[1, 2, 3], ids=["gemm128", "gemm256", "gemm256p"])
 def gemm_kernel(request):
     """run every GEMM-family test on both kernels (gemm.hip 128x128 register-staged, gemm2.hip 256x256 LDS-DMA)."""
     from naturalspeech2_pytorch_amd import _lib
