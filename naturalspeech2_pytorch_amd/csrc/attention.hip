@@ -58,6 +58,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   const bf16_t* q_pl[2] = {a.q_hi, a.q_lo};
   const bf16_t* k_pl[2] = {a.k_hi, a.k_lo};
   const bf16_t* v_pl[2] = {a.vt_hi, a.vt_lo};
+  // operands with a lo plane are interleaved [hi32|lo32] per 32 columns (ns2_common.h); ld* are logical
+  const bool qil = a.q_lo != nullptr, kil = a.k_lo != nullptr, vil = a.vt_lo != nullptr, oil = a.o_lo != nullptr;
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = l31][d = 16c + 8hi .. +7]
   bf16x8 qf[NP][4];
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (q_ok) v = ld16g(q_pl[p] + ((long)b * a.Nq + qrow) * a.ldq + a.q_col0 + h * 64 + 16 * c + 8 * hi);
+      if (q_ok) v = ld16g(q_pl[p] + ((long)b * a.Nq + qrow) * pld(a.ldq, qil) + pcol(a.q_col0 + h * 64 + 16 * c + 8 * hi, qil));
       qf[p][c] = *reinterpret_cast<bf16x8*>(&v);
     }
 
@@ -85,10 +87,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
     for (int i = 0; i < 2; ++i) {
       const int key = key0 + srow[i];
       const bool kok = key < a.Nk;
-      const long koff = ((long)b * a.Nk + key) * a.ldk + a.k_col0 + h * 64 + sch[i] * 8;
+      const long koff = ((long)b * a.Nk + key) * pld(a.ldk, kil) + pcol(a.k_col0 + h * 64 + sch[i] * 8, kil);
       const int vkey = key0 + sch[i] * 8;
       const int nvalid = a.Nk - vkey;
-      const long voff = ((long)b * a.H * 64 + h * 64 + srow[i]) * a.vt_ld + vkey;
+      const long voff = ((long)b * a.H * 64 + h * 64 + srow[i]) * pld(a.vt_ld, vil) + pcol(vkey, vil);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         rg.k[p][i] = kok ? ld16g(k_pl[p] + koff) : make_uint4(0u, 0u, 0u, 0u);
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   if (q_ok) {
-    const long obase = ((long)b * a.Nq + qrow) * a.ldo + h * 64;
+    const long obase = ((long)b * a.Nq + qrow) * pld(a.ldo, oil);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -243,9 +245,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
         uint32_t h01, l01, h23, l23;
         split2(ot[dt][4 * gq + 0] * inv, ot[dt][4 * gq + 1] * inv, h01, l01);
         split2(ot[dt][4 * gq + 2] * inv, ot[dt][4 * gq + 3] * inv, h23, l23);
-        const long o = obase + 32 * dt + 8 * gq + 4 * hi;
+        const long o = obase + pcol(h * 64 + 32 * dt + 8 * gq + 4 * hi, oil);
         *reinterpret_cast<uint2*>(a.o_hi + o) = make_uint2(h01, h23);
-        if (a.o_lo) *reinterpret_cast<uint2*>(a.o_lo + o) = make_uint2(l01, l23);
+        if (oil) *reinterpret_cast<uint2*>(a.o_lo + o) = make_uint2(l01, l23);
       }
   }
 }
@@ -267,6 +269,9 @@ static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
 
 hipError_t launch_attention(const AttnArgs& a, int nsplit, hipStream_t s) {
   if (a.B <= 0 || a.H <= 0 || a.Nq <= 0 || a.Nk <= 0 || (a.vt_ld & 7)) return hipErrorInvalidValue;
+  if (!planes_ok(a.q_hi, a.q_lo) || !planes_ok(a.k_hi, a.k_lo) || !planes_ok(a.vt_hi, a.vt_lo) || !planes_ok(a.o_hi, a.o_lo))
+    return hipErrorInvalidValue;
+  if (a.vt_lo && (a.vt_ld & 31)) return hipErrorInvalidValue;   // interleaved rows come in 32-column blocks
   if (nsplit == 3) {
     if (!a.q_lo || !a.k_lo || !a.vt_lo) return hipErrorInvalidValue;
     return launch_attn_t<3>(a, s);

@@ -44,7 +44,7 @@ static inline int prec_ok(int p) { return p == 1 || p == 3; }
 extern "C" const char* ns2_last_error(void) { return g_err; }
 extern "C" int ns2_version(void) { return 101; }
 extern "C" int ns2_debug_force_gemm(int kernel) {
-  ARGCHK(kernel >= 0 && kernel <= 3, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 8-wave kernel, 3 = 256x256 pipelined kernel");
+  ARGCHK(kernel >= 0 && kernel <= 2, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
   force_gemm_kernel(kernel);
   return NS2_OK;
 }

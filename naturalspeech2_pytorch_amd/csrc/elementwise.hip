@@ -63,8 +63,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const NormArgs a) {
     split2(o[0], o[1], h01, l01);
     split2(o[2], o[3], h23, l23);
     if (a.out_hi) {
-      *reinterpret_cast<uint2*>(a.out_hi + row * a.ldo + c) = make_uint2(h01, h23);
-      if (a.out_lo) *reinterpret_cast<uint2*>(a.out_lo + row * a.ldo + c) = make_uint2(l01, l23);
+      const bool il = a.out_lo != nullptr;
+      const long po = row * pld(a.ldo, il) + pcol(c, il);
+      *reinterpret_cast<uint2*>(a.out_hi + po) = make_uint2(h01, h23);
+      if (il) *reinterpret_cast<uint2*>(a.out_lo + po) = make_uint2(l01, l23);
     }
     if (a.out_f && c < a.d) *reinterpret_cast<float4*>(a.out_f + row * a.ldo_f + c) = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const NormArgs a) {
 
 hipError_t launch_rmsnorm(const NormArgs& a, hipStream_t s) {
   if (a.M <= 0 || (a.d & 3) || (a.ldo & 3) || (a.ldx & 3) || a.ldo > 2048 || a.d > 2048) return hipErrorInvalidValue;
+  if (!planes_ok(a.out_hi, a.out_lo) || (a.out_lo && (a.ldo & 31))) return hipErrorInvalidValue;
   const dim3 grid((a.M + 3) / 4), block(256);
   const int width = a.ldo > a.d ? a.ldo : a.d;
   if (width <= 256) hipLaunchKernelGGL(rmsnorm_kernel<1>, grid, block, 0, s, a);
@@ -114,13 +117,16 @@ __global__ __launch_bounds__(256) void split_kernel(const float* x, int ldx, con
   uint32_t h01, l01, h23, l23;
   split2(o[0], o[1], h01, l01);
   split2(o[2], o[3], h23, l23);
-  *reinterpret_cast<uint2*>(out_hi + row * ldo + c) = make_uint2(h01, h23);
-  if (out_lo) *reinterpret_cast<uint2*>(out_lo + row * ldo + c) = make_uint2(l01, l23);
+  const bool il = out_lo != nullptr;
+  const long po = row * pld(ldo, il) + pcol(c, il);
+  *reinterpret_cast<uint2*>(out_hi + po) = make_uint2(h01, h23);
+  if (il) *reinterpret_cast<uint2*>(out_lo + po) = make_uint2(l01, l23);
 }
 
 hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, int add_rows_per_batch, int add_valid_rows,
                         bf16_t* out_hi, bf16_t* out_lo, int ldo, int M, int d, int seq_len, hipStream_t s) {
   if (M <= 0 || (ldo & 3) || ldo < d || (add && seq_len <= 0)) return hipErrorInvalidValue;
+  if (!planes_ok(out_hi, out_lo) || (out_lo && (ldo & 31))) return hipErrorInvalidValue;
   const long total = (long)M * (ldo >> 2);
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, add, ldadd,
                      add_rows_per_batch, add_valid_rows, out_hi, out_lo, ldo, (long)M, d, seq_len);
@@ -349,11 +355,14 @@ __global__ void join_kernel(const bf16_t* hi, const bf16_t* lo, int ld, float* o
   if (i >= M * d) return;
   const long r = i / d;
   const int c = (int)(i - r * d);
-  float v = bf2f(hi[r * ld + c]);
-  if (lo) v += bf2f(lo[r * ld + c]);
+  const bool il = lo != nullptr;
+  const long o = r * pld(ld, il) + pcol(c, il);
+  float v = bf2f(hi[o]);
+  if (il) v += bf2f(lo[o]);
   out[r * ldo + c] = v;
 }
 hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s) {
+  if (!planes_ok(hi, lo)) return hipErrorInvalidValue;
   const long n = M * d;
   hipLaunchKernelGGL(join_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hi, lo, ld, out, ldo, M, d);
   return hipGetLastError();
@@ -430,12 +439,14 @@ __global__ void pack_weight_kernel(const float* src, int C, int T, int Cp, const
   if (r >= 0 && c < C) v = src[((long)r * C + c) * T + tap];
   bf16_t h, l;
   split_bf16(v, h, l);
-  const long o = (long)rp * ldk + k_off + kk;
+  const bool il = dst_lo != nullptr;
+  const long o = (long)rp * pld(ldk, il) + pcol(k_off + kk, il);
   dst_hi[o] = h;
-  dst_lo[o] = l;
+  if (il) dst_lo[o] = l;
 }
 hipError_t launch_pack_weight(const float* src, int C, int T, int Cp, const int* row_map, int rows_p, bf16_t* dst_hi,
                               bf16_t* dst_lo, int ldk, int k_off, hipStream_t s) {
+  if (!planes_ok(dst_hi, dst_lo)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((T * Cp + 255) / 256, rows_p), dim3(256), 0, s, src, C, T, Cp, row_map,
                      rows_p, dst_hi, dst_lo, ldk, k_off);
   return hipGetLastError();

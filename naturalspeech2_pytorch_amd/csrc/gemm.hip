@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   const int tm = bid % ntm;
   const int z = bid / ntm;
 
-  const bf16_t* a_pl[2] = {g.a_hi + (long)z * g.a_zs, g.a_lo + (long)z * g.a_zs};
-  const bf16_t* w_pl[2] = {g.w_hi + (long)z * g.w_zs, g.w_lo + (long)z * g.w_zs};
+  // interleaved [hi32|lo32] rows when the operand has a lo plane (ns2_common.h); a_zs = logical column offset per z
+  const bool ail = g.a_lo != nullptr, wil = g.w_lo != nullptr;
+  const long azo = pcol((int)(z * g.a_zs), ail), wzo = ((long)z * g.w_zs) << (wil ? 1 : 0);
+  const bf16_t* a_pl[2] = {g.a_hi + azo, g.a_lo + azo};
+  const bf16_t* w_pl[2] = {g.w_hi + wzo, g.w_lo + wzo};
   const int dil = g.dil_z ? (g.dil << z) : g.dil;
 
   // ---- staging coordinates (2 chunks of 16 B per plane per thread)
@@ -85,8 +88,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     for (int i = 0; i < 2; ++i) {
       const long m = (long)tm * BM + srow[i];
       const bool ok = arow_ok[i] && ((unsigned)(nseq[i] - shift) < slim);   // source row inside the same utterance
-      const long aoff = (m - shift) * (long)g.lda + kcol + skc[i] * 8;
-      const long woff = ((long)tn * BN + srow[i]) * (long)g.ldw + (long)kt * BK + skc[i] * 8;
+      const long aoff = (m - shift) * pld(g.lda, ail) + pcol(kcol + skc[i] * 8, ail);
+      const long woff = ((long)tn * BN + srow[i]) * pld(g.ldw, wil) + pcol(kt * BK + skc[i] * 8, wil);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         st.a[p][i] = ok ? ld16(a_pl[p] + aoff) : zero16();

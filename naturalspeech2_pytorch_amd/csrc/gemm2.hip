@@ -9,9 +9,12 @@
 //   * operands go global -> LDS by **LDS-DMA** (`global_load_lds_dwordx4`, 1 KiB per wave-instruction), no VGPR staging,
 //     no ds_write pass; two 64 KiB stages (128 KiB of the 160 KiB LDS), the next K-tile's DMA is issued before the
 //     current tile's MFMAs and has a full iteration (>= 3k cycles at 2 waves/SIMD) to land;
+//   * every LDS row is 128 B = one cache line of the source: exact mode (BK=32) [hi(32) | lo(32)] of the interleaved
+//     split-plane layout (ns2_common.h), fast mode (BK=64) 64 hi values; one DMA wave-instruction moves 8 full lines
+//     (the planar layout this replaced moved 16 half lines and measured 2.5x the DMA time);
 //   * LDS image is lane-linear per DMA instruction, so bank conflicts are removed by an XOR swizzle applied to the
 //     per-lane SOURCE address and to the fragment read address (guide rule 21): 16-B chunk c of row r is stored at
-//     chunk c ^ ((r>>2)&3) (64-B rows, exact mode, BK=32) or c ^ ((r>>1)&7) (128-B rows, fast mode, BK=64);
+//     chunk c ^ ((r>>1)&7);
 //   * causal-conv zero fill (rows before the utterance start) and M-edge rows are lanes whose source pointer is
 //     redirected to a 16-B zero page -- the DMA needs no predication.
 #include <cstdlib>
@@ -31,16 +34,16 @@ NS2_DEVINL void glds16(const void* gsrc, unsigned char* ldst) {
 
 template <int NSPLIT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const bf16_t* __restrict__ zero_page) {
-  constexpr int NP = (NSPLIT == 3) ? 2 : 1;          // planes per operand
-  constexpr int BK = (NSPLIT == 3) ? 32 : 64;        // K-tile depth (elements)
-  constexpr int RB = BK * 2;                         // LDS row bytes (64 / 128)
-  constexpr int CPR = RB / 16;                       // 16-B chunks per row (4 / 8)
-  constexpr int RPI = 64 / CPR;                      // tile rows moved by one DMA wave-instruction (16 / 8)
-  constexpr int PLANE = G2_BM * RB;                  // 16 KiB / 32 KiB
-  constexpr int STAGE = 2 * NP * PLANE;              // 64 KiB
+  constexpr int NP = (NSPLIT == 3) ? 2 : 1;          // planes per operand (both inside one 128-B LDS row in exact mode)
+  constexpr int BK = (NSPLIT == 3) ? 32 : 64;        // K-tile depth (logical elements)
+  constexpr int RB = 128;                            // LDS row bytes: [hi32|lo32] (exact) or hi64 (fast)
+  constexpr int CPR = RB / 16;                       // 16-B chunks per row (8)
+  constexpr int RPI = 64 / CPR;                      // tile rows moved by one DMA wave-instruction (8)
+  constexpr int REGION = G2_BM * RB;                 // one operand of one K tile: 32 KiB
+  constexpr int STAGE = 2 * REGION;                  // 64 KiB
   constexpr int KCH = BK / 16;                       // 16-deep MFMA K chunks per tile (2 / 4)
-  constexpr int IPP = G2_BM / RPI;                   // DMA instructions per plane (16 / 32)
-  static_assert(2 * NP * IPP == 64, "8 waves x 8 DMA instructions per K-tile");
+  constexpr int IPO = G2_BM / RPI;                   // DMA instructions per operand (32)
+  static_assert(2 * IPO == 64, "8 waves x 8 DMA instructions per K-tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -61,37 +64,41 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
   const int z = bid / ntm;
   const int dil = g.dil_z ? (g.dil << z) : g.dil;
 
-  // ---- DMA roles: instruction j = wave*8 + i ; waves 0-3 stream A, waves 4-7 stream W
+  // operand layouts (ns2_common.h): exact mode requires interleaved operands (checked by launch_gemm); the fast kernel
+  // reads the hi plane of either layout
+  const bool ail = g.a_lo != nullptr, wil = g.w_lo != nullptr;
+  const long a_rs = pld(g.lda, ail), w_rs = pld(g.ldw, wil);     // physical row strides
+
+  // ---- DMA roles: instruction j = (wave&3)*8 + i of the operand; waves 0-3 stream A, waves 4-7 stream W
   const bool a_wave = wave < 4;
   const int lrow = lane / CPR, pchunk = lane % CPR;
   const bf16_t* src[8];        // per-instruction source pointer at K offset 0 (A: unshifted row)
   int nseq[8];                 // A only: position inside the utterance (for the causal zero fill); -1 = row >= M
   int ldst[8];                 // LDS byte offset inside a stage (wave-uniform)
-  bool lchunk_hi[8];           // this lane fetches one of the upper 32 columns of a 64-deep tile
+  bool lchunk_hi[8];           // fast mode: this lane fetches one of the upper 32 columns of a 64-deep tile
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int j = (wave & 3) * 8 + i;                // instruction index inside this operand: [0, NP*IPP)
-    const int plane = j / IPP, rg = j % IPP;
+    const int rg = (wave & 3) * 8 + i;               // row group inside the operand: [0, IPO)
     const int row = rg * RPI + lrow;                 // tile row
-    const int swz = (NSPLIT == 3) ? ((row >> 2) & 3) : ((row >> 1) & 7);
-    const int lchunk = pchunk ^ swz;                 // logical 16-B chunk this lane fetches
-    ldst[i] = (a_wave ? 0 : NP * PLANE) + plane * PLANE + rg * 1024;
+    const int lchunk = pchunk ^ ((row >> 1) & 7);    // logical 16-B chunk this lane fetches
+    ldst[i] = (a_wave ? 0 : REGION) + rg * 1024;
     lchunk_hi[i] = lchunk >= 4;
     if (a_wave) {
       const long m = (long)tm * G2_BM + row;
-      const bf16_t* base = (plane == 0 ? g.a_hi : g.a_lo) + (long)z * g.a_zs;
-      src[i] = base + m * g.lda + lchunk * 8;
+      // exact: chunk c of the line = 8 elements at c*8 (hi chunks 0-3, lo chunks 4-7); fast: logical column c*8
+      const int coff = (NSPLIT == 3) ? lchunk * 8 : pcol(lchunk * 8, ail);
+      src[i] = g.a_hi + pcol((int)(z * g.a_zs), ail) + m * a_rs + coff;
       nseq[i] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -1;
     } else {
-      const bf16_t* base = (plane == 0 ? g.w_hi : g.w_lo) + (long)z * g.w_zs;
-      src[i] = base + ((long)tn * G2_BN + row) * g.ldw + lchunk * 8;
+      const int coff = (NSPLIT == 3) ? lchunk * 8 : pcol(lchunk * 8, wil);
+      src[i] = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN + row) * w_rs + coff;
       nseq[i] = 0;
     }
   }
 
   // K tiling in BK units: every tap spans tpt tiles; with BK = 64 an odd 32-multiple tap ends in a half tile whose
   // upper 32 columns are zero-filled (A and W lanes of those chunks read the zero page)
-  const int tap_k = g.kt_per_tap * 32;                        // elements per tap
+  const int tap_k = g.kt_per_tap * 32;                        // logical elements per tap
   const int tpt = (tap_k + BK - 1) / BK;
   const bool half_tail = (NSPLIT != 3) && (g.kt_per_tap & 1);
   const int ntaps = g.nkt / g.kt_per_tap;
@@ -107,24 +114,18 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
       const int pl = g.pad_left < 0 ? g.conv_taps - 1 : g.pad_left;      // causal: all padding on the left (NS2:583-595)
       const int shift = (tap < g.conv_taps) ? (pl - tap) * dil : 0;
       const unsigned slim = g.seq_len > 0 ? (unsigned)g.seq_len : 0x7fffffffu;
-      const long off = (long)it * BK - (long)shift * g.lda;
+      const long off = pcol(it * BK, ail) - (long)shift * a_rs;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bool ok = ((unsigned)(nseq[i] - shift) < slim) && !(half && lchunk_hi[i]);   // nseq = -1 marks rows >= M
         const bf16_t* p = ok ? (src[i] + off) : zero_page;
-#ifdef G2_CONTIG
-        p = g.a_hi + (long)tm * 256 * g.lda + (((kt * 64 + (wave & 3) * 8 + i) * 512) & 0x3ffff) + lane * 8;
-#endif
         glds16(p, sbase + ldst[i]);
       }
     } else {
-      const long off = (long)tap * tap_k + (long)it * BK;
+      const long off = pcol(tap * tap_k + it * BK, wil);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bf16_t* p = (half && lchunk_hi[i]) ? zero_page : (src[i] + off);
-#ifdef G2_CONTIG
-        p = g.w_hi + (long)tn * 256 * g.ldw + (((kt * 64 + (wave & 3) * 8 + i) * 512) & 0x3ffff) + lane * 8;
-#endif
         glds16(p, sbase + ldst[i]);
       }
     }
@@ -144,10 +145,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
   const int ncols_needed = (EPI == EPI_GEGLU || EPI == EPI_F32 || EPI == EPI_QKV) ? g.N : max(g.N, g.out_ncols);
   const bool wave_active = col_base < ncols_needed;
 
-  // fragment read addressing: row = wave base + 32*i + l31 ; physical chunk = (2*kc + hi) ^ swz(row), swz depends on l31 only
-  const int fswz = (NSPLIT == 3) ? ((l31 >> 2) & 3) : ((l31 >> 1) & 7);
+  // fragment read addressing: row = wave base + 32*i + l31 ; physical chunk = (4*plane + 2*kc + hi) ^ swz(row); the swizzle
+  // depends on l31 only, and a 16-lane ds_read_b128 group covers 16 distinct (row&1, (row>>1)&7) pairs = all 64 banks
+  const int fswz = (l31 >> 1) & 7;
   const int a_row_off = (wm * 128 + l31) * RB;
-  const int w_row_off = NP * PLANE + (wn * 64 + l31) * RB;
+  const int w_row_off = REGION + (wn * 64 + l31) * RB;
 
   auto run_k = [&](const int kt0, const int kt1) {
     issue_tile(kt0, kt0 & 1);
@@ -162,29 +164,17 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
       if (wave_active) {
 #pragma unroll
       for (int kc = 0; kc < KCH; ++kc) {
-        const int coff = ((2 * kc + hi) ^ fswz) * 16;
         bf16x8 af[NP][4], wf[NP][2];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
+          const int coff = ((4 * p + 2 * kc + hi) ^ fswz) * 16;
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            af[p][i] = *reinterpret_cast<const bf16x8*>(sb + p * PLANE + a_row_off + i * 32 * RB + coff);
+            af[p][i] = *reinterpret_cast<const bf16x8*>(sb + a_row_off + i * 32 * RB + coff);
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            wf[p][i] = *reinterpret_cast<const bf16x8*>(sb + p * PLANE + w_row_off + i * 32 * RB + coff);
+            wf[p][i] = *reinterpret_cast<const bf16x8*>(sb + w_row_off + i * 32 * RB + coff);
         }
-#ifdef NS2_ABLATE
-        if (g.dbg & 2) {                              // keep the fragment reads alive, skip the MFMAs
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[p][i]));
-#pragma unroll
-            for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(wf[p][i]));
-          }
-          continue;
-        }
-#endif
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -214,15 +204,6 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
   }
   if (!wave_active) return;
   // all waves are past the K loop's last barrier: the LDS ring is free, every wave takes a private 18 KiB region
-#ifdef NS2_ABLATE
-  if (g.dbg & 4) {                                   // no epilogue: keep the accumulators alive, store nothing
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
-    return;
-  }
-#endif
   if constexpr (EPI == EPI_F32) {
     if (epi_lds_supported<EPI>(g, row_base)) {
       gemm_epilogue_lds<EPI, 2, 0>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane, smem + wave * EPI_LDS_WAVE_BYTES);
@@ -240,8 +221,6 @@ static const bf16_t* zero_page() {
   }
   return p;
 }
-
-const bf16_t* gemm_zero_page() { return zero_page(); }
 
 template <int NSPLIT, int EPI>
 static hipError_t launch2_one(const GemmArgs& g, hipStream_t s) {
@@ -274,7 +253,6 @@ static hipError_t launch2_epi(const GemmArgs& g, hipStream_t s) {
 }
 
 hipError_t launch_gemm1(const GemmArgs& g, int nsplit, hipStream_t s);   // gemm.hip (128x128 register-staged kernel)
-hipError_t launch_gemm3(const GemmArgs& g, int nsplit, hipStream_t s);   // gemm3.hip (256x256, 4 waves, software-pipelined)
 
 static int g_forced_kernel = -1;     // -1: read NS2_GEMM once; 0 auto; 1 / 2 force a kernel (tests exercise both)
 void force_gemm_kernel(int k) { g_forced_kernel = k; }
@@ -291,10 +269,13 @@ static int forced_kernel() {
 hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.nkt <= 0 || g.kt_per_tap <= 0 || (g.nkt % g.kt_per_tap)) return hipErrorInvalidValue;
   if (nsplit == 3 && (!g.a_lo || !g.w_lo)) return hipErrorInvalidValue;
+  // a lo plane means the interleaved layout: lo = hi + 32 (ns2_common.h)
+  if (!planes_ok(g.a_hi, g.a_lo) || !planes_ok(g.w_hi, g.w_lo) || !planes_ok(g.out_hi, g.out_lo) ||
+      !planes_ok(g.vt_hi, g.vt_lo))
+    return hipErrorInvalidValue;
   const int f = forced_kernel();
-  const bool big = (f >= 2) || (f != 1 && g.N > 128);
+  const bool big = (f == 2) || (f != 1 && g.N > 128);
   if (!big) return launch_gemm1(g, nsplit, s);
-  if (f == 3) return launch_gemm3(g, nsplit, s);
   return nsplit == 3 ? launch2_epi<3>(g, s) : launch2_epi<1>(g, s);
 }
 

@@ -46,6 +46,7 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
                               int lane) {
   const int l31 = lane & 31, hi = lane >> 5;
   const bool odd = lane & 1;
+  const bool il = g.out_lo != nullptr;               // interleaved [hi32|lo32] output rows (ns2_common.h)
 
   if constexpr (EPI == EPI_F32) {
     // out = acc + bias (+ residual)      (to_out / FF-out / final_conv / to_pred)
@@ -95,9 +96,9 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
         if (row < g.M && col < g.out_ncols) {
           uint32_t ph, pl;
           split2(c_lo, c_hi, ph, pl);
-          const long o = (long)row * g.ldo_s + col;
+          const long o = (long)row * pld(g.ldo_s, il) + pcol(col, il);
           *reinterpret_cast<uint32_t*>(g.out_hi + o) = ph;
-          if (g.out_lo) *reinterpret_cast<uint32_t*>(g.out_lo + o) = pl;
+          if (il) *reinterpret_cast<uint32_t*>(g.out_lo + o) = pl;
         }
       }
     }
@@ -105,8 +106,9 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
   } else {
     // EPI_SPLIT / EPI_QKV / EPI_WAVENET: split planes, optionally the tail columns transposed (V^T for attention)
     const float* bias = g.bias ? g.bias + (long)z * g.bias_zs : nullptr;
-    bf16_t* out_hi = g.out_hi + (long)z * g.out_zs;
-    bf16_t* out_lo = g.out_lo ? g.out_lo + (long)z * g.out_zs : nullptr;
+    const long zo = pcol((int)(z * g.out_zs), il);    // out_zs = logical column offset of slice z
+    bf16_t* out_hi = g.out_hi + zo;
+    bf16_t* out_lo = il ? g.out_lo + zo : nullptr;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -132,9 +134,9 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
               if (c0 + 1 >= g.N) c_hi = 0.f;
               uint32_t ph, pl;
               split2(c_lo, c_hi, ph, pl);
-              const long o = (long)row * g.ldo_s + c0;
+              const long o = (long)row * pld(g.ldo_s, il) + pcol(c0, il);
               *reinterpret_cast<uint32_t*>(out_hi + o) = ph;
-              if (out_lo) *reinterpret_cast<uint32_t*>(out_lo + o) = pl;
+              if (il) *reinterpret_cast<uint32_t*>(out_lo + o) = pl;
             }
           }
         } else {
@@ -151,19 +153,20 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
               split2(acc[mi][ni][4 * gq + 2] + bc, acc[mi][ni][4 * gq + 3] + bc, h23, l23);
               const bf16_t h[4] = {(bf16_t)(h01 & 0xffffu), (bf16_t)(h01 >> 16), (bf16_t)(h23 & 0xffffu), (bf16_t)(h23 >> 16)};
               const bf16_t l[4] = {(bf16_t)(l01 & 0xffffu), (bf16_t)(l01 >> 16), (bf16_t)(l23 & 0xffffu), (bf16_t)(l23 >> 16)};
-              const long o = ((long)b * g.vt_rows + feat) * g.vt_ld + n0;
-              if ((g.seq_len & 3) == 0) {            // 4 tokens stay inside one utterance and are 8-B aligned
+              const bool vil = g.vt_lo != nullptr;
+              const long o = ((long)b * g.vt_rows + feat) * pld(g.vt_ld, vil) + pcol(n0, vil);
+              if ((g.seq_len & 3) == 0) {            // 4 tokens stay inside one utterance (and one 32-block), 8-B aligned
                 *reinterpret_cast<uint2*>(g.vt_hi + o) = make_uint2(h01, h23);
-                if (g.vt_lo) *reinterpret_cast<uint2*>(g.vt_lo + o) = make_uint2(l01, l23);
+                if (vil) *reinterpret_cast<uint2*>(g.vt_lo + o) = make_uint2(l01, l23);
               } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   const int row = row0 + e;
                   if (row < g.M) {
                     const int bb = row / g.seq_len, nn = row - bb * g.seq_len;
-                    const long oo = ((long)bb * g.vt_rows + feat) * g.vt_ld + nn;
+                    const long oo = ((long)bb * g.vt_rows + feat) * pld(g.vt_ld, vil) + pcol(nn, vil);
                     g.vt_hi[oo] = h[e];
-                    if (g.vt_lo) g.vt_lo[oo] = l[e];
+                    if (vil) g.vt_lo[oo] = l[e];
                   }
                 }
               }
@@ -183,18 +186,11 @@ constexpr int EPI_LDS_WAVE_BYTES = 18432;     // 128 rows x (128 B + 16 B pad)
 
 NS2_DEVINL uint32_t pk2(float a, float b) { return cvt2(a, b); }
 
-// returns false when the tile needs the generic path (ragged utterances for the transposed V store)
-// Measured (MI355X, M = 32768): the fp32 + residual epilogue gains 1.45x-1.65x on the whole launch (FF-out 218 -> 150 us),
-// the bf16 split-plane epilogues are neutral (their cost is the store burst itself, not store issue), and the GEGLU
-// variant would spill.  Only EPI_F32 therefore takes the LDS path.
+// Measured (MI355X, M = 32768): the fp32 + residual epilogue gains 1.45x-1.65x on the whole launch (FF-out 218 -> 150 us);
+// LDS-staged variants of the bf16 split-plane epilogues were built too and were neutral (their cost is the store burst
+// itself, not store issue) -- only EPI_F32 has an LDS path.
 template <int EPI>
-NS2_DEVINL bool epi_lds_supported(const GemmArgs& g, int row_base) {
-  if constexpr (EPI != EPI_F32) return false;
-  if constexpr (EPI == EPI_QKV) {
-    if ((g.split_col & 63) || (g.seq_len & 127) || row_base + 128 > g.M) return false;
-  }
-  return true;
-}
+NS2_DEVINL bool epi_lds_supported(const GemmArgs&, int) { return EPI == EPI_F32; }
 
 // NIT = accumulator column tiles of the wave, NI0 = first of the two column tiles this call stores
 template <int EPI, int NIT, int NI0>
@@ -244,114 +240,6 @@ NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][NIT], const GemmArgs& g, int 
                 g.out_f[(long)row * g.ldo_f + col + e] = t;
               }
           }
-        }
-      }
-    }
-  } else if constexpr (EPI == EPI_GEGLU) {
-    // out tile 128 rows x 32 cols per plane, LDS rows of 80 B
-    constexpr int RS = 80;
-    const int cx = col_base + l31, cg = col_base + 32 + l31;
-    const float bx = g.bias[cx], bg = g.bias[cg];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)                   // result overwrites the x accumulators (no extra registers)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][NI0][r] = gelu_erf(acc[mi][NI0 + 1][r] + bg) * (acc[mi][NI0][r] + bx);
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-      bf16_t* outp = pl ? g.out_lo : g.out_hi;
-      if (!outp) break;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int rp = 0; rp < 8; ++rp) {
-          float v0 = acc[mi][NI0][2 * rp], v1 = acc[mi][NI0][2 * rp + 1];
-          if (pl) { v0 -= bf2f(f2bf(v0)); v1 -= bf2f(f2bf(v1)); }
-          const float send = odd ? v0 : v1;
-          const float recv = __shfl_xor(send, 1, 64);
-          const float c_lo = odd ? recv : v0, c_hi = odd ? v1 : recv;
-          const int r = 2 * rp + (odd ? 1 : 0);
-          const int lr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          *reinterpret_cast<uint32_t*>(wbuf + lr * RS + (l31 & ~1) * 2) = pk2(c_lo, c_hi);
-        }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int lr = it * 16 + (lane >> 2), ch = lane & 3;
-        const int row = row_base + lr, col = ocol_base + ch * 8;
-        const uint4 d = *reinterpret_cast<const uint4*>(wbuf + lr * RS + ch * 16);
-        if (row < g.M && col < g.out_ncols) *reinterpret_cast<uint4*>(outp + (long)row * g.ldo_s + col) = d;
-      }
-    }
-  } else {
-    // EPI_SPLIT / EPI_WAVENET / EPI_QKV
-    const float* bias = g.bias ? g.bias + (long)z * g.bias_zs : nullptr;
-    const bool transposed = (EPI == EPI_QKV) && (col_base >= g.split_col);       // wave-uniform (split_col % 64 == 0)
-    float bc[2] = {0.f, 0.f};
-    if constexpr (EPI != EPI_WAVENET) {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int col = col_base + ni * 32 + l31;
-        bc[ni] = (bias && col < g.N) ? bias[col] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-      if (!transposed) {
-        constexpr int RS = 144;                      // 128 rows x 64 cols bf16
-        bf16_t* outp = (pl ? g.out_lo : g.out_hi);
-        if (!outp) break;
-        outp += (long)z * g.out_zs;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            const int col = col_base + ni * 32 + l31;
-#pragma unroll
-            for (int rp = 0; rp < 8; ++rp) {
-              float v0 = acc[mi][NI0 + ni][2 * rp] + bc[ni], v1 = acc[mi][NI0 + ni][2 * rp + 1] + bc[ni];
-              if (col >= g.N) { v0 = 0.f; v1 = 0.f; }                 // zero the K padding of the next GEMM's operand
-              if (pl) { v0 -= bf2f(f2bf(v0)); v1 -= bf2f(f2bf(v1)); }
-              const float send = odd ? v0 : v1;
-              const float recv = __shfl_xor(send, 1, 64);
-              const float c_lo = odd ? recv : v0, c_hi = odd ? v1 : recv;
-              const int r = 2 * rp + (odd ? 1 : 0);
-              const int lr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-              *reinterpret_cast<uint32_t*>(wbuf + lr * RS + (ni * 32 + (l31 & ~1)) * 2) = pk2(c_lo, c_hi);
-            }
-          }
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-          const int lr = it * 8 + (lane >> 3), ch = lane & 7;
-          const int row = row_base + lr, col = col_base + ch * 8;
-          const uint4 d = *reinterpret_cast<const uint4*>(wbuf + lr * RS + ch * 16);
-          if (row < g.M && col < g.out_ncols) *reinterpret_cast<uint4*>(outp + (long)row * g.ldo_s + col) = d;
-        }
-      } else {
-        constexpr int RS = 272;                      // 64 features x 128 tokens bf16
-        bf16_t* outp = pl ? g.vt_lo : g.vt_hi;
-        if (!outp) break;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-              float t[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                t[e] = acc[mi][NI0 + ni][4 * gq + e] + bc[ni];
-                if (pl) t[e] -= bf2f(f2bf(t[e]));
-              }
-              *reinterpret_cast<uint2*>(wbuf + (ni * 32 + l31) * RS + (mi * 32 + 8 * gq + 4 * hi) * 2) =
-                  make_uint2(pk2(t[0], t[1]), pk2(t[2], t[3]));
-            }
-        const int b = row_base / g.seq_len, n0 = row_base - b * g.seq_len;       // 128 tokens inside one utterance
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-          const int lf = it * 4 + (lane >> 4), ch = lane & 15;
-          const int feat = col_base - g.split_col + lf;
-          const uint4 d = *reinterpret_cast<const uint4*>(wbuf + lf * RS + ch * 16);
-          if (col_base + lf < g.N)
-            *reinterpret_cast<uint4*>(outp + ((long)b * g.vt_rows + feat) * g.vt_ld + n0 + ch * 8) = d;
         }
       }
     }

@@ -96,18 +96,21 @@ static int dev_alloc(std::vector<void*>* owned, void** p, size_t bytes) {
   return NS2_OK;
 }
 
-// allocate a packed weight of rows_p x ldk (zero-filled)
+// Layout of the weights being packed (ns2_common.h): interleaved [hi32|lo32] rows with a lo plane (exact models and
+// ns2_weight_pack), dense hi-only rows for precision-1 ("fast") models.  Set by the two packing entry points.
+static bool g_pack_il = true;
+
+// allocate a packed weight of rows_p x ldk logical columns (zero-filled)
 static int alloc_packed(std::vector<void*>* owned, PackedW* w, int N, int ldk, int kt_per_tap) {
   w->N = N;
   w->rows_p = rup(N, 256);
   w->ldk = ldk;
   w->nkt = ldk / 32;
   w->kt_per_tap = kt_per_tap;
-  size_t bytes = (size_t)w->rows_p * ldk * sizeof(bf16_t);
+  size_t bytes = (size_t)w->rows_p * ldk * sizeof(bf16_t) * (g_pack_il ? 2 : 1);
   NSCHK(dev_alloc(owned, (void**)&w->hi, bytes));
-  NSCHK(dev_alloc(owned, (void**)&w->lo, bytes));
+  w->lo = g_pack_il ? w->hi + 32 : nullptr;
   HIPCHK(hipMemset(w->hi, 0, bytes));
-  HIPCHK(hipMemset(w->lo, 0, bytes));
   return NS2_OK;
 }
 
@@ -118,8 +121,9 @@ static int pack_into(PackedW* w, const float* src, int C, int T, int Cp, const s
   int* d_map = nullptr;
   HIPCHK(hipMalloc((void**)&d_map, row_map.size() * sizeof(int)));
   HIPCHK(hipMemcpy(d_map, row_map.data(), row_map.size() * sizeof(int), hipMemcpyHostToDevice));
-  hipError_t e = launch_pack_weight(src, C, T, Cp, d_map, (int)row_map.size(), w->hi + (size_t)row0 * w->ldk,
-                                    w->lo + (size_t)row0 * w->ldk, w->ldk, k_off, s);
+  const size_t roff = (size_t)row0 * w->ldk * (w->lo ? 2 : 1);
+  hipError_t e = launch_pack_weight(src, C, T, Cp, d_map, (int)row_map.size(), w->hi + roff, w->lo ? w->lo + roff : nullptr,
+                                    w->ldk, k_off, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(d_map);
   HIPCHK(e);
@@ -170,6 +174,7 @@ static int pack_geglu_bias(std::vector<void*>* owned, float** out, const float* 
 int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, PackedW* out,
                        std::vector<void*>* owned, hipStream_t s) {
   const int Cp = rup(cols, 32);
+  g_pack_il = true;                                  // op-level weights serve both precisions
   if (geglu) return pack_geglu(owned, out, w, rows / 2, cols, s);
   const int T = taps + (extra ? 1 : 0);
   NSCHK(alloc_packed(owned, out, rows, T * Cp, Cp / 32));
@@ -186,7 +191,9 @@ static GemmArgs base_args(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_
   g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk;
   g.M = M; g.N = w.N; g.nkt = w.nkt; g.kt_per_tap = w.nkt; g.conv_taps = 0; g.dil = 1; g.mid_kt = -1;
   g.nz = 1; g.pad_left = -1; g.act = 0;
+#ifdef NS2_ABLATE
   { const char* e = getenv("NS2_DBG"); g.dbg = e ? atoi(e) : 0; }
+#endif
   return g;
 }
 static void set_conv(GemmArgs& g, const PackedW& w, int taps, int dil, int seq_len) {
@@ -301,6 +308,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
   const int dim = m->dim, a = m->a, f = m->f, L = m->L, S = m->S;
   const bool cond = m->cfg.condition_on_prompt;
   char key[256];
+  g_pack_il = (m->cfg.precision == 3);               // exact: interleaved hi/lo rows; fast: dense hi-only weights
 
   // ---- time conditioning (NS2:839-843)
   { GETP(fw, "to_time_cond.0.weights"); m->freqs = fw->p; }
@@ -338,18 +346,17 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
     PackedW& W = m->w_wn[st];
     // batched: L matrices of [rows_p, 4*dp] back to back
     W.N = dim; W.rows_p = rup(dim, 256); W.ldk = 4 * m->dp; W.nkt = W.ldk / 32; W.kt_per_tap = m->dp / 32;
-    const size_t per = (size_t)W.rows_p * W.ldk;
+    const size_t per = (size_t)W.rows_p * W.ldk * (g_pack_il ? 2 : 1);     // physical elements per matrix
     NSCHK(dev_alloc(&m->owned, (void**)&W.hi, per * L * sizeof(bf16_t)));
-    NSCHK(dev_alloc(&m->owned, (void**)&W.lo, per * L * sizeof(bf16_t)));
+    W.lo = g_pack_il ? W.hi + 32 : nullptr;
     HIPCHK(hipMemset(W.hi, 0, per * L * sizeof(bf16_t)));
-    HIPCHK(hipMemset(W.lo, 0, per * L * sizeof(bf16_t)));
     NSCHK(dev_alloc(&m->owned, (void**)&m->b_wn_conv[st], (size_t)L * dim * sizeof(float)));
     NSCHK(dev_alloc(&m->owned, (void**)&m->b_wn_res[st], (size_t)L * dim * sizeof(float)));
     for (int i = 0; i < L; ++i) {
       snprintf(key, sizeof key, "wavenet.stacks.%d.blocks.%d", st, i);
       GETP(cw, std::string(key) + ".conv.weight"); GETP(cb, std::string(key) + ".conv.bias");
       GETP(rw, std::string(key) + ".res_conv.weight"); GETP(rb, std::string(key) + ".res_conv.bias");
-      PackedW view = W; view.hi = W.hi + per * i; view.lo = W.lo + per * i;
+      PackedW view = W; view.hi = W.hi + per * i; view.lo = W.lo ? W.lo + per * i : nullptr;
       NSCHK(pack_into(&view, cw->p, dim, 3, m->dp, identity_map(dim, W.rows_p), 0, 0, s));
       NSCHK(pack_into(&view, rw->p, dim, 1, m->dp, identity_map(dim, W.rows_p), 0, 3 * m->dp, s));
       HIPCHK(hipMemcpyAsync(m->b_wn_conv[st] + (size_t)i * dim, cb->p, dim * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -451,7 +458,13 @@ struct Carver {
   }
 };
 struct Planes { bf16_t* hi; bf16_t* lo; };
-static Planes take_planes(Carver& c, int64_t n) { Planes p; p.hi = c.take<bf16_t>(n); p.lo = c.take<bf16_t>(n); return p; }
+// n logical elements; il: interleaved [hi32|lo32] rows in one buffer (exact), else a dense hi plane only (fast)
+static Planes take_planes(Carver& c, int64_t n, bool il) {
+  Planes p;
+  p.hi = c.take<bf16_t>(il ? 2 * n : n);
+  p.lo = il ? p.hi + 32 : nullptr;
+  return p;
+}
 
 struct Work {
   float *tfeat, *t, *condall, *xres, *tmp_f;
@@ -467,35 +480,37 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
   const int64_t M = (int64_t)B * N;
   const int64_t Mq = (int64_t)B * std::max(N, m->cfg.condition_on_prompt ? m->Lm : 0);   // prepare_cond reuses qk / o / ffh
   const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, L = m->L;
+  const bool il = m->cfg.precision == 3;
+  const int kpad = il ? 32 : 8;                       // key-axis padding of the transposed V planes
   w->tfeat = c.take<float>((int64_t)B * (dim + 1));
   w->t = c.take<float>((int64_t)B * m->Tc);
   w->condall = c.take<float>((int64_t)B * m->Jtot);
   w->xres = c.take<float>(M * dim);
-  w->xs = take_planes(c, M * dp);
-  w->h0 = take_planes(c, M * dp);
-  w->wA = take_planes(c, M * L * dp);
-  w->wB = take_planes(c, M * L * dp);
-  w->ssum = take_planes(c, M * dp);
-  w->xn = take_planes(c, M * dp);
-  w->qk = take_planes(c, Mq * 2 * a);
-  w->Nkp = rup(N, 8);
-  w->vt = take_planes(c, (int64_t)B * a * w->Nkp);
-  w->o = take_planes(c, Mq * a);
-  w->ffh = take_planes(c, Mq * fp);
-  w->ffc = take_planes(c, M * fp);
+  w->xs = take_planes(c, M * dp, il);
+  w->h0 = take_planes(c, M * dp, il);
+  w->wA = take_planes(c, M * L * dp, il);
+  w->wB = take_planes(c, M * L * dp, il);
+  w->ssum = take_planes(c, M * dp, il);
+  w->xn = take_planes(c, M * dp, il);
+  w->qk = take_planes(c, Mq * 2 * a, il);
+  w->Nkp = rup(N, kpad);
+  w->vt = take_planes(c, (int64_t)B * a * w->Nkp, il);
+  w->o = take_planes(c, Mq * a, il);
+  w->ffh = take_planes(c, Mq * fp, il);
+  w->ffc = take_planes(c, M * fp, il);
   if (m->cfg.condition_on_prompt && n_prompt > 0) {
     const int Lm = m->Lm;
-    w->Nctx = Lm + n_prompt; w->Nctxp = rup(w->Nctx, 8);
+    w->Nctx = Lm + n_prompt; w->Nctxp = rup(w->Nctx, kpad);
     w->pmean = c.take<float>((int64_t)B * m->cfg.dim_prompt);
     w->ctxf = c.take<float>((int64_t)B * w->Nctx * dim);
     w->latf = c.take<float>((int64_t)B * Lm * dim);
     w->projf = c.take<float>((int64_t)B * n_prompt * dim);
     w->condT = c.take<float>((int64_t)B * n_cond * m->cfg.dim_prompt);
-    w->ctxp = take_planes(c, (int64_t)B * std::max(w->Nctx, std::max(n_prompt, n_cond)) * std::max(dp, m->dpp));
-    w->latp = take_planes(c, (int64_t)B * Lm * std::max(dp, std::max(fp, a)));
-    w->cpl = take_planes(c, (int64_t)B * Lm * dp);
-    w->rkv = take_planes(c, (int64_t)B * w->Nctx * a);
-    w->rvt = take_planes(c, (int64_t)B * a * w->Nctxp);
+    w->ctxp = take_planes(c, (int64_t)B * std::max(w->Nctx, std::max(n_prompt, n_cond)) * std::max(dp, m->dpp), il);
+    w->latp = take_planes(c, (int64_t)B * Lm * std::max(dp, std::max(fp, a)), il);
+    w->cpl = take_planes(c, (int64_t)B * Lm * dp, il);
+    w->rkv = take_planes(c, (int64_t)B * w->Nctx * a, il);
+    w->rvt = take_planes(c, (int64_t)B * a * w->Nctxp, il);
   }
   return rup64(c.off, 256);
 }
@@ -511,11 +526,12 @@ static int64_t carve_cond(const ns2_model* m, CondState* cs, void* base, int64_t
   c.take<int64_t>(4);                              // header: {magic, B, N, n_cond_valid}
   cs->prompt_cond = c.take<float>((int64_t)B * m->dt);
   cs->condadd = c.take<float>((int64_t)B * n_cond * m->dim);
-  cs->Lmp = rup(m->Lm, 8);
+  const bool il = m->cfg.precision == 3;
+  cs->Lmp = rup(m->Lm, il ? 32 : 8);
   cs->ck.resize(m->cfg.depth); cs->cvt.resize(m->cfg.depth);
   for (int l = 0; l < m->cfg.depth; ++l) {
-    cs->ck[l] = take_planes(c, (int64_t)B * m->Lm * m->a);
-    cs->cvt[l] = take_planes(c, (int64_t)B * m->a * cs->Lmp);
+    cs->ck[l] = take_planes(c, (int64_t)B * m->Lm * m->a, il);
+    cs->cvt[l] = take_planes(c, (int64_t)B * m->a * cs->Lmp, il);
   }
   cs->n_cond_valid = std::min(n_cond, N);
   return rup64(c.off, 256);

@@ -4,6 +4,15 @@
 // hi = bf16_rne(x) and lo = bf16_rne(x - float(hi)).  A product of two split operands is evaluated as
 // hi*hi + hi*lo + lo*hi on the bf16 MFMA pipe with fp32 accumulation (3 MFMAs, relative error ~2^-16 per
 // product => fp32-class results); the "fast" mode uses the hi plane only (1 MFMA).
+//
+// Memory layout of a split-plane matrix [rows, ld] (ld = LOGICAL columns, a multiple of 32):
+//   * with a lo plane ("interleaved"): ONE bf16 buffer [rows, 2*ld]; every 32 logical columns occupy one 128-byte
+//     line [hi(32) | lo(32)], i.e. element (r, c) has hi at r*2*ld + pcol(c) and lo 32 elements further
+//     (lo pointer == hi pointer + 32, checked by the launchers).  A K tile of 32 columns of both planes is therefore
+//     ONE full cache line per row: the GEMM's LDS-DMA touches 8 full lines per 1 KiB wave-instruction instead of
+//     16 half lines of two planar buffers -- the vector-memory front end retires requests per line, and the planar
+//     layout measured 2.5x the DMA time (GEMM measurements);
+//   * hi only (lo == nullptr, "fast" precision): dense [rows, ld].
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,6 +38,10 @@ NS2_DEVINL void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
   hi = f2bf(x);
   lo = f2bf(x - bf2f(hi));
 }
+
+// physical column / row stride of a split-plane matrix (see the layout note above); il = "has a lo plane"
+NS2_DEVINL int pcol(int c, bool il) { return il ? (((c & ~31) << 1) | (c & 31)) : c; }
+NS2_DEVINL long pld(int ld, bool il) { return il ? 2L * ld : (long)ld; }
 
 NS2_DEVINL uint32_t pack2(bf16_t a, bf16_t b) { return (uint32_t)a | ((uint32_t)b << 16); }
 

@@ -8,6 +8,9 @@ typedef uint16_t bf16_t;
 
 namespace ns2 {
 
+// split-plane operands: a lo plane implies the interleaved [hi32|lo32] row layout, i.e. lo == hi + 32 (ns2_common.h)
+inline bool planes_ok(const bf16_t* hi, const bf16_t* lo) { return lo == nullptr || lo == hi + 32; }
+
 enum GemmEpilogue : int {
   EPI_F32 = 0,      // out_f = acc + bias (+ resid)
   EPI_SPLIT = 1,    // split planes = acc + bias
@@ -17,7 +20,8 @@ enum GemmEpilogue : int {
 };
 
 struct GemmArgs {
-  // A operand: activations, bf16 split planes [M, lda]
+  // A operand: activations, bf16 split planes [M, lda]; every ld / column count in this struct is LOGICAL (the
+  // physical row stride is 2*ld when the lo plane exists, see ns2_common.h); a_zs / out_zs are logical column offsets
   const bf16_t* a_hi; const bf16_t* a_lo; int lda;
   // W operand: packed weights, bf16 split planes [ceil(N/128)*128, ldw], K contiguous
   const bf16_t* w_hi; const bf16_t* w_lo; int ldw;

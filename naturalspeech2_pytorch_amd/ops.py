@@ -3,15 +3,12 @@
 PyTorch is plumbing here: device memory and the current HIP stream.  Every function launches hand-written HIP
 kernels through ctypes; nothing in this module computes with torch ops.
 """
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 
 from . import _lib
 from ._lib import check
-
-Planes = Tuple[torch.Tensor, Optional[torch.Tensor]]     # (hi, lo) bf16 tensors of identical shape
-
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -30,9 +27,44 @@ def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-def empty_planes(rows: int, cols: int, device, lo: bool = True) -> Planes:
-    hi = torch.empty(rows, cols, dtype=torch.bfloat16, device=device)
-    return hi, (torch.empty_like(hi) if lo else None)
+class Planes:
+    """A split-plane matrix [rows, ld] held by the library's layout (csrc/ns2_common.h).
+
+    With a lo plane ("interleaved", what precision 3 needs) `buf` is ONE bf16 tensor [rows, 2*ld]: every 32 logical columns
+    occupy a 128-byte line [hi(32) | lo(32)], so the lo pointer is the hi pointer + 32 elements.  Without (hi only,
+    precision 1) `buf` is the dense [rows, ld] hi plane.  `ld` is always the LOGICAL column count (a multiple of 32).
+    """
+    __slots__ = ("buf", "rows", "ld", "has_lo")
+
+    def __init__(self, buf: torch.Tensor, rows: int, ld: int, has_lo: bool):
+        self.buf, self.rows, self.ld, self.has_lo = buf, rows, ld, has_lo
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    @property
+    def hi(self) -> int:
+        return self.buf.data_ptr()
+
+    @property
+    def lo(self) -> Optional[int]:
+        return self.buf.data_ptr() + 64 if self.has_lo else None
+
+    def hi_plane(self) -> torch.Tensor:
+        """the logical hi plane as a dense [rows, ld] bf16 tensor (copy)"""
+        if not self.has_lo:
+            return self.buf.reshape(self.rows, self.ld).clone()
+        return self.buf.reshape(self.rows, self.ld // 32, 2, 32)[:, :, 0, :].reshape(self.rows, self.ld).contiguous()
+
+    def hi_only(self) -> "Planes":
+        return Planes(self.hi_plane(), self.rows, self.ld, False)
+
+
+def empty_planes(rows: int, cols: int, device, lo: bool = True, zero: bool = False) -> Planes:
+    assert cols % 32 == 0 or not lo, "interleaved split planes come in 32-column blocks"
+    alloc = torch.zeros if zero else torch.empty
+    return Planes(alloc(rows, cols * (2 if lo else 1), dtype=torch.bfloat16, device=device), rows, cols, lo)
 
 
 def split(x: torch.Tensor, ldo: Optional[int] = None, lo: bool = True) -> Planes:
@@ -41,16 +73,15 @@ def split(x: torch.Tensor, ldo: Optional[int] = None, lo: bool = True) -> Planes
     M, d = x.shape
     ldo = ldo or round_up(d, 32)
     out = empty_planes(M, ldo, x.device, lo)
-    check(_lib.load().ns2_split_f32(x.data_ptr(), d, M, d, out[0].data_ptr(), _p(out[1]), ldo, _stream()), "ns2_split_f32")
+    check(_lib.load().ns2_split_f32(x.data_ptr(), d, M, d, out.hi, out.lo, ldo, _stream()), "ns2_split_f32")
     return out
 
 
 def join(p: Planes, d: Optional[int] = None) -> torch.Tensor:
-    hi, lo = p
-    M, ld = hi.shape
+    M, ld = p.rows, p.ld
     d = d or ld
-    out = torch.empty(M, d, dtype=torch.float32, device=hi.device)
-    check(_lib.load().ns2_join_f32(hi.data_ptr(), _p(lo), ld, out.data_ptr(), d, M, d, _stream()), "ns2_join_f32")
+    out = torch.empty(M, d, dtype=torch.float32, device=p.device)
+    check(_lib.load().ns2_join_f32(p.hi, p.lo, ld, out.data_ptr(), d, M, d, _stream()), "ns2_join_f32")
     return out
 
 
@@ -82,22 +113,20 @@ class PackedWeight:
 
 def linear_f32(w: PackedWeight, a: Planes, M: Optional[int] = None, bias=None, resid=None, conv_taps=0, dilation=1,
                seq_len=0, precision=3, pad_left=-1, act=0) -> torch.Tensor:
-    hi, lo = a
-    M = M or hi.shape[0]
-    out = torch.empty(M, w.rows, dtype=torch.float32, device=hi.device)
-    check(_lib.load().ns2_linear_f32(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, conv_taps, dilation, seq_len, _p(bias),
+    M = M or a.rows
+    out = torch.empty(M, w.rows, dtype=torch.float32, device=a.device)
+    check(_lib.load().ns2_linear_f32(w.handle, a.hi, a.lo, a.ld, M, conv_taps, dilation, seq_len, _p(bias),
                                      _p(resid), w.rows, out.data_ptr(), w.rows, pad_left, act, precision, _stream()), "ns2_linear_f32")
     return out
 
 
 def linear_split(w: PackedWeight, a: Planes, bias=None, conv_taps=0, dilation=1, seq_len=0, precision=3, ldo=None, pad_left=-1,
                  act=0) -> Planes:
-    hi, lo = a
-    M = hi.shape[0]
+    M = a.rows
     ldo = ldo or round_up(w.rows, 32)
-    out = empty_planes(M, ldo, hi.device)
-    check(_lib.load().ns2_linear_split(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, conv_taps, dilation, seq_len, _p(bias),
-                                       out[0].data_ptr(), out[1].data_ptr(), ldo, pad_left, act, precision, _stream()), "ns2_linear_split")
+    out = empty_planes(M, ldo, a.device)
+    check(_lib.load().ns2_linear_split(w.handle, a.hi, a.lo, a.ld, M, conv_taps, dilation, seq_len, _p(bias),
+                                       out.hi, out.lo, ldo, pad_left, act, precision, _stream()), "ns2_linear_split")
     return out
 
 
@@ -109,54 +138,50 @@ def geglu_pack_bias(bias: torch.Tensor, f: int) -> torch.Tensor:
 
 
 def linear_geglu(w: PackedWeight, a: Planes, packed_bias: torch.Tensor, precision=3) -> Planes:
-    hi, lo = a
-    M = hi.shape[0]
+    M = a.rows
     f = w.rows // 2
     ldo = round_up(f, 32)
-    out = empty_planes(M, ldo, hi.device)
-    check(_lib.load().ns2_linear_geglu(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, packed_bias.data_ptr(), out[0].data_ptr(),
-                                       out[1].data_ptr(), ldo, precision, _stream()), "ns2_linear_geglu")
+    out = empty_planes(M, ldo, a.device)
+    check(_lib.load().ns2_linear_geglu(w.handle, a.hi, a.lo, a.ld, M, packed_bias.data_ptr(), out.hi,
+                                       out.lo, ldo, precision, _stream()), "ns2_linear_geglu")
     return out
 
 
 def linear_qkv(w: PackedWeight, a: Planes, seq_len: int, split_col: int, precision=3):
-    """returns (row-major planes [M, split_col], transposed planes [B, rows - split_col, vt_ld])."""
-    hi, lo = a
-    M = hi.shape[0]
+    """returns (row-major planes [M, split_col], transposed planes [B * (rows - split_col), vt_ld])."""
+    M = a.rows
     B = M // seq_len
-    vt_ld = round_up(seq_len, 8)
-    out = empty_planes(M, split_col, hi.device)
+    vt_ld = round_up(seq_len, 32)
+    out = empty_planes(M, split_col, a.device)
     vt_rows = w.rows - split_col
-    vt_hi = torch.zeros(B, vt_rows, vt_ld, dtype=torch.bfloat16, device=hi.device)
-    vt_lo = torch.zeros_like(vt_hi)
-    check(_lib.load().ns2_linear_qkv(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, seq_len, split_col, out[0].data_ptr(),
-                                     out[1].data_ptr(), split_col, vt_hi.data_ptr(), vt_lo.data_ptr(), vt_ld, precision, _stream()),
+    vt = empty_planes(B * vt_rows, vt_ld, a.device, zero=True)
+    check(_lib.load().ns2_linear_qkv(w.handle, a.hi, a.lo, a.ld, M, seq_len, split_col, out.hi,
+                                     out.lo, split_col, vt.hi, vt.lo, vt_ld, precision, _stream()),
           "ns2_linear_qkv")
-    return out, (vt_hi, vt_lo)
+    return out, vt
 
 
 def wavenet_block(w: PackedWeight, a: Planes, seq_len: int, dilation: int, conv_bias, res_bias, film: torch.Tensor,
                   precision=3) -> Planes:
-    hi, lo = a
-    M = hi.shape[0]
+    M = a.rows
     ldo = round_up(w.rows, 32)
-    out = empty_planes(M, ldo, hi.device)
-    check(_lib.load().ns2_wavenet_block(w.handle, hi.data_ptr(), _p(lo), hi.shape[1], M, seq_len, dilation, conv_bias.data_ptr(),
-                                        res_bias.data_ptr(), _f32(film).data_ptr(), film.shape[1], out[0].data_ptr(),
-                                        out[1].data_ptr(), ldo, precision, _stream()), "ns2_wavenet_block")
+    out = empty_planes(M, ldo, a.device)
+    check(_lib.load().ns2_wavenet_block(w.handle, a.hi, a.lo, a.ld, M, seq_len, dilation, conv_bias.data_ptr(),
+                                        res_bias.data_ptr(), _f32(film).data_ptr(), film.shape[1], out.hi,
+                                        out.lo, ldo, precision, _stream()), "ns2_wavenet_block")
     return out
 
 
 def attention(q: Planes, k: Planes, vt: Planes, B: int, H: int, Nq: int, Nk: int, q_col0=0, k_col0=0, scale=0.125,
               precision=3, key_mask: Optional[torch.Tensor] = None) -> Planes:
-    """key_mask: optional bool/uint8 [B, Nk], True = attend (key-padding mask of ATT:92-94)."""
-    out = empty_planes(B * Nq, H * 64, q[0].device)
+    """vt: transposed value planes [B * H*64, vt_ld]; key_mask: optional bool/uint8 [B, Nk], True = attend (ATT:92-94)."""
+    out = empty_planes(B * Nq, H * 64, q.device)
     km = None
     if key_mask is not None:
         km = key_mask.to(torch.uint8).contiguous()
         assert km.shape == (B, Nk)
-    check(_lib.load().ns2_attention(q[0].data_ptr(), _p(q[1]), q[0].shape[1], q_col0, k[0].data_ptr(), _p(k[1]), k[0].shape[1],
-                                    k_col0, vt[0].data_ptr(), _p(vt[1]), vt[0].shape[-1], out[0].data_ptr(), out[1].data_ptr(),
+    check(_lib.load().ns2_attention(q.hi, q.lo, q.ld, q_col0, k.hi, k.lo, k.ld,
+                                    k_col0, vt.hi, vt.lo, vt.ld, out.hi, out.lo,
                                     H * 64, B, H, Nq, Nk, scale, _p(km), precision, _stream()), "ns2_attention")
     return out
 
@@ -168,7 +193,7 @@ def rmsnorm(x: torch.Tensor, seq_len: int = 0, gamma=None, cond=None, want_f32=F
     out = empty_planes(M, ldo, x.device)
     of = torch.empty(M, d, dtype=torch.float32, device=x.device) if want_f32 else None
     check(_lib.load().ns2_rmsnorm(x.data_ptr(), d, M, d, seq_len, _p(gamma), _p(cond), cond.shape[1] if cond is not None else 0,
-                                  out[0].data_ptr(), out[1].data_ptr(), ldo, _p(of), d, _stream()), "ns2_rmsnorm")
+                                  out.hi, out.lo, ldo, _p(of), d, _stream()), "ns2_rmsnorm")
     return (out, of) if want_f32 else out
 
 

@@ -37,7 +37,7 @@ def exact(p):        # value the kernels see for a split operand
     return ops.join(p).double()
 
 
-@pytest.fixture(params=[1, 2, 3], ids=["gemm128", "gemm256", "gemm256p"])
+@pytest.fixture(params=[1, 2], ids=["gemm128", "gemm256"])
 def gemm_kernel(request):
     """run every GEMM-family test on both kernels (gemm.hip 128x128 register-staged, gemm2.hip 256x256 LDS-DMA)."""
     from naturalspeech2_pytorch_amd import _lib
@@ -49,13 +49,15 @@ def gemm_kernel(request):
 def test_split_join_roundtrip():
     x = rnd(300, 100, seed=1, scale=3.0)
     p = ops.split(x)
-    assert p[0].shape == (300, 128)
+    assert (p.rows, p.ld) == (300, 128) and p.buf.shape == (300, 256)      # interleaved [hi32|lo32] rows
     y = ops.join(p, 100)
     assert rel(y, x) < 1e-5
     assert ops.join(p)[:, 100:].abs().sum().item() == 0.0       # zero padding
-    hi_only = ops.join((p[0], None), 100)
+    hi_only = ops.join(p.hi_only(), 100)
     assert rel(hi_only, x) < 5e-3
-    assert torch.equal(p[0][:, :100], x.to(torch.bfloat16))      # hi plane == RNE bf16
+    assert torch.equal(p.hi_plane()[:, :100], x.to(torch.bfloat16))      # hi plane == RNE bf16
+    d = ops.split(x, lo=False)                                   # dense hi-only layout (precision 1 models)
+    assert d.buf.shape == (300, 128) and torch.equal(d.buf[:, :100], x.to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("prec", [3, 1])
@@ -139,7 +141,7 @@ def test_geglu(M, K, f, prec, gemm_kernel):
     out = ops.linear_geglu(pw, a, pb, precision=prec)
     h = exact(a)[:, :K] @ w.double().t() + b.double()
     ref = F.gelu(h[:, f:]) * h[:, :f]                              # NS2:1006-1007: first half x, second half gate
-    assert out[0].shape[1] == ops.round_up(f, 32)
+    assert out.ld == ops.round_up(f, 32)
     e = rel(ops.join(out, f), ref)
     assert e < TOL[prec] + 1e-5, f"rel err {e}"
     assert ops.join(out)[:, f:].abs().sum().item() == 0.0
@@ -156,7 +158,7 @@ def test_qkv(B, N, K, prec, gemm_kernel):
     qk, vt = ops.linear_qkv(pw, a, seq_len=N, split_col=2 * a_dim, precision=prec)
     ref = exact(a)[:, :K] @ w.double().t()
     assert rel(ops.join(qk), ref[:, : 2 * a_dim]) < TOL[prec] + 1e-5
-    v = (vt[0].float() + vt[1].float())[:, :, :N]                 # [B, a, N]
+    v = ops.join(vt).reshape(B, a_dim, vt.ld)[:, :, :N]           # [B, a, N]
     vref = ref[:, 2 * a_dim:].reshape(B, N, a_dim).transpose(1, 2)
     assert rel(v, vref) < TOL[prec] + 1e-5
 
@@ -196,17 +198,16 @@ def test_attention(B, H, Nq, Nk, prec):
     k = rnd(B * Nk, a_dim, seed=21)
     v = rnd(B * Nk, a_dim, seed=22)
     qp, kp = ops.split(q), ops.split(k)
-    vt_ld = ops.round_up(Nk, 8)
+    vt_ld = ops.round_up(Nk, 32)
     # V^T planes [B, a, vt_ld]; poison the padding to prove the kernel masks it
     vt_f = torch.full((B, a_dim, vt_ld), float("nan"), device=DEV)
     vt_f[:, :, :Nk] = v.reshape(B, Nk, a_dim).transpose(1, 2)
-    vp = ops.split(vt_f.reshape(B * a_dim, vt_ld), ldo=vt_ld)
-    vt = (vp[0].reshape(B, a_dim, vt_ld), vp[1].reshape(B, a_dim, vt_ld))
+    vt = ops.split(vt_f.reshape(B * a_dim, vt_ld), ldo=vt_ld)
     o = ops.attention(qp, kp, vt, B, H, Nq, Nk, precision=prec)
 
     def heads(p, n):
         return exact(p).reshape(B, n, H, 64).permute(0, 2, 1, 3)
-    ve = (vt[0].double() + vt[1].double())[:, :, :Nk].reshape(B, H, 64, Nk).transpose(2, 3)
+    ve = exact(vt).reshape(B, a_dim, vt_ld)[:, :, :Nk].reshape(B, H, 64, Nk).transpose(2, 3)
     ref = attn_ref(heads(qp, Nq), heads(kp, Nk), ve, 0.125).permute(0, 2, 1, 3).reshape(B * Nq, a_dim)
     got = ops.join(o)
     assert torch.isfinite(got).all()
@@ -223,16 +224,15 @@ def test_attention_key_padding_mask():
     mask[0, :5] = False
     mask = mask.to(DEV)
     qp, kp = ops.split(q), ops.split(k)
-    vt_ld = ops.round_up(Nk, 8)
+    vt_ld = ops.round_up(Nk, 32)
     vt_f = torch.zeros(B, a_dim, vt_ld, device=DEV)
     vt_f[:, :, :Nk] = v.reshape(B, Nk, a_dim).transpose(1, 2)
-    vp = ops.split(vt_f.reshape(B * a_dim, vt_ld), ldo=vt_ld)
-    vt = (vp[0].reshape(B, a_dim, vt_ld), vp[1].reshape(B, a_dim, vt_ld))
+    vt = ops.split(vt_f.reshape(B * a_dim, vt_ld), ldo=vt_ld)
     o = ops.attention(qp, kp, vt, B, H, Nq, Nk, key_mask=mask)
 
     def heads(p, n):
         return exact(p).reshape(B, n, H, 64).permute(0, 2, 1, 3)
-    ve = (vt[0].double() + vt[1].double())[:, :, :Nk].reshape(B, H, 64, Nk).transpose(2, 3)
+    ve = exact(vt).reshape(B, a_dim, vt_ld)[:, :, :Nk].reshape(B, H, 64, Nk).transpose(2, 3)
     sim = torch.einsum("bhid,bhjd->bhij", heads(qp, Nq), heads(kp, Nk)) * 0.125
     sim = sim.masked_fill(~mask[:, None, None, :], -torch.finfo(torch.float32).max)
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), ve).permute(0, 2, 1, 3).reshape(B * Nq, a_dim)
@@ -279,7 +279,7 @@ def test_attention_spiked_softmax():
     k[200] = q[5] * 6.0                                           # huge score for (q5, k200) in the 4th key tile
     qp, kp = ops.split(q), ops.split(k)
     vp = ops.split(v.reshape(Nk, 64).t().contiguous(), ldo=Nk)
-    o = ops.attention(qp, kp, (vp[0].reshape(1, 64, Nk), vp[1].reshape(1, 64, Nk)), B, H, Nq, Nk)
+    o = ops.attention(qp, kp, vp, B, H, Nq, Nk)
     ve = exact(vp).t().reshape(1, 1, Nk, 64)
     ref = attn_ref(exact(qp).reshape(1, 1, Nq, 64), exact(kp).reshape(1, 1, Nk, 64), ve, 0.125).reshape(Nq, 64)
     assert rel(ops.join(o), ref) < 3e-5

@@ -6,5 +6,5 @@ cd "$(dirname "$0")/../naturalspeech2_pytorch_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -I../../include -mllvm -pragma-unroll-threshold=200000"
 mkdir -p obj_g3
 hipcc $FLAGS "$@" -c gemm2.hip -o obj_g3/gemm2_$TAG.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../libns2hip_g2_$TAG.so obj/gemm.o obj_g3/gemm2_$TAG.o obj/gemm3.o obj/attention.o obj/elementwise.o obj/rvq.o obj/model_exec.o obj/capi.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libns2hip_g2_$TAG.so obj/gemm.o obj_g3/gemm2_$TAG.o obj/attention.o obj/elementwise.o obj/rvq.o obj/model_exec.o obj/capi.o
 echo built $TAG
