@@ -79,8 +79,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   }
 
   auto load_stage = [&](Stage<NSPLIT>& st, int kt) {
-    const int tap = kt / g.kt_per_tap;
-    const int kcol = (kt - tap * g.kt_per_tap) * BK;
+    // same K order as gemm2.hip: shifted conv taps tap-minor (L2 reuse of the shifted A rows), then the unshifted taps
+    int tap, kin;
+    if (kt < g.conv_taps * g.kt_per_tap) { kin = kt / g.conv_taps; tap = kt - kin * g.conv_taps; }
+    else { tap = kt / g.kt_per_tap; kin = kt - tap * g.kt_per_tap; }
+    const int kcol = kin * BK;
     const int pl = g.pad_left < 0 ? g.conv_taps - 1 : g.pad_left;        // causal: all padding on the left (NS2:583-595)
     const int shift = (tap < g.conv_taps) ? (pl - tap) * dil : 0;
     const unsigned slim = g.seq_len > 0 ? (unsigned)g.seq_len : 0x7fffffffu;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
       const long m = (long)tm * BM + srow[i];
       const bool ok = arow_ok[i] && ((unsigned)(nseq[i] - shift) < slim);   // source row inside the same utterance
       const long aoff = (m - shift) * pld(g.lda, ail) + pcol(kcol + skc[i] * 8, ail);
-      const long woff = ((long)tn * BN + srow[i]) * pld(g.ldw, wil) + pcol(kt * BK + skc[i] * 8, wil);
+      const long woff = ((long)tn * BN + srow[i]) * pld(g.ldw, wil) + pcol((tap * g.kt_per_tap + kin) * BK + skc[i] * 8, wil);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         st.a[p][i] = ok ? ld16(a_pl[p] + aoff) : zero16();

@@ -104,11 +104,16 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
   const int ntaps = g.nkt / g.kt_per_tap;
   const int ntiles = ntaps * tpt;
   const int mid_tile = (g.mid_kt > 0) ? (g.mid_kt / g.kt_per_tap) * tpt : 0;
+  const int nconv = g.conv_taps * tpt;                        // tiles of the row-shifted taps (come first)
 
   auto issue_tile = [&](int kt, int stage) {
     unsigned char* sbase = smem + stage * STAGE;
-    const int tap = kt / tpt;
-    const int it = kt - tap * tpt;
+    // K order: the shifted conv taps are visited tap-minor (k chunk 0: taps 0..T-1, k chunk 1: ...).  Consecutive taps
+    // read the same A lines shifted by `dil` rows, so every re-read comes straight after the first touch and hits L2;
+    // tap-major order streamed the whole A row range (1.4 MB per block, ~7.5 MB per XCD) between two visits.
+    int tap, it;
+    if (kt < nconv) { it = kt / g.conv_taps; tap = kt - it * g.conv_taps; }
+    else { tap = kt / tpt; it = kt - tap * tpt; }
     const bool half = half_tail && (it == tpt - 1);
     if (a_wave) {
       const int pl = g.pad_left < 0 ? g.conv_taps - 1 : g.pad_left;      // causal: all padding on the left (NS2:583-595)

@@ -1,0 +1,33 @@
+"""Phase timeline of the 256x256 GEMM (FF conv shape) from a -DG2_TRACE build:  tools/ablate_gemm2.sh trace -DG2_TRACE ;
+NS2_LIB=.../libns2hip_g2_trace.so python tools/trace_gemm2.py [--prec 3]"""
+import argparse, ctypes, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from naturalspeech2_pytorch_amd import _lib, ops
+
+ap = argparse.ArgumentParser(); ap.add_argument("--prec", type=int, default=3); args = ap.parse_args()
+lib = _lib.load(); _lib.check(lib.ns2_debug_force_gemm(2))
+raw = ctypes.CDLL(os.environ["NS2_LIB"])
+g = torch.Generator().manual_seed(0)
+M, f, N = 32768, 1365, 1024
+x = ops.split((torch.randn(M, f, generator=g)).cuda(), ldo=ops.round_up(f, 32))
+w = ops.PackedWeight((torch.randn(f, f, 3, generator=g) * 0.02).cuda()); b = torch.randn(f, generator=g).cuda()
+for _ in range(5):
+    ops.linear_split(w, x, bias=b, conv_taps=3, dilation=1, seq_len=N, precision=args.prec)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * (8 * 64 * 10))()
+assert raw.ns2_debug_read_trace(buf) == 0
+t = np.array(buf, dtype=np.int64).reshape(8, 64, 10)[:, :, :8]
+# group A (waves 0-3): reads issued, DMA issued, reads landed, barrier X, MFMAs issued, DMA landed, barrier Y
+# group B (waves 4-7): barrier X, reads issued, DMA issued, reads landed, barrier Y, MFMAs issued, DMA landed
+names = ["A:rd/B:X", "A:dma/B:rd", "A:lgkm/B:dma", "A:X/B:lgkm", "A:mfma/B:Y", "A:vm/B:mfma", "A:Y/B:vm"]
+d = np.diff(t, axis=2).astype(np.float64)                     # [wave][tile][7 phases]
+tile = (t[:, 1:, 0] - t[:, :-1, 0]).astype(np.float64)
+print("cycles per tile (wave mean):", np.round(tile.mean(axis=1), 0))
+print("phase means per wave (cycles):   " + "  ".join(f"{n:>12s}" for n in names))
+for wv in range(8):
+    print(f"  wave {wv}:                        " + "  ".join(f"{v:12.0f}" for v in d[wv, 4:60].mean(axis=0)))
+print("  p90 over tiles (wave 0 / wave 4):")
+for wv in (0, 4):
+    print(f"  wave {wv}:                        " + "  ".join(f"{v:12.0f}" for v in np.percentile(d[wv, 4:60], 90, axis=0)))
