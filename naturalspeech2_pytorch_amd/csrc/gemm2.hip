@@ -32,6 +32,13 @@ NS2_DEVINL void glds16(const void* gsrc, unsigned char* ldst) {
   __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)ldst, 16, 0, 0);
 }
 
+#ifdef G2_TRACE      // per-wave phase timeline of one block (tools/trace_gemm2.py): [wave][tile][stamp] shader-clock values
+__device__ unsigned long long g2_trace[8 * 64 * 10];
+#define STAMP(n) do { if (tr_on) ts[n] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(n)
+#endif
+
 template <int NSPLIT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const bf16_t* __restrict__ zero_page) {
   constexpr int NP = (NSPLIT == 3) ? 2 : 1;          // planes per operand (both inside one 128-B LDS row in exact mode)
@@ -161,10 +168,16 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                  // tile kt0 landed for every wave
     for (int kt = kt0; kt < kt1; ++kt) {
+#ifdef G2_TRACE
+      unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const bool tr_on = (EPI == EPI_SPLIT) && blockIdx.x == 8 * 37 && kt >= 16 && kt < 80;
+#endif
+      STAMP(0);
       // Anti-phase DMA issue: an LDS-DMA instruction blocks its wave for ~60-180 clocks at issue.  The A-streaming
       // waves 0-3 (one per SIMD) issue theirs now, while their SIMD partners 4-7 already run MFMAs; waves 4-7 issue
       // the W half after their first K step, when waves 0-3 are in their MFMA phase (measured +5 % on the FF conv).
       if (kt + 1 < kt1 && a_wave) issue_tile(kt + 1, (kt + 1) & 1);
+      STAMP(1);
       const unsigned char* sb = smem + (kt & 1) * STAGE;
       if (wave_active) {
 #pragma unroll
@@ -180,6 +193,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
           for (int i = 0; i < 2; ++i)
             wf[p][i] = *reinterpret_cast<const bf16x8*>(sb + w_row_off + i * 32 * RB + coff);
         }
+#ifdef G2_TRACE
+        if (kc < 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (kc == 0) STAMP(2); else STAMP(5); }
+#endif
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -190,13 +206,27 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
             }
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], wf[0][ni], acc[mi][ni], 0, 0, 0);
           }
+#ifdef G2_TRACE
+        if (kc == 0) STAMP(3); else if (kc == 1) STAMP(6);
+#endif
         if (kc == 0 && kt + 1 < kt1 && !a_wave) issue_tile(kt + 1, (kt + 1) & 1);
+#ifdef G2_TRACE
+        if (kc == 0) STAMP(4);
+#endif
       }
       } else if (kt + 1 < kt1 && !a_wave) {
         issue_tile(kt + 1, (kt + 1) & 1);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile has landed
+      STAMP(7);
       __syncthreads();                                // ... everybody's has, and this stage is free to overwrite
+#ifdef G2_TRACE
+      STAMP(8);
+      if (tr_on && lane == 0) {
+#pragma unroll
+        for (int n = 0; n < 9; ++n) g2_trace[(wave * 64 + (kt - 16)) * 10 + n] = ts[n];
+      }
+#endif
     }
   };
 
@@ -217,6 +247,12 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
   }
   gemm_epilogue<EPI, 4, 2>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane);
 }
+
+#ifdef G2_TRACE
+extern "C" int ns2_debug_read_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2_trace), sizeof(unsigned long long) * 8 * 64 * 10);
+}
+#endif
 
 static const bf16_t* zero_page() {
   static bf16_t* p = nullptr;

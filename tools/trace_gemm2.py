@@ -18,16 +18,13 @@ for _ in range(5):
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (8 * 64 * 10))()
 assert raw.ns2_debug_read_trace(buf) == 0
-t = np.array(buf, dtype=np.int64).reshape(8, 64, 10)[:, :, :8]
-# group A (waves 0-3): reads issued, DMA issued, reads landed, barrier X, MFMAs issued, DMA landed, barrier Y
-# group B (waves 4-7): barrier X, reads issued, DMA issued, reads landed, barrier Y, MFMAs issued, DMA landed
-names = ["A:rd/B:X", "A:dma/B:rd", "A:lgkm/B:dma", "A:X/B:lgkm", "A:mfma/B:Y", "A:vm/B:mfma", "A:Y/B:vm"]
-d = np.diff(t, axis=2).astype(np.float64)                     # [wave][tile][7 phases]
+t = np.array(buf, dtype=np.int64).reshape(8, 64, 10)[:, :, :9]
+# stamps: tile start | early DMA issued (waves 0-3) | K-step-0 fragments landed | K-step-0 MFMAs issued | late DMA issued
+# (waves 4-7) | K-step-1 fragments landed | K-step-1 MFMAs issued [fast mode: steps 2,3 follow] | own DMA landed | barrier passed
+names = ["dma_early", "rd0", "mfma0", "dma_late", "rd1", "mfma1", "vmcnt", "barrier"]
+d = np.diff(t, axis=2).astype(np.float64)                     # [wave][tile][8 phases]
 tile = (t[:, 1:, 0] - t[:, :-1, 0]).astype(np.float64)
-print("cycles per tile (wave mean):", np.round(tile.mean(axis=1), 0))
-print("phase means per wave (cycles):   " + "  ".join(f"{n:>12s}" for n in names))
+print("cycles per tile (wave mean):", np.round(tile[:, 4:60].mean(axis=1), 0))
+print("phase means per wave (cycles):   " + "  ".join(f"{n:>9s}" for n in names))
 for wv in range(8):
-    print(f"  wave {wv}:                        " + "  ".join(f"{v:12.0f}" for v in d[wv, 4:60].mean(axis=0)))
-print("  p90 over tiles (wave 0 / wave 4):")
-for wv in (0, 4):
-    print(f"  wave {wv}:                        " + "  ".join(f"{v:12.0f}" for v in np.percentile(d[wv, 4:60], 90, axis=0)))
+    print(f"  wave {wv}:                        " + "  ".join(f"{v:9.0f}" for v in d[wv, 4:60].mean(axis=0)))
