@@ -9,7 +9,7 @@ path's single RCCL all-gather of the generated latents runs once after the K ste
     python bench.py [--gpus N --steps K --warmup W] [--precision exact|fast] [--graph]
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events recorded by the executor on the
-launch stream around every launch of the dominant kernel symbol (gemm_kernel<NSPLIT, EPI_SPLIT>: the 12 FF causal
+launch stream around every launch of the dominant kernel symbol (gemm2_kernel<NSPLIT, EPI_SPLIT>: the 12 FF causal
 convs + wavenet init conv + skip GEMM); `cpu_baseline` times the CPU oracle (a port of the reference path) on a
 bounded sample.  See DESIGN.md §Measurement.
 """

@@ -13,6 +13,12 @@
  *   - return value 0 = ok; otherwise a negative code, message via ns2_last_error() (thread-local).
  *   - activations travel between kernels as bf16 "split planes": hi = bf16(x), lo = bf16(x - hi).  precision
  *     3 = hi*hi+hi*lo+lo*hi on the bf16 MFMA (fp32-class, matches the fp32 reference to <1e-3), 1 = hi only.
+ *   - layout of a split-plane matrix (x_hi, x_lo, ld): `ld` is the LOGICAL column count, a multiple of 32.
+ *     x_lo != NULL: ONE bf16 buffer [rows, 2*ld]; every 32 logical columns occupy a 128-byte line [hi(32) | lo(32)],
+ *       i.e. element (r, c) has hi at r*2*ld + ((c & ~31) << 1) + (c & 31) and lo 32 elements further; the caller
+ *       passes x_lo == x_hi + 32 (anything else is NS2_ERR_HIP / invalid value).  precision 3 needs this form.
+ *     x_lo == NULL: the dense [rows, ld] hi plane alone (precision 1 only).
+ *     Transposed value planes (vt_hi, vt_lo, vt_ld) use the same rule along the key axis.
  */
 #ifndef NS2HIP_H
 #define NS2HIP_H
@@ -35,7 +41,7 @@ int ns2_debug_force_gemm(int kernel);
 /* ------------------------------------------------------------------ packed weights (library-owned) */
 typedef struct ns2_weight ns2_weight;
 /* nn.Linear weight [rows, cols] (taps = 1) or Conv1d weight [rows, cols, taps] (NS2:583-595) -> K-contiguous bf16
- * split planes, rows padded to 128, each tap's columns padded to 32.  geglu != 0 packs the rows of
+ * split planes (interleaved layout, usable at both precisions), rows padded to 256, each tap's columns padded to 32.  geglu != 0 packs the rows of
  * FeedForward's first Linear (NS2:1021) so that GEGLU (NS2:1004-1007) fuses into the GEMM epilogue.
  * extra1x1 (may be null): a [rows, cols, 1] weight appended as one more, unshifted tap (WavenetResBlock.res_conv). */
 int ns2_weight_pack(const float* w, int rows, int cols, int taps, int geglu, const float* extra1x1, ns2_weight** out,
@@ -46,7 +52,7 @@ void ns2_weight_free(ns2_weight* w);
 /* fp32 [M, d] (+ optional per-utterance addend) -> split planes [M, ldo] (zero padded) */
 int ns2_split_f32(const float* x, int ldx, int M, int d, uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream);
 
-/* split planes -> fp32 (hi + lo); lo may be null */
+/* split planes -> fp32 (hi + lo); lo may be null (dense hi-only layout) */
 int ns2_join_f32(const uint16_t* hi, const uint16_t* lo, int ld, float* out, int ldo, int64_t M, int d, void* stream);
 
 /* nn.Linear / CausalConv1d as one GEMM (NS2:1051-1069, 1021-1024, 583-595).

@@ -42,7 +42,7 @@ using namespace ns2;
 static inline int prec_ok(int p) { return p == 1 || p == 3; }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 101; }
+extern "C" int ns2_version(void) { return 102; }   // 102: interleaved [hi32|lo32] split-plane layout
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 2, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
   force_gemm_kernel(kernel);
