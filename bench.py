@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph (no live per-kernel events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conditioned", action="store_true",
+                    help="BASELINE config 3 instead of the headline: dim_prompt=512, condition_on_prompt, prompt of 103 codec "
+                         "frames, frame-aligned cond (side measurement; the roofline/cpu_baseline objects stay the headline's)")
+    ap.add_argument("--cond-scale", type=float, default=1.0, help="with --conditioned: classifier-free guidance scale (NS2:914-927)")
     args = ap.parse_args()
 
     from naturalspeech2_pytorch_amd import Model, _lib, ops
@@ -95,9 +99,13 @@ def main():
 
     B, N, dim, depth = args.batch, args.frames, args.dim, args.depth
     torch.manual_seed(1234)                          # same random-init weights on every rank
-    model = Model(dim=dim, depth=depth, precision=args.precision).to(dev).eval()
+    mkw = dict(dim_prompt=512, condition_on_prompt=True) if args.conditioned else {}
+    model = Model(dim=dim, depth=depth, precision=args.precision, **mkw).to(dev).eval()
     g = torch.Generator().manual_seed(100 + rank)
     audio = torch.randn(B, N, dim, generator=g).to(dev)
+    fwd_kw = {}
+    if args.conditioned:
+        fwd_kw = dict(prompt=torch.randn(B, 103, 512, generator=g).to(dev), cond=torch.randn(B, 512, N, generator=g).to(dev))
     n_total = args.warmup + args.steps
     ts = torch.linspace(1.0, 0.0, n_total + 1)
     t_dev = [ts[i].expand(B).contiguous().to(dev) for i in range(n_total + 1)]
@@ -106,7 +114,7 @@ def main():
     t_cur, t_nxt = t_dev[0].clone(), t_dev[1].clone()
 
     def step():
-        out = model.forward_with_cond_scale(audio, t_cur, cond_scale=1.0)
+        out = model.forward_with_cond_scale(audio, t_cur, cond_scale=args.cond_scale if args.conditioned else 1.0, **fwd_kw)
         ops.ddim_step(audio, out, t_cur, t_nxt, "v", "sigmoid", 1.0, out=audio)
 
     def barrier():
@@ -172,20 +180,25 @@ def main():
                         algorithmic_gflop_per_launch=round(fl / nl / 1e9, 2),
                         mfma_flops_per_algorithmic_flop=3 if args.precision == "exact" else 1)
         whole = None
-        if dim == 512 and depth == 12 and N == 1024:
+        if dim == 512 and depth == 12 and N == 1024 and not args.conditioned:
             whole = round(UTT_GFLOP * B * 1e9 / (elapsed / args.steps) / 1e12, 2)
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.conditioned:
             cpu = cpu_baseline(dim, depth, N)
         line = {
-            "metric": "denoise steps/sec (dim=512 depth=12, B=32x1024 latents)", "value": round(steps_per_s, 3), "unit": "steps/s",
+            "metric": "denoise steps/sec (dim=512 depth=12, B=32x1024 latents)" if not args.conditioned and (dim, depth, B, N) == (512, 12, 32, 1024)
+                      else f"denoise steps/sec (side measurement: dim={dim} depth={depth} B={B}x{N}{' conditioned' if args.conditioned else ''})",
+            "value": round(steps_per_s, 3), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3 split operands on bf16 MFMA, fp32 accumulate (fp32-class, <=1e-3 vs fp32 reference)"
                      if args.precision == "exact" else "bf16 operands, fp32 accumulate",
             "data": "synthetic (randn codec latents, random-init weights)",
-            "config": {"workload": f"Model(dim={dim}, depth={depth}) unconditional, batch {B} x {N} latent frames per GPU, "
-                                   f"forward_with_cond_scale(cond_scale=1) + DDIM update", "precision": args.precision,
+            "config": {"workload": (f"Model(dim={dim}, depth={depth}) unconditional, batch {B} x {N} latent frames per GPU, "
+                                    f"forward_with_cond_scale(cond_scale=1) + DDIM update") if not args.conditioned else
+                                   (f"Model(dim={dim}, depth={depth}, dim_prompt=512, condition_on_prompt) batch {B} x {N} frames, "
+                                    f"prompt 103 frames, cond_scale={args.cond_scale} + DDIM update (BASELINE config 3 shape)"),
+                       "precision": args.precision,
                        "global_batch": B * world, "parallelism": f"dp{world}", "graph_replay": bool(args.graph)},
             "whole_step_algorithmic_tflops_per_gpu": whole,
             "roofline": roof, "cpu_baseline": cpu,

@@ -191,9 +191,6 @@ static GemmArgs base_args(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_
   g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk;
   g.M = M; g.N = w.N; g.nkt = w.nkt; g.kt_per_tap = w.nkt; g.conv_taps = 0; g.dil = 1; g.mid_kt = -1;
   g.nz = 1; g.pad_left = -1; g.act = 0;
-#ifdef NS2_ABLATE
-  { const char* e = getenv("NS2_DBG"); g.dbg = e ? atoi(e) : 0; }
-#endif
   return g;
 }
 static void set_conv(GemmArgs& g, const PackedW& w, int taps, int dil, int seq_len) {

@@ -44,7 +44,6 @@ struct GemmArgs {
   int nz; long a_zs, w_zs, bias_zs, film_zs, out_zs;
   int pad_left;      // conv: zero rows in front of the sequence (-1 = causal: conv_taps-1); k=9 'same' padding = 4
   int act;           // 1 = SiLU after the bias (EPI_F32 / EPI_SPLIT)
-  int dbg;           // ablation switches (only honoured by -DNS2_ABLATE builds): 1 = no DMA after the first tile, 2 = no MFMA
 };
 
 hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s);   // dispatches gemm.hip / gemm2.hip by shape

@@ -1,11 +1,10 @@
 #!/bin/bash
-# effective clock of the GEMM micro-benchmark variants: GRBM_GUI_ACTIVE (per-XCD cycles, summed over 8 XCDs) / kernel time
+# effective clock of the FF-conv GEMM micro-benchmark: GRBM_GUI_ACTIVE (per-XCD cycles, summed over 8 XCDs) / kernel time
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-export NS2_LIB=$R/naturalspeech2_pytorch_amd/libns2hip_ablate.so
 cd /tmp && export TMPDIR=/tmp
-for d in 0 1 5 13; do
+for d in 0; do
   OUT=$R/gpurun_out/clk_$d; rm -rf $OUT; mkdir -p $OUT
-  NS2_DBG=$d rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT -- python $R/tools/bench_gemm.py --which ffconv --prec 3 --iters 5 > $OUT/log 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT -- python $R/tools/bench_gemm.py --which ffconv --prec 3 --iters 5 > $OUT/log 2>&1
   python - <<PY
 import csv, glob
 cc = glob.glob("$OUT/*/*counter_collection.csv")[0]; kt = glob.glob("$OUT/*/*kernel_trace.csv")[0]
