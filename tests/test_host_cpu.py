@@ -166,3 +166,20 @@ def test_sharded_sample_world2_gloo(tmp_path, total):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "OK 2" in r.stdout
+
+
+def test_planes_layout_helper_cpu():
+    """ops.Planes mirrors the library's split-plane layout (csrc/ns2_common.h): [hi32|lo32] per 32 logical columns."""
+    import torch
+    from naturalspeech2_pytorch_amd import ops
+    rows, ld = 5, 96
+    hi = torch.arange(rows * ld, dtype=torch.float32).reshape(rows, ld).to(torch.bfloat16)
+    lo = (-torch.arange(rows * ld, dtype=torch.float32).reshape(rows, ld)).to(torch.bfloat16)
+    buf = torch.stack([hi.reshape(rows, ld // 32, 32), lo.reshape(rows, ld // 32, 32)], dim=2).reshape(rows, 2 * ld).contiguous()
+    p = ops.Planes(buf, rows, ld, True)
+    assert p.lo == p.hi + 64                                   # lo pointer = hi + 32 bf16 elements
+    assert torch.equal(p.hi_plane(), hi)
+    d = p.hi_only()
+    assert not d.has_lo and d.lo is None and torch.equal(d.buf, hi)
+    for c in (0, 31, 32, 63, 64, 95):                          # physical column of logical column c
+        assert buf[2, ((c & ~31) << 1) | (c & 31)] == hi[2, c] and buf[2, (((c & ~31) << 1) | (c & 31)) + 32] == lo[2, c]
