@@ -319,6 +319,11 @@ class Model(nn.Module):
         logits = self.forward(*args, cond_drop_prob=0., **kwargs)
         if cond_scale == 1.:
             return logits
+        if not self.condition_on_prompt and not torch.is_grad_enabled():
+            # an unconditional Model ignores cond_drop_prob, so the reference's second forward reproduces `logits` bit for
+            # bit and null + (logits - null) * s == logits exactly: skip it (deterministic kernels, see
+            # test_batch_independence_and_determinism)
+            return logits
         null_logits = self.forward(*args, cond_drop_prob=1., **kwargs)
         if logits.is_cuda and not torch.is_grad_enabled():
             from . import ops
