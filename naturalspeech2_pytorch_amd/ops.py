@@ -45,10 +45,12 @@ class Planes:
 
     @property
     def hi(self) -> int:
+        """device address of the hi plane (what the C ABI takes as x_hi)"""
         return self.buf.data_ptr()
 
     @property
     def lo(self) -> Optional[int]:
+        """device address of the lo plane = hi + 32 bf16 elements, or None for the dense hi-only layout"""
         return self.buf.data_ptr() + 64 if self.has_lo else None
 
     def hi_plane(self) -> torch.Tensor:
