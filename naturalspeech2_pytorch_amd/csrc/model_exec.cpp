@@ -96,20 +96,22 @@ static int dev_alloc(std::vector<void*>* owned, void** p, size_t bytes) {
   return NS2_OK;
 }
 
-// Layout of the weights being packed (ns2_common.h): interleaved [hi32|lo32] rows with a lo plane (exact models and
-// ns2_weight_pack), dense hi-only rows for precision-1 ("fast") models.  Set by the two packing entry points.
-static bool g_pack_il = true;
+// Packing context: who owns the allocations and the layout of the weights being packed (ns2_common.h): interleaved
+// [hi32|lo32] rows with a lo plane (exact models and ns2_weight_pack) or dense hi-only rows (precision-1 "fast" models).
+struct PackCtx { std::vector<void*>* owned; bool il; };
 
 // allocate a packed weight of rows_p x ldk logical columns (zero-filled)
-static int alloc_packed(std::vector<void*>* owned, PackedW* w, int N, int ldk, int kt_per_tap) {
+static int alloc_packed(const PackCtx& pc, PackedW* w, int N, int ldk, int kt_per_tap) {
+  std::vector<void*>* owned = pc.owned;
+  const bool il = pc.il;
   w->N = N;
   w->rows_p = rup(N, 256);
   w->ldk = ldk;
   w->nkt = ldk / 32;
   w->kt_per_tap = kt_per_tap;
-  size_t bytes = (size_t)w->rows_p * ldk * sizeof(bf16_t) * (g_pack_il ? 2 : 1);
+  size_t bytes = (size_t)w->rows_p * ldk * sizeof(bf16_t) * (il ? 2 : 1);
   NSCHK(dev_alloc(owned, (void**)&w->hi, bytes));
-  w->lo = g_pack_il ? w->hi + 32 : nullptr;
+  w->lo = il ? w->hi + 32 : nullptr;
   HIPCHK(hipMemset(w->hi, 0, bytes));
   return NS2_OK;
 }
@@ -147,15 +149,15 @@ std::vector<int> geglu_row_map(int f, int rows_p) {
   return m;
 }
 
-static int pack_linear(std::vector<void*>* owned, PackedW* w, const float* src, int R, int C, int T, hipStream_t s) {
+static int pack_linear(const PackCtx& pc, PackedW* w, const float* src, int R, int C, int T, hipStream_t s) {
   const int Cp = rup(C, 32);
-  NSCHK(alloc_packed(owned, w, R, T * Cp, Cp / 32));
+  NSCHK(alloc_packed(pc, w, R, T * Cp, Cp / 32));
   return pack_into(w, src, C, T, Cp, identity_map(R, w->rows_p), 0, 0, s);
 }
 
-static int pack_geglu(std::vector<void*>* owned, PackedW* w, const float* src, int f, int C, hipStream_t s) {
+static int pack_geglu(const PackCtx& pc, PackedW* w, const float* src, int f, int C, hipStream_t s) {
   const int Cp = rup(C, 32), fpad = rup(f, 32);
-  NSCHK(alloc_packed(owned, w, 2 * fpad, Cp, Cp / 32));
+  NSCHK(alloc_packed(pc, w, 2 * fpad, Cp, Cp / 32));
   return pack_into(w, src, C, 1, Cp, geglu_row_map(f, w->rows_p), 0, 0, s);
 }
 
@@ -174,10 +176,10 @@ static int pack_geglu_bias(std::vector<void*>* owned, float** out, const float* 
 int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, PackedW* out,
                        std::vector<void*>* owned, hipStream_t s) {
   const int Cp = rup(cols, 32);
-  g_pack_il = true;                                  // op-level weights serve both precisions
-  if (geglu) return pack_geglu(owned, out, w, rows / 2, cols, s);
+  const PackCtx pc{owned, true};                     // op-level weights serve both precisions
+  if (geglu) return pack_geglu(pc, out, w, rows / 2, cols, s);
   const int T = taps + (extra ? 1 : 0);
-  NSCHK(alloc_packed(owned, out, rows, T * Cp, Cp / 32));
+  NSCHK(alloc_packed(pc, out, rows, T * Cp, Cp / 32));
   NSCHK(pack_into(out, w, cols, taps, Cp, identity_map(rows, out->rows_p), 0, 0, s));
   if (extra) NSCHK(pack_into(out, extra, cols, 1, Cp, identity_map(rows, out->rows_p), 0, taps * Cp, s));
   return NS2_OK;
@@ -305,7 +307,8 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
   const int dim = m->dim, a = m->a, f = m->f, L = m->L, S = m->S;
   const bool cond = m->cfg.condition_on_prompt;
   char key[256];
-  g_pack_il = (m->cfg.precision == 3);               // exact: interleaved hi/lo rows; fast: dense hi-only weights
+  const PackCtx pc{&m->owned, m->cfg.precision == 3};  // exact: interleaved hi/lo rows; fast: dense hi-only weights
+  const bool il = pc.il;
 
   // ---- time conditioning (NS2:839-843)
   { GETP(fw, "to_time_cond.0.weights"); m->freqs = fw->p; }
@@ -337,15 +340,15 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
 
   // ---- wavenet (NS2:690-725)
   { GETP(w, "wavenet.init_conv.weight"); GETP(b, "wavenet.init_conv.bias");
-    NSCHK(pack_linear(&m->owned, &m->w_init, w->p, dim, dim, (int)w->dims[2], s)); m->b_init = b->p; }
+    NSCHK(pack_linear(pc, &m->w_init, w->p, dim, dim, (int)w->dims[2], s)); m->b_init = b->p; }
   m->w_wn.resize(S); m->b_wn_conv.resize(S); m->b_wn_res.resize(S);
   for (int st = 0; st < S; ++st) {
     PackedW& W = m->w_wn[st];
     // batched: L matrices of [rows_p, 4*dp] back to back
     W.N = dim; W.rows_p = rup(dim, 256); W.ldk = 4 * m->dp; W.nkt = W.ldk / 32; W.kt_per_tap = m->dp / 32;
-    const size_t per = (size_t)W.rows_p * W.ldk * (g_pack_il ? 2 : 1);     // physical elements per matrix
+    const size_t per = (size_t)W.rows_p * W.ldk * (il ? 2 : 1);     // physical elements per matrix
     NSCHK(dev_alloc(&m->owned, (void**)&W.hi, per * L * sizeof(bf16_t)));
-    W.lo = g_pack_il ? W.hi + 32 : nullptr;
+    W.lo = il ? W.hi + 32 : nullptr;
     HIPCHK(hipMemset(W.hi, 0, per * L * sizeof(bf16_t)));
     NSCHK(dev_alloc(&m->owned, (void**)&m->b_wn_conv[st], (size_t)L * dim * sizeof(float)));
     NSCHK(dev_alloc(&m->owned, (void**)&m->b_wn_res[st], (size_t)L * dim * sizeof(float)));
@@ -361,7 +364,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
     }
   }
   { // skip convs of the last stack, concatenated along K; summed bias (NS2:639-640, 685-686, 725)
-    NSCHK(alloc_packed(&m->owned, &m->w_skip, dim, L * m->dp, L * m->dp / 32));
+    NSCHK(alloc_packed(pc, &m->w_skip, dim, L * m->dp, L * m->dp / 32));
     std::vector<float> bsum(dim, 0.f), hb(dim);
     for (int i = 0; i < L; ++i) {
       snprintf(key, sizeof key, "wavenet.stacks.%d.blocks.%d.skip_conv", S - 1, i);
@@ -374,7 +377,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
     HIPCHK(hipMemcpy(m->b_skip, bsum.data(), dim * sizeof(float), hipMemcpyHostToDevice));
   }
   { GETP(w, "wavenet.final_conv.weight"); GETP(b, "wavenet.final_conv.bias");
-    NSCHK(pack_linear(&m->owned, &m->w_final, w->p, dim, dim, 1, s)); m->b_final = b->p; }
+    NSCHK(pack_linear(pc, &m->w_final, w->p, dim, dim, 1, s)); m->b_final = b->p; }
 
   // ---- transformer (NS2:748-809)
   m->layers.resize(m->cfg.depth);
@@ -383,27 +386,27 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
     snprintf(key, sizeof key, "transformer.layers.%d", l);
     const std::string p(key);
     { GETP(q, p + ".1.to_q.weight"); GETP(kv, p + ".1.to_kv.weight"); GETP(o, p + ".1.to_out.weight");
-      NSCHK(alloc_packed(&m->owned, &ly.qkv, 3 * a, m->dp, m->dp / 32));
+      NSCHK(alloc_packed(pc, &ly.qkv, 3 * a, m->dp, m->dp / 32));
       NSCHK(pack_into(&ly.qkv, q->p, dim, 1, m->dp, identity_map(a, a), 0, 0, s));
       NSCHK(pack_into(&ly.qkv, kv->p, dim, 1, m->dp, identity_map(2 * a, ly.qkv.rows_p - a), a, 0, s));
-      NSCHK(pack_linear(&m->owned, &ly.out, o->p, dim, a, 1, s)); }
+      NSCHK(pack_linear(pc, &ly.out, o->p, dim, a, 1, s)); }
     if (cond) {
       GETP(q, p + ".3.to_q.weight"); GETP(kv, p + ".3.to_kv.weight"); GETP(o, p + ".3.to_out.weight");
-      NSCHK(pack_linear(&m->owned, &ly.cq, q->p, a, dim, 1, s));
-      NSCHK(pack_linear(&m->owned, &ly.ckv, kv->p, 2 * a, dim, 1, s));
-      NSCHK(pack_linear(&m->owned, &ly.cout, o->p, dim, a, 1, s));
+      NSCHK(pack_linear(pc, &ly.cq, q->p, a, dim, 1, s));
+      NSCHK(pack_linear(pc, &ly.ckv, kv->p, 2 * a, dim, 1, s));
+      NSCHK(pack_linear(pc, &ly.cout, o->p, dim, a, 1, s));
     }
     { GETP(w1, p + ".5.0.weight"); GETP(b1, p + ".5.0.bias");
       GETP(cw, p + ".5.2.1.weight"); GETP(cb, p + ".5.2.1.bias");
       GETP(w2, p + ".5.3.weight"); GETP(b2, p + ".5.3.bias");
       if (w1->dims[0] != 2 * f) { set_error("FF inner dim mismatch: expected %d got %lld", 2 * f, (long long)w1->dims[0]); return NS2_ERR_STATE; }
-      NSCHK(pack_geglu(&m->owned, &ly.ffin, w1->p, f, dim, s));
+      NSCHK(pack_geglu(pc, &ly.ffin, w1->p, f, dim, s));
       NSCHK(pack_geglu_bias(&m->owned, &ly.b_ffin, b1->p, f, ly.ffin.rows_p));
-      NSCHK(pack_linear(&m->owned, &ly.conv, cw->p, f, f, 3, s)); ly.b_conv = cb->p;
-      NSCHK(pack_linear(&m->owned, &ly.ffout, w2->p, dim, f, 1, s)); ly.b_ffout = b2->p; }
+      NSCHK(pack_linear(pc, &ly.conv, cw->p, f, f, 3, s)); ly.b_conv = cb->p;
+      NSCHK(pack_linear(pc, &ly.ffout, w2->p, dim, f, 1, s)); ly.b_ffout = b2->p; }
   }
   { GETP(g, "transformer.to_pred.0.gamma"); GETP(w, "transformer.to_pred.1.weight");
-    m->g_pred = g->p; NSCHK(pack_linear(&m->owned, &m->w_pred, w->p, dim, dim, 1, s)); }
+    m->g_pred = g->p; NSCHK(pack_linear(pc, &m->w_pred, w->p, dim, dim, 1, s)); }
 
   // ---- prompt conditioning (NS2:849-881)
   if (cond) {
@@ -414,11 +417,11 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
     { GETP(p2, "null_prompt_tokens"); m->null_prompt_tokens = p2->p; }
     { GETP(p3, "null_cond"); m->null_cond = p3->p; }
     { GETP(w, "cond_to_model_dim.weight"); GETP(b, "cond_to_model_dim.bias");
-      NSCHK(pack_linear(&m->owned, &m->w_cond2model, w->p, dim, dprompt, 1, s)); m->b_cond2model = b->p; }
+      NSCHK(pack_linear(pc, &m->w_cond2model, w->p, dim, dprompt, 1, s)); m->b_cond2model = b->p; }
     m->has_proj = find_param(m, "perceiver_resampler.proj_context.weight") != nullptr;
     if (m->has_proj) {
       GETP(w, "perceiver_resampler.proj_context.weight"); GETP(b, "perceiver_resampler.proj_context.bias");
-      NSCHK(pack_linear(&m->owned, &m->w_proj, w->p, dim, dprompt, 1, s)); m->b_proj = b->p;
+      NSCHK(pack_linear(pc, &m->w_proj, w->p, dim, dprompt, 1, s)); m->b_proj = b->p;
     } else if (dprompt != dim) { set_error("dim_prompt != dim but proj_context is missing"); return NS2_ERR_STATE; }
     { GETP(lt, "perceiver_resampler.latents"); m->latents = lt->p; }
     { GETP(g, "perceiver_resampler.norm.gamma"); m->g_resampler = g->p; }
@@ -429,12 +432,12 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
       const std::string p(key);
       GETP(q, p + ".0.to_q.weight"); GETP(kv, p + ".0.to_kv.weight"); GETP(o, p + ".0.to_out.weight");
       GETP(w1, p + ".1.0.weight"); GETP(b1, p + ".1.0.bias"); GETP(w2, p + ".1.2.weight"); GETP(b2, p + ".1.2.bias");
-      NSCHK(pack_linear(&m->owned, &r.q, q->p, a, dim, 1, s));
-      NSCHK(pack_linear(&m->owned, &r.kv, kv->p, 2 * a, dim, 1, s));
-      NSCHK(pack_linear(&m->owned, &r.out, o->p, dim, a, 1, s));
-      NSCHK(pack_geglu(&m->owned, &r.ffin, w1->p, f, dim, s));
+      NSCHK(pack_linear(pc, &r.q, q->p, a, dim, 1, s));
+      NSCHK(pack_linear(pc, &r.kv, kv->p, 2 * a, dim, 1, s));
+      NSCHK(pack_linear(pc, &r.out, o->p, dim, a, 1, s));
+      NSCHK(pack_geglu(pc, &r.ffin, w1->p, f, dim, s));
       NSCHK(pack_geglu_bias(&m->owned, &r.b_ffin, b1->p, f, r.ffin.rows_p));
-      NSCHK(pack_linear(&m->owned, &r.ffout, w2->p, dim, f, 1, s)); r.b_ffout = b2->p;
+      NSCHK(pack_linear(pc, &r.ffout, w2->p, dim, f, 1, s)); r.b_ffout = b2->p;
     }
   }
   HIPCHK(hipStreamSynchronize(s));
