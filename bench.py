@@ -8,8 +8,12 @@ path's single RCCL all-gather of the generated latents runs once after the K ste
 
     python bench.py [--gpus N --steps K --warmup W] [--precision exact|fast] [--graph]
 
+Default precision is "half" (one fp16 product per contraction, fp32 accumulate): it meets the 1e-3 tolerance of
+BASELINE.json on every reference golden and at the headline architecture (7.6e-4..8.5e-4) with a third of the MFMA work of
+the bf16x3 "exact" mode (1e-5), which the same JSON line reports under "exact_mode" from a short second measurement.
+
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events recorded by the executor on the
-launch stream around every launch of the dominant kernel symbol (gemm2_kernel<NSPLIT, EPI_SPLIT>: the 12 FF causal
+launch stream around every launch of the dominant kernel symbol (gemm2_kernel<NSPLIT, EPI_SPLIT, F16>: the 12 FF causal
 convs + wavenet init conv + skip GEMM); `cpu_baseline` times the CPU oracle (a port of the reference path) on a
 bounded sample.  See DESIGN.md §Measurement.
 """
@@ -71,7 +75,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--precision", default="half", choices=["exact", "half", "fast"],
+                    help="half (default): one fp16 product per contraction, 7.6e-4 from the fp32 reference at this config; "
+                         "exact: bf16x3 split, 1e-5; fast: bf16, ~1e-2 (outside the 1e-3 tolerance, for comparison only)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short exact-mode measurement added to the default line")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--dim", type=int, default=512)
@@ -98,85 +105,97 @@ def main():
     dev = torch.device("cuda", local_dev)
 
     B, N, dim, depth = args.batch, args.frames, args.dim, args.depth
-    torch.manual_seed(1234)                          # same random-init weights on every rank
-    mkw = dict(dim_prompt=512, condition_on_prompt=True) if args.conditioned else {}
-    model = Model(dim=dim, depth=depth, precision=args.precision, **mkw).to(dev).eval()
-    g = torch.Generator().manual_seed(100 + rank)
-    audio = torch.randn(B, N, dim, generator=g).to(dev)
-    fwd_kw = {}
-    if args.conditioned:
-        fwd_kw = dict(prompt=torch.randn(B, 103, 512, generator=g).to(dev), cond=torch.randn(B, 512, N, generator=g).to(dev))
-    n_total = args.warmup + args.steps
-    ts = torch.linspace(1.0, 0.0, n_total + 1)
-    t_dev = [ts[i].expand(B).contiguous().to(dev) for i in range(n_total + 1)]
     lib = _lib.load()
 
-    t_cur, t_nxt = t_dev[0].clone(), t_dev[1].clone()
+    def measure(precision, steps, warmup):
+        """W untimed + exactly K timed steps of one precision mode; returns (elapsed s of the K steps, kernel ms, launches)"""
+        torch.manual_seed(1234)                          # same random-init weights on every rank
+        mkw = dict(dim_prompt=512, condition_on_prompt=True) if args.conditioned else {}
+        model = Model(dim=dim, depth=depth, precision=precision, **mkw).to(dev).eval()
+        g = torch.Generator().manual_seed(100 + rank)
+        audio = torch.randn(B, N, dim, generator=g).to(dev)
+        fwd_kw = {}
+        if args.conditioned:
+            fwd_kw = dict(prompt=torch.randn(B, 103, 512, generator=g).to(dev), cond=torch.randn(B, 512, N, generator=g).to(dev))
+        n_total = warmup + steps
+        ts = torch.linspace(1.0, 0.0, n_total + 1)
+        t_dev = [ts[i].expand(B).contiguous().to(dev) for i in range(n_total + 1)]
 
-    def step():
-        out = model.forward_with_cond_scale(audio, t_cur, cond_scale=args.cond_scale if args.conditioned else 1.0, **fwd_kw)
-        ops.ddim_step(audio, out, t_cur, t_nxt, "v", "sigmoid", 1.0, out=audio)
+        t_cur, t_nxt = t_dev[0].clone(), t_dev[1].clone()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def step():
+            out = model.forward_with_cond_scale(audio, t_cur, cond_scale=args.cond_scale if args.conditioned else 1.0, **fwd_kw)
+            ops.ddim_step(audio, out, t_cur, t_nxt, "v", "sigmoid", 1.0, out=audio)
 
-    with torch.no_grad():
-        graph = None
-        for i in range(args.warmup):
-            t_cur.copy_(t_dev[i]); t_nxt.copy_(t_dev[i + 1])
-            step()
-        if args.graph:
+        def barrier():
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            keep = audio.clone()
-            with torch.cuda.graph(graph):
-                step()
-            audio.copy_(keep)
-        ns = model._ensure_native()
-        prof_mask = 0 if args.graph else (1 << 1)    # gemm_kernel<*, EPI_SPLIT>
-        barrier()
-        if prof_mask:
-            lib.ns2_model_profile_begin(ns.handle, prof_mask)
-        t0 = time.perf_counter()
-        for i in range(args.warmup, n_total):
-            t_cur.copy_(t_dev[i]); t_nxt.copy_(t_dev[i + 1])
-            if graph is not None:
-                graph.replay()
-            else:
-                step()
-        if world > 1:                                # the sharded sampler's single collective
-            bufs = [torch.empty_like(audio) for _ in range(world)]
-            dist.all_gather(bufs, audio)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        kern_ms, kern_n = ctypes.c_double(0), ctypes.c_int64(0)
-        if prof_mask:
-            _lib.check(lib.ns2_model_profile_end(ns.handle, ctypes.byref(kern_ms), ctypes.byref(kern_n)), "profile_end")
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = el.item()
-    assert torch.isfinite(audio).all()
+        with torch.no_grad():
+            graph = None
+            for i in range(warmup):
+                t_cur.copy_(t_dev[i]); t_nxt.copy_(t_dev[i + 1])
+                step()
+            if args.graph:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                keep = audio.clone()
+                with torch.cuda.graph(graph):
+                    step()
+                audio.copy_(keep)
+            ns = model._ensure_native()
+            prof_mask = 0 if args.graph else (1 << 1)    # gemm_kernel<*, EPI_SPLIT>
+            barrier()
+            if prof_mask:
+                lib.ns2_model_profile_begin(ns.handle, prof_mask)
+            t0 = time.perf_counter()
+            for i in range(warmup, n_total):
+                t_cur.copy_(t_dev[i]); t_nxt.copy_(t_dev[i + 1])
+                if graph is not None:
+                    graph.replay()
+                else:
+                    step()
+            if world > 1:                                # the sharded sampler's single collective (SURVEY §8e)
+                bufs = [torch.empty_like(audio) for _ in range(world)]
+                dist.all_gather(bufs, audio)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            kern_ms, kern_n = ctypes.c_double(0), ctypes.c_int64(0)
+            if prof_mask:
+                _lib.check(lib.ns2_model_profile_end(ns.handle, ctypes.byref(kern_ms), ctypes.byref(kern_n)), "profile_end")
 
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        assert torch.isfinite(audio).all()
+        return el.item(), kern_ms.value, kern_n.value
+
+    elapsed, kern_ms_v, kern_n_v = measure(args.precision, args.steps, args.warmup)
+    secondary = None
+    if args.precision == "half" and not args.no_secondary and world == 1 and not args.graph:
+        k2 = min(args.steps, 10)
+        e2, _, _ = measure("exact", k2, 2)
+        secondary = dict(value=round(k2 / e2, 3), unit="steps/s", steps=k2, ms_per_step=round(1e3 * e2 / k2, 3),
+                         dtype="bf16x3 split operands on bf16 MFMA, fp32 accumulate",
+                         rel_err_vs_fp32_reference="<=1e-4 (tests/test_model_gpu.py goldens, 1e-5 typical)")
     if rank == 0:
         steps_per_s = world * args.steps / elapsed
         fl, nl = dominant_flops(B, N, dim, depth, 4, 8)
         roof = None
-        if kern_n.value:
-            avg_ms = kern_ms.value / kern_n.value
+        if kern_n_v:
+            avg_ms = kern_ms_v / kern_n_v
             ach = (fl / nl) / (avg_ms * 1e-3) / 1e12
             traffic = None
             pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
             if os.path.exists(pj):
-                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
-            roof = dict(bound="mfma", kernel="ns2::gemm2_kernel<%d, 1> = EPI_SPLIT (FF causal conv k3 x%d, wavenet init conv, skip-sum GEMM)"
-                        % (3 if args.precision == "exact" else 1, depth),
+                tj = json.load(open(pj))
+                traffic = tj.get("hbm_bytes_per_launch_by_precision", {}).get(args.precision, tj.get("hbm_bytes_per_launch"))
+            roof = dict(bound="mfma", kernel="ns2::gemm2_kernel<%d, 1, %s> = EPI_SPLIT (FF causal conv k3 x%d, wavenet init conv, skip-sum GEMM)"
+                        % (3 if args.precision == "exact" else 1, "true" if args.precision == "half" else "false", depth),
                         achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=traffic, avg_launch_ms=round(avg_ms, 4), launches=kern_n.value,
+                        traffic=traffic, avg_launch_ms=round(avg_ms, 4), launches=kern_n_v,
                         algorithmic_gflop_per_launch=round(fl / nl / 1e9, 2),
                         mfma_flops_per_algorithmic_flop=3 if args.precision == "exact" else 1)
         whole = None
@@ -191,8 +210,9 @@ def main():
             "value": round(steps_per_s, 3), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 split operands on bf16 MFMA, fp32 accumulate (fp32-class, <=1e-3 vs fp32 reference)"
-                     if args.precision == "exact" else "bf16 operands, fp32 accumulate",
+            "dtype": {"exact": "bf16x3 split operands on bf16 MFMA, fp32 accumulate (fp32-class, <=1e-3 vs fp32 reference)",
+                      "half": "fp16 operands on the f16 MFMA (one product), fp32 accumulate",
+                      "fast": "bf16 operands, fp32 accumulate"}[args.precision],
             "data": "synthetic (randn codec latents, random-init weights)",
             "config": {"workload": (f"Model(dim={dim}, depth={depth}) unconditional, batch {B} x {N} latent frames per GPU, "
                                     f"forward_with_cond_scale(cond_scale=1) + DDIM update") if not args.conditioned else
@@ -202,7 +222,13 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "graph_replay": bool(args.graph)},
             "whole_step_algorithmic_tflops_per_gpu": whole,
             "roofline": roof, "cpu_baseline": cpu,
+            "parity": {"exact": "1e-5 vs the fp32 reference goldens (asserted < 1e-3; tests/test_model_gpu.py)",
+                       "half": "7.6e-4 at this architecture, 7.7e-4..8.5e-4 on the reference goldens (asserted < 1e-3; "
+                               "tests/test_model_gpu.py::test_half_mode_*)",
+                       "fast": "~4e-3..1e-2: outside the 1e-3 tolerance, comparison only"}[args.precision],
         }
+        if secondary:
+            line["exact_mode"] = secondary
         if cpu:
             line["gpu_over_cpu"] = round(steps_per_s / cpu["value"], 1)
         print(json.dumps(line))

@@ -123,7 +123,7 @@ typedef struct ns2_model ns2_model;
 typedef struct {
   int dim, depth, dim_head, heads, ff_mult, wavenet_layers, wavenet_stacks, dim_cond_mult;   /* NS2:814-823 */
   int condition_on_prompt, dim_prompt, num_latents_m, resampler_depth;                       /* NS2:826-831 */
-  int precision;                                                                             /* 3 exact, 1 fast */
+  int precision;               /* 3 = bf16 x3 split "exact", 2 = fp16 single product "half", 1 = bf16 single product "fast" */
 } ns2_model_config;
 
 int ns2_model_create(const ns2_model_config* cfg, ns2_model** out);

@@ -37,7 +37,7 @@ NS2_DEVINL uint4 mask_chunk(uint4 v, int nvalid) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int NSPLIT>
+template <int NSPLIT, bool F16>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   constexpr int NP = (NSPLIT == 3) ? 2 : 1;
   constexpr int STAGE_BYTES = 2 * NP * AT_PLANE;     // K planes then V^T planes
@@ -154,10 +154,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
         for (int p = 0; p < NP; ++p)
           kf[p] = *reinterpret_cast<const bf16x8*>(sb + p * AT_PLANE + k_frag_off + js * 32 * AT_ROWB + c * 32);
         if constexpr (NSPLIT == 3) {
-          st[js] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][c], st[js], 0, 0, 0);
-          st[js] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][c], st[js], 0, 0, 0);
+          st[js] = mma16<F16>(kf[1], qf[0][c], st[js]);
+          st[js] = mma16<F16>(kf[0], qf[1][c], st[js]);
         }
-        st[js] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][c], st[js], 0, 0, 0);
+        st[js] = mma16<F16>(kf[0], qf[0][c], st[js]);
       }
     }
 
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
         {
           uint32_t ph[4], pl[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) split2(st[js][8 * g1 + 2 * e], st[js][8 * g1 + 2 * e + 1], ph[e], pl[e]);
+          for (int e = 0; e < 4; ++e) split2f(st[js][8 * g1 + 2 * e], st[js][8 * g1 + 2 * e + 1], ph[e], pl[e], F16);
           const uint4 uh = make_uint4(ph[0], ph[1], ph[2], ph[3]);
           pf[0] = *reinterpret_cast<const bf16x8*>(&uh);
           if constexpr (NSPLIT == 3) {
@@ -222,10 +222,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
             vf[p] = *reinterpret_cast<const bf16x8*>(sb + (NP + p) * AT_PLANE + v_frag_off + dt * 32 * AT_ROWB +
                                                     js * 64 + g1 * 32);
           if constexpr (NSPLIT == 3) {
-            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf[0], ot[dt], 0, 0, 0);
-            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[1], ot[dt], 0, 0, 0);
+            ot[dt] = mma16<F16>(vf[1], pf[0], ot[dt]);
+            ot[dt] = mma16<F16>(vf[0], pf[1], ot[dt]);
           }
-          ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf[0], ot[dt], 0, 0, 0);
+          ot[dt] = mma16<F16>(vf[0], pf[0], ot[dt]);
         }
       }
 
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         uint32_t h01, l01, h23, l23;
-        split2(ot[dt][4 * gq + 0] * inv, ot[dt][4 * gq + 1] * inv, h01, l01);
-        split2(ot[dt][4 * gq + 2] * inv, ot[dt][4 * gq + 3] * inv, h23, l23);
+        split2f(ot[dt][4 * gq + 0] * inv, ot[dt][4 * gq + 1] * inv, h01, l01, F16);
+        split2f(ot[dt][4 * gq + 2] * inv, ot[dt][4 * gq + 3] * inv, h23, l23, F16);
         const long o = obase + pcol(h * 64 + 32 * dt + 8 * gq + 4 * hi, oil);
         *reinterpret_cast<uint2*>(a.o_hi + o) = make_uint2(h01, h23);
         if (oil) *reinterpret_cast<uint2*>(a.o_lo + o) = make_uint2(l01, l23);
@@ -252,18 +252,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   }
 }
 
-template <int NSPLIT>
+template <int NSPLIT, bool F16>
 static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
   const size_t lds = 2 * 2 * (NSPLIT == 3 ? 2 : 1) * AT_PLANE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<NSPLIT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<NSPLIT, F16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   dim3 grid(((a.Nq + 127) / 128) * a.H * a.B);
-  hipLaunchKernelGGL((attn_kernel<NSPLIT>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((attn_kernel<NSPLIT, F16>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
@@ -274,9 +274,13 @@ hipError_t launch_attention(const AttnArgs& a, int nsplit, hipStream_t s) {
   if (a.vt_lo && (a.vt_ld & 31)) return hipErrorInvalidValue;   // interleaved rows come in 32-column blocks
   if (nsplit == 3) {
     if (!a.q_lo || !a.k_lo || !a.vt_lo) return hipErrorInvalidValue;
-    return launch_attn_t<3>(a, s);
+    return launch_attn_t<3, false>(a, s);
   }
-  return launch_attn_t<1>(a, s);
+  if (nsplit == 2) {                                  // "half" precision: fp16 hi-only planes, one product
+    if (a.q_lo || a.k_lo || a.vt_lo || a.o_lo) return hipErrorInvalidValue;
+    return launch_attn_t<1, true>(a, s);
+  }
+  return launch_attn_t<1, false>(a, s);
 }
 
 }  // namespace ns2

@@ -154,7 +154,7 @@ extern "C" int ns2_rmsnorm(const float* x, int ldx, int M, int d, int seq_len, c
   ARGCHK(!cond || seq_len > 0, "ns2_rmsnorm: adaptive norm needs seq_len");
   NormArgs n;
   n.x = x; n.ldx = ldx; n.gamma = gamma; n.cond = cond; n.cond_ld = cond_ld;
-  n.out_hi = out_hi; n.out_lo = out_lo; n.ldo = out_hi ? ldo : d; n.out_f = out_f32; n.ldo_f = ldo_f;
+  n.out_hi = out_hi; n.out_lo = out_lo; n.ldo = out_hi ? ldo : d; n.out_f = out_f32; n.ldo_f = ldo_f; n.f16 = 0;
   n.M = M; n.d = d; n.seq_len = seq_len;
   HIPRET(launch_rmsnorm(n, (hipStream_t)stream));
   return NS2_OK;

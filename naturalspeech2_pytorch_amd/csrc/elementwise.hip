@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const NormArgs a) {
       }
     }
     uint32_t h01, l01, h23, l23;
-    split2(o[0], o[1], h01, l01);
-    split2(o[2], o[3], h23, l23);
+    split2f(o[0], o[1], h01, l01, a.f16);
+    split2f(o[2], o[3], h23, l23, a.f16);
     if (a.out_hi) {
       const bool il = a.out_lo != nullptr;
       const long po = row * pld(a.ldo, il) + pcol(c, il);
@@ -87,7 +87,7 @@ hipError_t launch_rmsnorm(const NormArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------- x (+ add) -> split planes
 __global__ __launch_bounds__(256) void split_kernel(const float* x, int ldx, const float* add, int ldadd, int add_rows,
                                                     int add_valid, bf16_t* out_hi, bf16_t* out_lo, int ldo, long M, int d,
-                                                    int seq_len) {
+                                                    int seq_len, int f16) {
   const int chunks = ldo >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * chunks) return;
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) void split_kernel(const float* x, int ldx, con
     }
   }
   uint32_t h01, l01, h23, l23;
-  split2(o[0], o[1], h01, l01);
-  split2(o[2], o[3], h23, l23);
+  split2f(o[0], o[1], h01, l01, f16);
+  split2f(o[2], o[3], h23, l23, f16);
   const bool il = out_lo != nullptr;
   const long po = row * pld(ldo, il) + pcol(c, il);
   *reinterpret_cast<uint2*>(out_hi + po) = make_uint2(h01, h23);
@@ -124,12 +124,12 @@ __global__ __launch_bounds__(256) void split_kernel(const float* x, int ldx, con
 }
 
 hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, int add_rows_per_batch, int add_valid_rows,
-                        bf16_t* out_hi, bf16_t* out_lo, int ldo, int M, int d, int seq_len, hipStream_t s) {
+                        bf16_t* out_hi, bf16_t* out_lo, int ldo, int M, int d, int seq_len, hipStream_t s, int f16) {
   if (M <= 0 || (ldo & 3) || ldo < d || (add && seq_len <= 0)) return hipErrorInvalidValue;
-  if (!planes_ok(out_hi, out_lo) || (out_lo && (ldo & 31))) return hipErrorInvalidValue;
+  if (!planes_ok(out_hi, out_lo) || (out_lo && (ldo & 31)) || (f16 && out_lo)) return hipErrorInvalidValue;
   const long total = (long)M * (ldo >> 2);
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, add, ldadd,
-                     add_rows_per_batch, add_valid_rows, out_hi, out_lo, ldo, (long)M, d, seq_len);
+                     add_rows_per_batch, add_valid_rows, out_hi, out_lo, ldo, (long)M, d, seq_len, f16);
   return hipGetLastError();
 }
 
@@ -350,21 +350,21 @@ hipError_t launch_transpose_into(const float* src, int R, int C, float* dst, lon
 }
 
 // split planes -> fp32 (hi + lo), used by debug taps and tests
-__global__ void join_kernel(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d) {
+__global__ void join_kernel(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, int f16) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= M * d) return;
   const long r = i / d;
   const int c = (int)(i - r * d);
   const bool il = lo != nullptr;
   const long o = r * pld(ld, il) + pcol(c, il);
-  float v = bf2f(hi[o]);
+  float v = f16 ? h2f(hi[o]) : bf2f(hi[o]);
   if (il) v += bf2f(lo[o]);
   out[r * ldo + c] = v;
 }
-hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s) {
-  if (!planes_ok(hi, lo)) return hipErrorInvalidValue;
+hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s, int f16) {
+  if (!planes_ok(hi, lo) || (f16 && lo)) return hipErrorInvalidValue;
   const long n = M * d;
-  hipLaunchKernelGGL(join_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hi, lo, ld, out, ldo, M, d);
+  hipLaunchKernelGGL(join_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hi, lo, ld, out, ldo, M, d, f16);
   return hipGetLastError();
 }
 
@@ -429,7 +429,7 @@ hipError_t launch_cfg_mix(const float* cond, const float* null, float* out, long
 
 // ---------------------------------------------------------------- weight packing (one-time, at model finalize)
 __global__ void pack_weight_kernel(const float* src, int C, int T, int Cp, const int* row_map, int rows_p, bf16_t* dst_hi,
-                                   bf16_t* dst_lo, int ldk, int k_off) {
+                                   bf16_t* dst_lo, int ldk, int k_off, int f16) {
   const int kk = blockIdx.x * 256 + threadIdx.x;          // column inside [0, T*Cp)
   const int rp = blockIdx.y;
   if (kk >= T * Cp || rp >= rows_p) return;
@@ -439,16 +439,17 @@ __global__ void pack_weight_kernel(const float* src, int C, int T, int Cp, const
   if (r >= 0 && c < C) v = src[((long)r * C + c) * T + tap];
   bf16_t h, l;
   split_bf16(v, h, l);
+  if (f16) h = (bf16_t)(cvt2h(v, 0.f) & 0xffffu);
   const bool il = dst_lo != nullptr;
   const long o = (long)rp * pld(ldk, il) + pcol(k_off + kk, il);
   dst_hi[o] = h;
   if (il) dst_lo[o] = l;
 }
 hipError_t launch_pack_weight(const float* src, int C, int T, int Cp, const int* row_map, int rows_p, bf16_t* dst_hi,
-                              bf16_t* dst_lo, int ldk, int k_off, hipStream_t s) {
-  if (!planes_ok(dst_hi, dst_lo)) return hipErrorInvalidValue;
+                              bf16_t* dst_lo, int ldk, int k_off, hipStream_t s, int f16) {
+  if (!planes_ok(dst_hi, dst_lo) || (f16 && dst_lo)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((T * Cp + 255) / 256, rows_p), dim3(256), 0, s, src, C, T, Cp, row_map,
-                     rows_p, dst_hi, dst_lo, ldk, k_off);
+                     rows_p, dst_hi, dst_lo, ldk, k_off, f16);
   return hipGetLastError();
 }
 

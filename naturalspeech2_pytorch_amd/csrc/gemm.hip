@@ -39,7 +39,7 @@ struct Stage {                                // registers holding one prefetche
 NS2_DEVINL uint4 ld16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 NS2_DEVINL uint4 zero16() { return make_uint4(0u, 0u, 0u, 0u); }
 
-template <int NSPLIT, int EPI>
+template <int NSPLIT, int EPI, bool F16>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   constexpr int NP = (NSPLIT == 3) ? 2 : 1;   // planes per operand
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -154,10 +154,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             if constexpr (NSPLIT == 3) {
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], wf[0][ni], acc[mi][ni], 0, 0, 0);
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], wf[1][ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = mma16<F16>(af[1][mi], wf[0][ni], acc[mi][ni]);
+              acc[mi][ni] = mma16<F16>(af[0][mi], wf[1][ni], acc[mi][ni]);
             }
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], wf[0][ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = mma16<F16>(af[0][mi], wf[0][ni], acc[mi][ni]);
           }
       }
       if (more) store_stage(st, (kt + 1) & 1);
@@ -176,30 +176,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   gemm_epilogue<EPI, 2, 2>(acc, g, z, row_base, col_base, tn * 64 + wn * 32, lane);
 }
 
-template <int NSPLIT, int EPI>
+template <int NSPLIT, int EPI, bool F16>
 static hipError_t launch_one(const GemmArgs& g, hipStream_t s) {
   const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
   const int nz = g.nz > 0 ? g.nz : 1;
   const size_t lds = 2 * 2 * (NSPLIT == 3 ? 2 : 1) * PLANE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NSPLIT, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NSPLIT, EPI, F16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<NSPLIT, EPI>), dim3(ntn * ntm * nz), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gemm_kernel<NSPLIT, EPI, F16>), dim3(ntn * ntm * nz), dim3(256), lds, s, g);
   return hipGetLastError();
 }
 
-template <int NSPLIT>
+template <int NSPLIT, bool F16>
 static hipError_t launch_epi(const GemmArgs& g, hipStream_t s) {
   switch (g.epi) {
-    case EPI_F32: return launch_one<NSPLIT, EPI_F32>(g, s);
-    case EPI_SPLIT: return launch_one<NSPLIT, EPI_SPLIT>(g, s);
-    case EPI_QKV: return launch_one<NSPLIT, EPI_QKV>(g, s);
-    case EPI_GEGLU: return launch_one<NSPLIT, EPI_GEGLU>(g, s);
-    case EPI_WAVENET: return launch_one<NSPLIT, EPI_WAVENET>(g, s);
+    case EPI_F32: return launch_one<NSPLIT, EPI_F32, F16>(g, s);
+    case EPI_SPLIT: return launch_one<NSPLIT, EPI_SPLIT, F16>(g, s);
+    case EPI_QKV: return launch_one<NSPLIT, EPI_QKV, F16>(g, s);
+    case EPI_GEGLU: return launch_one<NSPLIT, EPI_GEGLU, F16>(g, s);
+    case EPI_WAVENET: return launch_one<NSPLIT, EPI_WAVENET, F16>(g, s);
   }
   return hipErrorInvalidValue;
 }
@@ -208,9 +208,9 @@ hipError_t launch_gemm1(const GemmArgs& g, int nsplit, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.nkt <= 0) return hipErrorInvalidValue;
   if (nsplit == 3) {
     if (!g.a_lo || !g.w_lo) return hipErrorInvalidValue;
-    return launch_epi<3>(g, s);
+    return launch_epi<3, false>(g, s);
   }
-  return launch_epi<1>(g, s);
+  return g.f16 ? launch_epi<1, true>(g, s) : launch_epi<1, false>(g, s);
 }
 
 }  // namespace ns2

@@ -39,7 +39,7 @@ __device__ unsigned long long g2_trace[8 * 64 * 10];
 #define STAMP(n)
 #endif
 
-template <int NSPLIT, int EPI>
+template <int NSPLIT, int EPI, bool F16>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const bf16_t* __restrict__ zero_page) {
   constexpr int NP = (NSPLIT == 3) ? 2 : 1;          // planes per operand (both inside one 128-B LDS row in exact mode)
   constexpr int BK = (NSPLIT == 3) ? 32 : 64;        // K-tile depth (logical elements)
@@ -201,10 +201,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const b
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             if constexpr (NSPLIT == 3) {
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], wf[0][ni], acc[mi][ni], 0, 0, 0);
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], wf[1][ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = mma16<F16>(af[1][mi], wf[0][ni], acc[mi][ni]);
+              acc[mi][ni] = mma16<F16>(af[0][mi], wf[1][ni], acc[mi][ni]);
             }
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], wf[0][ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = mma16<F16>(af[0][mi], wf[0][ni], acc[mi][ni]);
           }
 #ifdef G2_TRACE
         if (kc == 0) STAMP(3); else if (kc == 1) STAMP(6);
@@ -263,32 +263,32 @@ static const bf16_t* zero_page() {
   return p;
 }
 
-template <int NSPLIT, int EPI>
+template <int NSPLIT, int EPI, bool F16>
 static hipError_t launch2_one(const GemmArgs& g, hipStream_t s) {
   const int ntn = (g.N + G2_BN - 1) / G2_BN, ntm = (g.M + G2_BM - 1) / G2_BM;
   const int nz = g.nz > 0 ? g.nz : 1;
   const size_t lds = 8 * EPI_LDS_WAVE_BYTES;          // 144 KiB: 2 x 64 KiB K stages, reused as 8 x 18 KiB epilogue regions
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, F16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const bf16_t* zp = zero_page();
   if (!zp) return hipErrorOutOfMemory;
-  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI>), dim3(ntn * ntm * nz), dim3(512), lds, s, g, zp);
+  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, F16>), dim3(ntn * ntm * nz), dim3(512), lds, s, g, zp);
   return hipGetLastError();
 }
 
-template <int NSPLIT>
+template <int NSPLIT, bool F16>
 static hipError_t launch2_epi(const GemmArgs& g, hipStream_t s) {
   switch (g.epi) {
-    case EPI_F32: return launch2_one<NSPLIT, EPI_F32>(g, s);
-    case EPI_SPLIT: return launch2_one<NSPLIT, EPI_SPLIT>(g, s);
-    case EPI_QKV: return launch2_one<NSPLIT, EPI_QKV>(g, s);
-    case EPI_GEGLU: return launch2_one<NSPLIT, EPI_GEGLU>(g, s);
-    case EPI_WAVENET: return launch2_one<NSPLIT, EPI_WAVENET>(g, s);
+    case EPI_F32: return launch2_one<NSPLIT, EPI_F32, F16>(g, s);
+    case EPI_SPLIT: return launch2_one<NSPLIT, EPI_SPLIT, F16>(g, s);
+    case EPI_QKV: return launch2_one<NSPLIT, EPI_QKV, F16>(g, s);
+    case EPI_GEGLU: return launch2_one<NSPLIT, EPI_GEGLU, F16>(g, s);
+    case EPI_WAVENET: return launch2_one<NSPLIT, EPI_WAVENET, F16>(g, s);
   }
   return hipErrorInvalidValue;
 }
@@ -307,7 +307,14 @@ static int forced_kernel() {
 
 // Dispatch: the 256x256 LDS-DMA kernel for wide outputs, the 128x128 kernel when N <= 128 (half of a 256-wide tile
 // would be padding, e.g. the dim=128 model's d x d projections).  W rows are padded to 256 by the packers.
-hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs& g_in, int nsplit, hipStream_t s) {
+  GemmArgs g = g_in;
+  g.f16 = 0;
+  if (nsplit == 2) {                                  // "half" precision: one fp16 product on hi-only (dense) operands
+    if (g.a_lo || g.w_lo || g.out_lo || g.vt_lo) return hipErrorInvalidValue;
+    g.f16 = 1;
+    nsplit = 1;
+  }
   if (g.M <= 0 || g.N <= 0 || g.nkt <= 0 || g.kt_per_tap <= 0 || (g.nkt % g.kt_per_tap)) return hipErrorInvalidValue;
   if (nsplit == 3 && (!g.a_lo || !g.w_lo)) return hipErrorInvalidValue;
   // a lo plane means the interleaved layout: lo = hi + 32 (ns2_common.h)
@@ -317,7 +324,8 @@ hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s) {
   const int f = forced_kernel();
   const bool big = (f == 2) || (f != 1 && g.N > 128);
   if (!big) return launch_gemm1(g, nsplit, s);
-  return nsplit == 3 ? launch2_epi<3>(g, s) : launch2_epi<1>(g, s);
+  if (nsplit == 3) return launch2_epi<3, false>(g, s);
+  return g.f16 ? launch2_epi<1, true>(g, s) : launch2_epi<1, false>(g, s);
 }
 
 }  // namespace ns2

@@ -95,7 +95,7 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
         const int col = ocol & ~1;
         if (row < g.M && col < g.out_ncols) {
           uint32_t ph, pl;
-          split2(c_lo, c_hi, ph, pl);
+          split2f(c_lo, c_hi, ph, pl, g.f16);
           const long o = (long)row * pld(g.ldo_s, il) + pcol(col, il);
           *reinterpret_cast<uint32_t*>(g.out_hi + o) = ph;
           if (il) *reinterpret_cast<uint32_t*>(g.out_lo + o) = pl;
@@ -133,7 +133,7 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
               if (c0 >= g.N) c_lo = 0.f;             // zero the K-padding columns of the next GEMM's operand
               if (c0 + 1 >= g.N) c_hi = 0.f;
               uint32_t ph, pl;
-              split2(c_lo, c_hi, ph, pl);
+              split2f(c_lo, c_hi, ph, pl, g.f16);
               const long o = (long)row * pld(g.ldo_s, il) + pcol(c0, il);
               *reinterpret_cast<uint32_t*>(out_hi + o) = ph;
               if (il) *reinterpret_cast<uint32_t*>(out_lo + o) = pl;
@@ -149,8 +149,8 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
               if (row0 >= g.M) continue;
               const int b = row0 / g.seq_len, n0 = row0 - b * g.seq_len;
               uint32_t h01, l01, h23, l23;
-              split2(acc[mi][ni][4 * gq + 0] + bc, acc[mi][ni][4 * gq + 1] + bc, h01, l01);
-              split2(acc[mi][ni][4 * gq + 2] + bc, acc[mi][ni][4 * gq + 3] + bc, h23, l23);
+              split2f(acc[mi][ni][4 * gq + 0] + bc, acc[mi][ni][4 * gq + 1] + bc, h01, l01, g.f16);
+              split2f(acc[mi][ni][4 * gq + 2] + bc, acc[mi][ni][4 * gq + 3] + bc, h23, l23, g.f16);
               const bf16_t h[4] = {(bf16_t)(h01 & 0xffffu), (bf16_t)(h01 >> 16), (bf16_t)(h23 & 0xffffu), (bf16_t)(h23 >> 16)};
               const bf16_t l[4] = {(bf16_t)(l01 & 0xffffu), (bf16_t)(l01 >> 16), (bf16_t)(l23 & 0xffffu), (bf16_t)(l23 >> 16)};
               const bool vil = g.vt_lo != nullptr;

@@ -62,6 +62,30 @@ NS2_DEVINL void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
   lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));
 }
 
+// ---- IEEE half operands ("half" precision: ONE fp16 product per contraction, fp32 accumulate).  fp16 carries 11
+// significand bits against bf16's 8, so a single product lands at ~5e-4 end to end where bf16 needs the 3-product split
+// (tools/precision_study.py); the price is range: values are clamped to +-65504 on conversion instead of becoming inf.
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+NS2_DEVINL uint32_t cvt2h(float a, float b) {         // {half(a) | half(b) << 16}, round to nearest even, saturating
+  f32x2_t v = {fminf(fmaxf(a, -65504.f), 65504.f), fminf(fmaxf(b, -65504.f), 65504.f)};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+NS2_DEVINL float h2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+// element-format-aware pair conversion: f16 planes have no lo part
+NS2_DEVINL void split2f(float a, float b, uint32_t& hi, uint32_t& lo, int f16) {
+  if (f16) { hi = cvt2h(a, b); lo = 0u; }
+  else split2(a, b, hi, lo);
+}
+// one 32x32x16 MFMA on 16-bit operands of either format
+template <bool F16>
+NS2_DEVINL f32x16 mma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 NS2_DEVINL float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

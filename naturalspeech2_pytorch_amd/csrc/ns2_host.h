@@ -14,6 +14,7 @@ void set_error(const char* fmt, ...);
 struct PackedW {                 // bf16 split-plane weight, rows padded to 128, K contiguous
   bf16_t* hi = nullptr; bf16_t* lo = nullptr;
   int rows_p = 0, ldk = 0, N = 0, nkt = 0, kt_per_tap = 0;
+  int f16 = 0;                   // hi plane holds IEEE half instead of bf16 (precision 2, no lo plane)
 };
 
 int gemm_f32(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,

@@ -44,9 +44,12 @@ struct GemmArgs {
   int nz; long a_zs, w_zs, bias_zs, film_zs, out_zs;
   int pad_left;      // conv: zero rows in front of the sequence (-1 = causal: conv_taps-1); k=9 'same' padding = 4
   int act;           // 1 = SiLU after the bias (EPI_F32 / EPI_SPLIT)
+  int f16;           // operands and split-plane outputs are IEEE half (hi plane only) instead of bf16; set by launch_gemm
+                     // for nsplit == 2 ("half" precision: one fp16 product)
 };
 
-hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s);   // dispatches gemm.hip / gemm2.hip by shape
+hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s);   // dispatches gemm.hip / gemm2.hip by shape;
+                                                                        // nsplit: 3 bf16x3, 1 bf16, 2 fp16 single product
 void force_gemm_kernel(int k);                                          // 0 auto, 1 = 128x128, 2 = 256x256 (test hook)
 
 // flash attention forward, head dim 64, non-causal (ATT:77-155 hot path)
@@ -59,7 +62,7 @@ struct AttnArgs {
   int B, H, Nq, Nk;
   float scale;
   const unsigned char* kmask;                            // optional key-padding mask [B, Nk], 1 = attend (ATT:92-94, 136-138)
-};
+};                                                       // launch_attention nsplit: 3 bf16x3, 1 bf16, 2 fp16
 hipError_t launch_attention(const AttnArgs& a, int nsplit, hipStream_t s);
 
 // RMSNorm (NS2:727-746): out = x / max(|x|, 1e-12) * sqrt(d) [* gamma] [* g_c + b_c]  -> split planes
@@ -70,12 +73,13 @@ struct NormArgs {
   bf16_t* out_hi; bf16_t* out_lo; int ldo;
   float* out_f; int ldo_f;           // optional fp32 copy (e.g. resampler output)
   int M, d, seq_len;
+  int f16;                           // write IEEE half instead of bf16 (hi plane only)
 };
 hipError_t launch_rmsnorm(const NormArgs& a, hipStream_t s);
 
 // x (+ add) -> split planes, with optional zero padding to ldo columns
 hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, int add_rows_per_batch, int add_valid_rows,
-                        bf16_t* out_hi, bf16_t* out_lo, int ldo, int M, int d, int seq_len, hipStream_t s);
+                        bf16_t* out_hi, bf16_t* out_lo, int ldo, int M, int d, int seq_len, hipStream_t s, int f16 = 0);
 
 // LearnedSinusoidalPosEmb + Linear(d+1, dt) + SiLU (NS2:108-120, 839-843): times[B] -> out[B, ld_out] columns [0, dt)
 // wt is the Linear weight stored K-major [dim+1, dt]; feat_ws is a [B, dim+1] fp32 scratch.
@@ -96,7 +100,7 @@ hipError_t launch_mean_rows(const float* in, int B, int n, int d, float* out, hi
 hipError_t launch_bcast_rows(const float* src, float* out, int B, long row_elems, long ld_out, hipStream_t s);
 
 hipError_t launch_embedding(const int64_t* ids, const float* table, float* out, long n, int dim, long pad_id, hipStream_t s);
-hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s);
+hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s, int f16 = 0);
 hipError_t launch_transpose_into(const float* src, int R, int C, float* dst, long ld_dst, long col_off, hipStream_t s);
 
 // DDIM update (NS2:1396-1429), objective 'v'/'eps'/'x0', sigmoid/cosine/linear schedule evaluated on device
@@ -115,7 +119,7 @@ hipError_t launch_cfg_mix(const float* cond, const float* null, float* out, long
 
 // weight packing: fp32 [rows, C, T] (T taps, 1 for linear) -> split planes [rows_p, T*Cp]; row_map[r] = source row or -1
 hipError_t launch_pack_weight(const float* src, int C, int T, int Cp, const int* row_map, int rows_p, bf16_t* dst_hi,
-                              bf16_t* dst_lo, int ldk, int k_off, hipStream_t s);
+                              bf16_t* dst_lo, int ldk, int k_off, hipStream_t s, int f16 = 0);
 
 // EnCodec residual VQ encode (HFENC:364-369, 424-447)
 struct RvqArgs {

@@ -141,7 +141,7 @@ class Model(nn.Module):
         precision="exact",
     ):
         super().__init__()
-        assert precision in ("exact", "fast")
+        assert precision in ("exact", "half", "fast")
         self.dim = dim
         self.depth = depth
         self.dim_head, self.heads, self.ff_mult = dim_head, heads, ff_mult
@@ -236,7 +236,7 @@ class Model(nn.Module):
             wavenet_layers=self.wavenet_layers, wavenet_stacks=self.wavenet_stacks, dim_cond_mult=self.dim_cond_mult_base,
             condition_on_prompt=int(self.condition_on_prompt), dim_prompt=int(self.dim_prompt or 0),
             num_latents_m=self.num_latents_m, resampler_depth=self.resampler_depth,
-            precision=3 if self.precision == "exact" else 1)
+            precision={"exact": 3, "half": 2, "fast": 1}[self.precision])
         h = ctypes.c_void_p()
         check(lib.ns2_model_create(ctypes.byref(cfg), ctypes.byref(h)), "ns2_model_create")
         ns.handle = h

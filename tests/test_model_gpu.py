@@ -104,6 +104,34 @@ def test_fast_mode_is_bf16_class():
     assert 1e-4 < e < TOL_FAST, f"fast-mode rel {e}"
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "model_*.pt"))), ids=os.path.basename)
+def test_half_mode_matches_reference_golden(path):
+    """precision="half": ONE fp16 product per contraction (fp32 accumulate) must still meet the 1e-3 tolerance."""
+    fix = torch.load(path, weights_only=False)
+    m, _ = build(fix["kwargs"], fix["shapes"], fix["weight_seed"], precision="half")
+    x, t, prompt, cond = case_inputs(fix)
+    kws = dict(prompt=dev(prompt), cond=dev(cond)) if prompt is not None else {}
+    with torch.no_grad():
+        y = m(dev(x), dev(t), **kws)
+    e = rel(y, fix["outputs"]["cond_scale_1.0"])
+    print(f"half-mode rel err {os.path.basename(path)}: {e:.2e}")
+    assert 1e-6 < e < TOL_EXACT, f"half-mode rel {e}"
+
+
+def test_half_mode_headline_config_vs_oracle():
+    """the headline architecture (dim=512, depth=12, 1024 frames) in half precision against the fp32 oracle"""
+    kw = dict(dim=512, depth=12)
+    m, sd = build(kw, seed=7, precision="half")
+    x = make_input("x", (2, 1024, 512), seed=8)
+    t = make_input("times", (2,), seed=8, uniform=True)
+    with torch.no_grad():
+        y = m(dev(x), dev(t))
+        ref = O.model_forward(sd, x, t)
+    e = rel(y, ref)
+    print(f"half-mode rel err d512/L12 x 1024: {e:.2e}")
+    assert torch.isfinite(y).all() and e < TOL_EXACT, f"rel {e}"
+
+
 def test_ddim_trajectory_matches_reference_golden():
     fix = torch.load(os.path.join(GOLD, "ddim_uncond_d64.pt"), weights_only=False)
     m, _ = build(fix["kwargs"], fix["shapes"], fix["weight_seed"])

@@ -1,0 +1,134 @@
+"""CPU study (no GPU): end-to-end error of Model.forward vs the fp32 oracle when every MFMA-class contraction of the HIP
+path (token-major Linear / conv / attention products) is evaluated with a given operand split.  Answers: how many MFMA
+products per contraction does the 1e-3 tolerance really need?  Uses the oracle's own forward with F.linear / F.conv1d /
+einsum replaced by emulations; conditioning projections ([B, Tc] rows) stay fp32 as in the HIP path.
+
+    python tools/precision_study.py [--dim 128 --depth 6 --n 256 --batch 2]
+"""
+import argparse, os, sys
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ns2_oracle as O
+from naturalspeech2_pytorch_amd import Model
+
+BF, FH = torch.bfloat16, torch.float16
+
+def split(x, fmt, n):
+    """x -> list of n pieces in `fmt` (as float64) whose sum approximates x"""
+    out, r = [], x.double()
+    for _ in range(n):
+        p = r.float().to(fmt).double()
+        out.append(p); r = r - p
+    return out
+
+def fp8_block(x, axis=-1):
+    """MX-style e4m3 with one power-of-two scale per 32 elements along `axis` (as float64)"""
+    x = x.double().movedim(axis, -1)
+    K = x.shape[-1]; pad = (-K) % 32
+    xp = F.pad(x, (0, pad)).reshape(*x.shape[:-1], -1, 32)
+    amax = xp.abs().amax(-1, keepdim=True).clamp_min(1e-300)
+    scale = torch.exp2(torch.ceil(torch.log2(amax)) - 8)
+    q = (xp / scale).float().to(torch.float8_e4m3fn).double() * scale
+    return q.reshape(*x.shape[:-1], -1)[..., :K].movedim(-1, axis)
+
+def fp8_row(x, axis=-1, extra=0):
+    """e4m3 with ONE power-of-two scale per row (the whole contraction axis); extra = additional binades of head-room"""
+    x = x.double().movedim(axis, -1)
+    amax = x.abs().amax(-1, keepdim=True).clamp_min(1e-300)
+    scale = torch.exp2(torch.ceil(torch.log2(amax)) - 8 + extra)
+    q = (x / scale).float().to(torch.float8_e4m3fn).double() * scale
+    return q.movedim(-1, axis)
+
+class Scheme:
+    def __init__(self, name, units, fn, attn_fn=None):
+        self.name, self.units, self.fn, self.attn_fn = name, units, fn, attn_fn or fn   # attn_fn: the two attention products
+
+def mk(fmt, terms):
+    """terms: list of (a_piece_index, w_piece_index)"""
+    na = 1 + max(t[0] for t in terms); nw = 1 + max(t[1] for t in terms)
+    def f(a, w, contract):
+        ap, wp = split(a, fmt, na), split(w, fmt, nw)
+        return sum(contract(ap[i], wp[j]) for i, j in terms)
+    return f
+
+def fp8_cross_row():
+    def f(a, w, contract):
+        ah, al = split(a, BF, 2); wh, wl = split(w, BF, 2)
+        return contract(ah, wh) + contract(fp8_row(ah), fp8_row(wl)) + contract(fp8_row(al), fp8_row(wh))
+    return f
+
+def fp8_cross(which):
+    def f(a, w, contract):
+        ah, al = split(a, BF, 2); wh, wl = split(w, BF, 2)
+        y = contract(ah, wh)
+        if "aw" in which: y = y + contract(fp8_block(ah), fp8_block(wl))     # a_hi * w_lo on the fp8 MFMA
+        else: y = y + contract(ah, wl)
+        if "wa" in which: y = y + contract(fp8_block(al), fp8_block(wh))     # a_lo * w_hi on the fp8 MFMA
+        else: y = y + contract(al, wh)
+        return y
+    return f
+
+SCHEMES = [
+    Scheme("bf16 x3  hi.hi+hi.lo+lo.hi (current exact)", 3.0, mk(BF, [(0, 0), (0, 1), (1, 0)])),
+    Scheme("bf16 x1  hi.hi (current fast)", 1.0, mk(BF, [(0, 0)])),
+    Scheme("bf16 x2  hi.hi+lo.hi (weights hi only)", 2.0, mk(BF, [(0, 0), (1, 0)])),
+    Scheme("bf16 x2  hi.hi+hi.lo (activations hi only)", 2.0, mk(BF, [(0, 0), (0, 1)])),
+    Scheme("fp16 x1  hi.hi", 1.0, mk(FH, [(0, 0)])),
+    Scheme("fp16 x2  hi.hi+lo.hi (weights hi only)", 2.0, mk(FH, [(0, 0), (1, 0)])),
+    Scheme("fp16 x2  hi.hi+hi.lo (activations hi only)", 2.0, mk(FH, [(0, 0), (0, 1)])),
+    Scheme("fp16 x3", 3.0, mk(FH, [(0, 0), (0, 1), (1, 0)])),
+    Scheme("fp16 x1 GEMMs, fp16 x3 attention products", 1.2, mk(FH, [(0, 0)]), mk(FH, [(0, 0), (0, 1), (1, 0)])),
+    Scheme("fp16 x3 GEMMs, fp16 x1 attention products", 2.8, mk(FH, [(0, 0), (0, 1), (1, 0)]), mk(FH, [(0, 0)])),
+    Scheme("bf16 hi.hi + both cross terms on fp8(e4m3, MX32)", 2.0, fp8_cross("aw wa")),
+    Scheme("bf16 hi.hi + both cross terms on fp8, one scale per row", 2.0, fp8_cross_row()),
+    Scheme("bf16 hi.hi + lo.hi bf16 + hi.lo on fp8", 2.5, fp8_cross("aw")),
+    Scheme("bf16 hi.hi + hi.lo bf16 + lo.hi on fp8", 2.5, fp8_cross("wa")),
+]
+
+def run(sd, x, t, scheme, big_rows):
+    lin0, conv0, ein0 = F.linear, F.conv1d, torch.einsum
+    def lin(inp, w, b=None):
+        if inp.numel() // inp.shape[-1] < big_rows: return lin0(inp, w, b)
+        y = scheme.fn(inp, w, lambda a, ww: a @ ww.t())
+        return (y + (b.double() if b is not None else 0)).float()
+    def conv(inp, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+        if inp.shape[-1] * inp.shape[0] < big_rows: return conv0(inp, w, b, stride, padding, dilation, groups)
+        y = scheme.fn(inp, w, lambda a, ww: conv0(a, ww, None, stride, padding, dilation, groups))
+        return (y + (b.double()[None, :, None] if b is not None else 0)).float()
+    def ein(eq, a, bb):
+        y = scheme.attn_fn(a, bb, lambda p, q: ein0(eq, p, q))
+        return y.float()
+    F.linear, F.conv1d, torch.einsum = lin, conv, ein
+    O.F.linear, O.F.conv1d, O.torch.einsum = lin, conv, ein
+    try:
+        with torch.no_grad(): return O.model_forward(sd, x, t)
+    finally:
+        F.linear, F.conv1d, torch.einsum = lin0, conv0, ein0
+        O.F.linear, O.F.conv1d, O.torch.einsum = lin0, conv0, ein0
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dim", type=int, default=128); ap.add_argument("--depth", type=int, default=6)
+    ap.add_argument("--n", type=int, default=256); ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--seeds", type=int, default=2)
+    ap.add_argument("--only", default="", help="comma-separated substrings of scheme names to run")
+    a = ap.parse_args()
+    print(f"Model(dim={a.dim}, depth={a.depth}), batch {a.batch} x {a.n} frames, random-init weights; rel = |y - y_fp32| / |y_fp32| (Frobenius)")
+    rows = []
+    for sc in SCHEMES:
+        if a.only and not any(k in sc.name for k in a.only.split(",")): continue
+        errs = []
+        for seed in range(a.seeds):
+            torch.manual_seed(seed)
+            m = Model(dim=a.dim, depth=a.depth)
+            sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+            x = torch.randn(a.batch, a.n, a.dim); t = torch.rand(a.batch)
+            with torch.no_grad(): ref = O.model_forward(sd, x, t).double()
+            y = run(sd, x, t, sc, big_rows=a.batch * 8).double()
+            errs.append(((y - ref).norm() / ref.norm()).item())
+        rows.append((sc.name, sc.units, max(errs)))
+        print(f"  {sc.name:52s} MFMA units {sc.units:3.1f}   rel err (max over {a.seeds} seeds) {max(errs):.2e}", flush=True)
+
+if __name__ == "__main__":
+    main()
