@@ -41,8 +41,9 @@ def fp8_row(x, axis=-1, extra=0):
     return q.movedim(-1, axis)
 
 class Scheme:
-    def __init__(self, name, units, fn, attn_fn=None):
+    def __init__(self, name, units, fn, attn_fn=None, resid_fn=None):
         self.name, self.units, self.fn, self.attn_fn = name, units, fn, attn_fn or fn   # attn_fn: the two attention products
+        self.resid_fn = resid_fn or fn          # Linears whose output goes to the residual stream (out features == dim)
 
 def mk(fmt, terms):
     """terms: list of (a_piece_index, w_piece_index)"""
@@ -80,17 +81,21 @@ SCHEMES = [
     Scheme("fp16 x3", 3.0, mk(FH, [(0, 0), (0, 1), (1, 0)])),
     Scheme("fp16 x1 GEMMs, fp16 x3 attention products", 1.2, mk(FH, [(0, 0)]), mk(FH, [(0, 0), (0, 1), (1, 0)])),
     Scheme("fp16 x3 GEMMs, fp16 x1 attention products", 2.8, mk(FH, [(0, 0), (0, 1), (1, 0)]), mk(FH, [(0, 0)])),
+    Scheme("fp16 x1, but x3 for Linears writing the residual stream", 1.2, mk(FH, [(0, 0)]), None, mk(FH, [(0, 0), (0, 1), (1, 0)])),
     Scheme("bf16 hi.hi + both cross terms on fp8(e4m3, MX32)", 2.0, fp8_cross("aw wa")),
     Scheme("bf16 hi.hi + both cross terms on fp8, one scale per row", 2.0, fp8_cross_row()),
     Scheme("bf16 hi.hi + lo.hi bf16 + hi.lo on fp8", 2.5, fp8_cross("aw")),
     Scheme("bf16 hi.hi + hi.lo bf16 + lo.hi on fp8", 2.5, fp8_cross("wa")),
 ]
 
+DIM = 0
+
 def run(sd, x, t, scheme, big_rows):
     lin0, conv0, ein0 = F.linear, F.conv1d, torch.einsum
     def lin(inp, w, b=None):
         if inp.numel() // inp.shape[-1] < big_rows: return lin0(inp, w, b)
-        y = scheme.fn(inp, w, lambda a, ww: a @ ww.t())
+        f = scheme.resid_fn if (w.shape[0] == DIM and w.shape[1] != DIM) else scheme.fn
+        y = f(inp, w, lambda a, ww: a @ ww.t())
         return (y + (b.double() if b is not None else 0)).float()
     def conv(inp, w, b=None, stride=1, padding=0, dilation=1, groups=1):
         if inp.shape[-1] * inp.shape[0] < big_rows: return conv0(inp, w, b, stride, padding, dilation, groups)
@@ -114,6 +119,8 @@ def main():
     ap.add_argument("--seeds", type=int, default=2)
     ap.add_argument("--only", default="", help="comma-separated substrings of scheme names to run")
     a = ap.parse_args()
+    global DIM
+    DIM = a.dim
     print(f"Model(dim={a.dim}, depth={a.depth}), batch {a.batch} x {a.n} frames, random-init weights; rel = |y - y_fp32| / |y_fp32| (Frobenius)")
     rows = []
     for sc in SCHEMES:
