@@ -11,13 +11,17 @@
  *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls are stream-ordered and never
  *     synchronise the device, except ns2_model_finalize / ns2_weight_pack which are one-time set-up calls.
  *   - return value 0 = ok; otherwise a negative code, message via ns2_last_error() (thread-local).
- *   - activations travel between kernels as bf16 "split planes": hi = bf16(x), lo = bf16(x - hi).  precision
- *     3 = hi*hi+hi*lo+lo*hi on the bf16 MFMA (fp32-class, matches the fp32 reference to <1e-3), 1 = hi only.
+ *   - activations travel between kernels as 16-bit "split planes": hi = bf16(x), lo = bf16(x - hi).  precision
+ *     3 = hi*hi+hi*lo+lo*hi on the bf16 MFMA (fp32-class, matches the fp32 reference to 1e-5), 1 = bf16 hi only,
+ *     2 = ONE IEEE-half plane (x_lo == NULL, values saturate at +-65504) multiplied on the f16 MFMA, fp32 accumulate.
+ *   - the library keeps no mutable host state and never allocates on a launch path: scratch is caller-owned
+ *     (ns2_*_workspace_bytes), constants live in per-device __device__ storage, so one host thread per device (or one
+ *     process per device) may drive several devices concurrently, also under stream capture.
  *   - layout of a split-plane matrix (x_hi, x_lo, ld): `ld` is the LOGICAL column count, a multiple of 32.
  *     x_lo != NULL: ONE bf16 buffer [rows, 2*ld]; every 32 logical columns occupy a 128-byte line [hi(32) | lo(32)],
  *       i.e. element (r, c) has hi at r*2*ld + ((c & ~31) << 1) + (c & 31) and lo 32 elements further; the caller
  *       passes x_lo == x_hi + 32 (anything else is NS2_ERR_HIP / invalid value).  precision 3 needs this form.
- *     x_lo == NULL: the dense [rows, ld] hi plane alone (precision 1 only).
+ *     x_lo == NULL: the dense [rows, ld] hi plane alone (precision 1: bf16, precision 2: IEEE half).
  *     Transposed value planes (vt_hi, vt_lo, vt_ld) use the same rule along the key axis.
  */
 #ifndef NS2HIP_H
@@ -41,19 +45,21 @@ int ns2_debug_force_gemm(int kernel);
 /* ------------------------------------------------------------------ packed weights (library-owned) */
 typedef struct ns2_weight ns2_weight;
 /* nn.Linear weight [rows, cols] (taps = 1) or Conv1d weight [rows, cols, taps] (NS2:583-595) -> K-contiguous bf16
- * split planes (interleaved layout, usable at both precisions), rows padded to 256, each tap's columns padded to 32.  geglu != 0 packs the rows of
+ * split planes (precision 1 or 3: interleaved layout, usable at both; precision 2: dense IEEE-half rows, usable at 2 only), rows padded to 256, each tap's columns padded to 32.  geglu != 0 packs the rows of
  * FeedForward's first Linear (NS2:1021) so that GEGLU (NS2:1004-1007) fuses into the GEMM epilogue.
  * extra1x1 (may be null): a [rows, cols, 1] weight appended as one more, unshifted tap (WavenetResBlock.res_conv). */
-int ns2_weight_pack(const float* w, int rows, int cols, int taps, int geglu, const float* extra1x1, ns2_weight** out,
-                    void* stream);
+int ns2_weight_pack(const float* w, int rows, int cols, int taps, int geglu, const float* extra1x1, int precision,
+                    ns2_weight** out, void* stream);
 void ns2_weight_free(ns2_weight* w);
 
 /* ------------------------------------------------------------------ op-level entry points */
 /* fp32 [M, d] (+ optional per-utterance addend) -> split planes [M, ldo] (zero padded) */
-int ns2_split_f32(const float* x, int ldx, int M, int d, uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream);
+int ns2_split_f32(const float* x, int ldx, int M, int d, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision,
+                  void* stream);
 
 /* split planes -> fp32 (hi + lo); lo may be null (dense hi-only layout) */
-int ns2_join_f32(const uint16_t* hi, const uint16_t* lo, int ld, float* out, int ldo, int64_t M, int d, void* stream);
+int ns2_join_f32(const uint16_t* hi, const uint16_t* lo, int ld, float* out, int ldo, int64_t M, int d, int precision,
+                 void* stream);
 
 /* nn.Linear / CausalConv1d as one GEMM (NS2:1051-1069, 1021-1024, 583-595).
  * conv_taps = 0 for a Linear, k for a Conv1d(kernel k) with `dilation`; seq_len = tokens per utterance (rows never read
@@ -92,14 +98,19 @@ int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col
 
 /* RMSNorm.forward (NS2:727-746).  gamma may be null; cond (may be null) holds [gamma_c | beta_c] per batch row */
 int ns2_rmsnorm(const float* x, int ldx, int M, int d, int seq_len, const float* gamma, const float* cond, int cond_ld,
-                uint16_t* out_hi, uint16_t* out_lo, int ldo, float* out_f32, int ldo_f, void* stream);
+                uint16_t* out_hi, uint16_t* out_lo, int ldo, float* out_f32, int ldo_f, int precision, void* stream);
 
-/* out[b, j] = act(in[b, :] . wt[:, j] + bias[j]); wt K-major [K, J]; act: 0 none, 1 SiLU (conditioning projections) */
+/* out[b, j] = act(in[b, :] . wt[:, j] + bias[j]); wt K-major [K, J]; act: 0 none, 1 SiLU (conditioning projections:
+ * to_time_cond / to_gamma_beta / to_prompt_cond Linears on [batch, dim_cond] rows, NS2:623, 744, 841, 860).
+ * workspace (may be null: slower single pass) = ns2_skinny_linear_workspace_bytes(B, K, J) bytes of caller-owned scratch
+ * for the deterministic split-K partial sums */
+int64_t ns2_skinny_linear_workspace_bytes(int B, int K, int J);
 int ns2_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out, int B, int K,
-                      int J, int act, void* stream);
-/* to_time_cond (NS2:108-120, 839-843); wt = Linear weight K-major [dim+1, dt]; feat_ws [B, dim+1] scratch */
+                      int J, int act, void* workspace, int64_t workspace_bytes, void* stream);
+/* to_time_cond (NS2:108-120, 839-843); wt = Linear weight K-major [dim+1, dt]; feat_ws [B, dim+1] scratch;
+ * workspace as for ns2_skinny_linear(B, dim + 1, dt) */
 int ns2_time_embed(const float* times, const float* freqs, const float* wt, const float* bias, float* feat_ws, float* out,
-                   int ld_out, int B, int dim, int dt, void* stream);
+                   int ld_out, int B, int dim, int dt, void* workspace, int64_t workspace_bytes, void* stream);
 int ns2_transpose_f32(const float* in, int batch, int R, int C, float* out, void* stream);
 /* nn.Embedding gather, ids < 0 -> pad_id (PhonemeEncoder NS2:281-284) */
 int ns2_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int dim, int64_t pad_id, void* stream);

@@ -1,0 +1,45 @@
+"""Cache holder for library-packed weights (ctypes handles are not copyable / picklable).
+
+`copy.deepcopy(module)` (ema_pytorch, NS2:1793-1798) and `torch.save(module)` must keep working after the first forward, so
+every module keeps its packed weights inside a `PackedCache`: a deep copy or an unpickled object starts with an EMPTY cache
+and re-packs lazily from its own parameters.  Staleness is detected by CONTENT (tensors_fingerprint), not only by
+`(data_ptr, _version)`: writes through `.data` do not bump the version counter.
+"""
+import torch
+
+
+def tensors_fingerprint(tensors):
+    """per-tensor (L1, L2) norms, reduced on the device and read back once"""
+    ts = [t.detach() for t in tensors if t.numel() > 0]
+    if not ts:
+        return ()
+    fl = [t if t.is_floating_point() else t.double() for t in ts]
+    n1 = torch.stack([x.double() for x in torch._foreach_norm(fl, 1)])
+    n2 = torch.stack([x.double() for x in torch._foreach_norm(fl, 2)])
+    return tuple(torch.cat((n1, n2)).cpu().tolist())
+
+
+class PackedCache:
+    def __init__(self):
+        self.value, self.sig = None, None
+
+    def __deepcopy__(self, memo):
+        return PackedCache()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
+    def clear(self):
+        self.value, self.sig = None, None
+
+    def get(self, tensors, build, extra=()):
+        """`build()` is re-run when any of `tensors` moved, was resized, was written (version counter) or changed content"""
+        tensors = list(tensors)
+        sig = (tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors), tensors_fingerprint(tensors), tuple(extra))
+        if self.value is None or self.sig != sig:
+            self.value = build()
+            self.sig = sig
+        return self.value

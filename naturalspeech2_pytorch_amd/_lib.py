@@ -31,10 +31,10 @@ SIGNATURES = {
     "ns2_last_error": (c_char_p, []),
     "ns2_version": (I, []),
     "ns2_debug_force_gemm": (I, [I]),
-    "ns2_weight_pack": (I, [P, I, I, I, I, P, POINTER(c_void_p), P]),
+    "ns2_weight_pack": (I, [P, I, I, I, I, P, I, POINTER(c_void_p), P]),
     "ns2_weight_free": (None, [P]),
-    "ns2_split_f32": (I, [P, I, I, I, P, P, I, P]),
-    "ns2_join_f32": (I, [P, P, I, P, I, L, I, P]),
+    "ns2_split_f32": (I, [P, I, I, I, P, P, I, I, P]),
+    "ns2_join_f32": (I, [P, P, I, P, I, L, I, I, P]),
     "ns2_linear_f32": (I, [P, P, P, I, I, I, I, I, P, P, I, P, I, I, I, I, P]),
     "ns2_linear_split": (I, [P, P, P, I, I, I, I, I, P, P, P, I, I, I, I, P]),
     "ns2_linear_geglu": (I, [P, P, P, I, I, P, P, P, I, I, P]),
@@ -42,9 +42,10 @@ SIGNATURES = {
     "ns2_linear_qkv": (I, [P, P, P, I, I, I, I, P, P, I, P, P, I, I, P]),
     "ns2_wavenet_block": (I, [P, P, P, I, I, I, I, P, P, P, I, P, P, I, I, P]),
     "ns2_attention": (I, [P, P, I, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, F, P, I, P]),
-    "ns2_rmsnorm": (I, [P, I, I, I, I, P, P, I, P, P, I, P, I, P]),
-    "ns2_skinny_linear": (I, [P, I, P, P, P, I, I, I, I, I, P]),
-    "ns2_time_embed": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "ns2_rmsnorm": (I, [P, I, I, I, I, P, P, I, P, P, I, P, I, I, P]),
+    "ns2_skinny_linear_workspace_bytes": (L, [I, I, I]),
+    "ns2_skinny_linear": (I, [P, I, P, P, P, I, I, I, I, I, P, L, P]),
+    "ns2_time_embed": (I, [P, P, P, P, P, P, I, I, I, I, P, L, P]),
     "ns2_transpose_f32": (I, [P, I, I, I, P, P]),
     "ns2_embedding": (I, [P, P, P, L, I, L, P]),
     "ns2_ddim_step": (I, [P, P, P, P, P, I, L, I, I, F, P]),

@@ -1,17 +1,24 @@
 """RVQ side of the codec boundary (`EncodecWrapper`, SURVEY §8b "Codec surface") with the residual-VQ encode and
 decode running in the HIP kernels of csrc/rvq.hip.
 
-The SEANet conv/LSTM encoder and decoder of EnCodec are out of scope (they stay on PyTorch-ROCm /
-MIOpen); they are injected as callables so that `codec(x, return_encoded=True)`, `codec.decode(emb)` and the
-attributes `NaturalSpeech2.__init__` reads (`target_sample_hz`, `seq_len_multiple_of`, `codebook_dim`;
-NS2:1213-1214, 1244) keep working.  With `encoder=None` the wrapper accepts latents [b, n, 128] directly.
+Surface kept for `NaturalSpeech2` (reference call sites in brackets):
+    codec.target_sample_hz, .seq_len_multiple_of [NS2:1213-1214], .codebook_dim [NS2:1244], .eval() [NS2:1444, 1610]
+    codec(x, return_encoded=True, curtail_from_left=...) -> (emb [b,n,128], codes [b,n,Q] int64, None)   [NS2:1445, 1611]
+    codec.decode(emb [b,n,128]) -> waveform [b,1,T]                                                        [NS2:1496-1499]
+    codec.rq(x_start, codes) -> (quantized, ce_loss)                                                       [NS2:1682]
+
+The SEANet conv/LSTM encoder and decoder of EnCodec are injected as callables (`encoder`, `decoder`); `from_hf` wires the
+ones of a HF `transformers.EncodecModel` (the in-container stand-in for the un-vendored `encodec` package) and
+copies its codebooks.  With `encoder=None` the wrapper accepts latents [b, n, 128] directly.
 """
 from typing import Callable, Optional
 
 import torch
 from torch import nn
+import torch.nn.functional as F
 
 from . import ops
+from ._cache import PackedCache
 
 
 class HipRVQ(nn.Module):
@@ -22,15 +29,10 @@ class HipRVQ(nn.Module):
         assert codebooks.ndim == 3 and codebooks.shape[-1] == 128 and codebooks.shape[1] % 64 == 0
         self.register_buffer("codebooks", codebooks.float().contiguous())
         self.tie_eps = tie_eps
-        self._norm = None
-        self._norm_sig = None
+        self._norm = PackedCache()
 
     def _cb_norm(self):
-        sig = (self.codebooks.data_ptr(), self.codebooks._version)
-        if self._norm is None or self._norm_sig != sig:
-            self._norm = ops.rvq_prepare(self.codebooks)
-            self._norm_sig = sig
-        return self._norm
+        return self._norm.get([self.codebooks], lambda: ops.rvq_prepare(self.codebooks))
 
     @torch.no_grad()
     def encode(self, latents: torch.Tensor):
@@ -46,6 +48,36 @@ class HipRVQ(nn.Module):
         return ops.rvq_decode(codes.reshape(b * n, q).contiguous(), self.codebooks).reshape(b, n, -1)
 
 
+class ResidualVQCrossEntropy(nn.Module):
+    """`codec.rq(x, indices) -> (quantized_out, ce_loss)`: the training-time cross-entropy of the diffusion model's predicted
+    x_start against the codec's own code indices (NS2:1670-1684, off by default: rvq_cross_entropy_loss_weight = 0).
+
+    PARITY UNPINNED: upstream this is `vector_quantize_pytorch.ResidualVQ.forward(x, indices=...)` (setup.py pins only
+    `>=1.4.1`, no lock file; not vendored, not installed here).  Restated from its published algorithm: per quantizer the
+    logits are the NEGATIVE EUCLIDEAN distances (with the square root) of the running residual to every code, the loss is
+    `F.cross_entropy(logits, indices[..., q])`, the residual is reduced by the nearest code (detached), and the layer losses
+    are summed.  Differentiable in `x` (autograd composite: the term only exists in training)."""
+
+    def __init__(self, owner: HipRVQ):
+        super().__init__()
+        self._owner = [owner]              # not registered: the codebooks stay owned (and moved) by the HipRVQ
+
+    def forward(self, x, indices):
+        cb = self._owner[0].codebooks.to(x.dtype)
+        assert indices.shape[:-1] == x.shape[:-1] and indices.shape[-1] == cb.shape[0]
+        assert not torch.any(indices == -1), "some of the residual vq indices were dropped out"
+        residual, out, ce = x, torch.zeros_like(x), 0.
+        for q in range(cb.shape[0]):
+            e = cb[q]
+            d2 = residual.pow(2).sum(-1, keepdim=True) - 2 * residual @ e.t() + e.pow(2).sum(-1)
+            logits = -d2.clamp(min=0).sqrt()                                     # [b, n, C]
+            ce = ce + F.cross_entropy(logits.transpose(1, 2), indices[..., q], ignore_index=-1)
+            quantized = F.embedding(logits.argmax(dim=-1), e)
+            residual = residual - quantized.detach()
+            out = out + quantized
+        return out, ce
+
+
 class EncodecWrapperHIP(nn.Module):
     target_sample_hz = 24000
     seq_len_multiple_of = 320          # strides 2*4*5*8
@@ -54,7 +86,16 @@ class EncodecWrapperHIP(nn.Module):
     def __init__(self, codebooks: torch.Tensor, encoder: Optional[Callable] = None, decoder: Optional[Callable] = None):
         super().__init__()
         self.rvq = HipRVQ(codebooks)
+        self.rq = ResidualVQCrossEntropy(self.rvq)
         self.encoder, self.decoder = encoder, decoder
+
+    @classmethod
+    def from_hf(cls, hf_model, num_quantizers: int = 8):
+        """wire a `transformers.EncodecModel`'s SEANet encoder / decoder and its first `num_quantizers` codebooks (6 kbps at
+        24 kHz = 8, what audiolm's EncodecWrapper uses)"""
+        layers = list(hf_model.quantizer.layers)[:num_quantizers]
+        cbs = torch.stack([l.codebook.embed.detach().float() for l in layers])
+        return cls(cbs, encoder=hf_model.encoder, decoder=hf_model.decoder)
 
     @property
     def num_quantizers(self):

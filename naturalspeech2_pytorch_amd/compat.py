@@ -1,0 +1,41 @@
+"""Drop-in at the reference's OWN boundary: a subclass of the reference's `Model` class whose inference forward runs in
+libns2hip, so that the unmodified reference `NaturalSpeech2` / `Trainer` can hold it:
+
+    import naturalspeech2_pytorch as ref                       # the upstream package
+    from naturalspeech2_pytorch_amd.compat import hip_backed_model_class
+    HipBackedModel = hip_backed_model_class(ref.Model)         # subclass of ref.Model: passes `model: Model` (beartype, NS2:1165)
+    model = HipBackedModel(dim=128, depth=6).cuda()            # same constructor keywords (NS2:814-831) + precision=
+    diffusion = ref.NaturalSpeech2(model=model, codec=codec, timesteps=1000)
+    audio = diffusion.sample(length=1024)                      # NS2:1410 -> model.forward_with_cond_scale -> HIP
+    loss = diffusion(raw_audio); loss.backward()               # NS2:1635 -> ref.Model.forward (autograd stays upstream's)
+
+The subclass owns the reference's parameters (constructed by the reference's own `__init__`, hence identical
+initialisation and state_dict), and `HipDenoiserMixin` hands them to the library by the same key names
+(SURVEY §8b state_dict contract).  Calls that need autograd, or per-utterance stochastic conditioning dropout, go to the
+reference's own `forward` — the composite of `autograd_path.py` is not involved here.
+"""
+import inspect
+
+from .model import HipDenoiserMixin, _CFG_KEYS
+
+
+def hip_backed_model_class(reference_model_cls):
+    """returns `HipBackedModel(reference_model_cls)`; the reference class is passed in so that this package never imports
+    (or depends on) the upstream package itself"""
+    sig = inspect.signature(reference_model_cls.__init__)
+    defaults = {k: v.default for k, v in sig.parameters.items() if v.default is not inspect.Parameter.empty}
+
+    class HipBackedModel(HipDenoiserMixin, reference_model_cls):
+        def __init__(self, dim, *args, precision="exact", **kwargs):
+            reference_model_cls.__init__(self, dim, *args, **kwargs)
+            bound = sig.bind(self, dim, *args, **kwargs)
+            cfg = dict(defaults)
+            cfg.update({k: v for k, v in bound.arguments.items() if k != "self"})
+            self._hip_init({k: cfg[k] for k in _CFG_KEYS}, precision)
+
+        def _forward_autograd(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None):
+            return reference_model_cls.forward(self, x, times, prompt=prompt, prompt_mask=prompt_mask, cond=cond,
+                                               cond_drop_prob=cond_drop_prob)
+
+    HipBackedModel.__qualname__ = HipBackedModel.__name__ = "HipBackedModel"
+    return HipBackedModel

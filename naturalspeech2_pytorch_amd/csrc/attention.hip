@@ -255,12 +255,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
 template <int NSPLIT, bool F16>
 static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
   const size_t lds = 2 * 2 * (NSPLIT == 3 ? 2 : 1) * AT_PLANE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<NSPLIT, F16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static DynLdsAttr attr;
+  {
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attn_kernel<NSPLIT, F16>), (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   dim3 grid(((a.Nq + 127) / 128) * a.H * a.B);
   hipLaunchKernelGGL((attn_kernel<NSPLIT, F16>), grid, dim3(256), lds, s, a);

@@ -39,23 +39,23 @@ using namespace ns2;
       return NS2_ERR_ARG;            \
     }                                \
   } while (0)
-static inline int prec_ok(int p) { return p == 1 || p == 3; }
+static inline int prec_ok(int p) { return p >= 1 && p <= 3; }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 102; }   // 102: interleaved [hi32|lo32] split-plane layout
+extern "C" int ns2_version(void) { return 103; }   // 103: precision 2 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 2, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
   force_gemm_kernel(kernel);
   return NS2_OK;
 }
 
-extern "C" int ns2_weight_pack(const float* w, int rows, int cols, int taps, int geglu, const float* extra1x1, ns2_weight** out,
-                               void* stream) {
-  ARGCHK(w && out && rows > 0 && cols > 0 && taps >= 1, "ns2_weight_pack: bad arguments");
+extern "C" int ns2_weight_pack(const float* w, int rows, int cols, int taps, int geglu, const float* extra1x1, int precision,
+                               ns2_weight** out, void* stream) {
+  ARGCHK(w && out && rows > 0 && cols > 0 && taps >= 1 && prec_ok(precision), "ns2_weight_pack: bad arguments");
   ARGCHK(!(geglu && (taps != 1 || extra1x1 || (rows & 1))), "ns2_weight_pack: geglu needs taps=1, no extra, even rows");
   ns2_weight* h = new ns2_weight();
   h->taps = taps; h->geglu = geglu; h->has_extra = extra1x1 != nullptr; h->cols_p = (cols + 31) / 32 * 32;
-  int r = pack_weight_public(w, rows, cols, taps, geglu, extra1x1, &h->w, &h->owned, (hipStream_t)stream);
+  int r = pack_weight_public(w, rows, cols, taps, geglu, extra1x1, precision == 2, &h->w, &h->owned, (hipStream_t)stream);
   if (r != NS2_OK) { ns2_weight_free(h); return r; }
   *out = h;
   return NS2_OK;
@@ -66,14 +66,21 @@ extern "C" void ns2_weight_free(ns2_weight* w) {
   delete w;
 }
 
-extern "C" int ns2_split_f32(const float* x, int ldx, int M, int d, uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream) {
-  ARGCHK(x && out_hi, "ns2_split_f32: null pointer");
-  HIPRET(launch_split(x, ldx, nullptr, 0, 0, 0, out_hi, out_lo, ldo, M, d, 0, (hipStream_t)stream));
+// the weight's element format must be the one the requested precision multiplies in (fp16 for 2, bf16 planes for 1 / 3)
+#define WFMT(w, precision, who) ARGCHK(((precision) == 2) == ((w)->w.f16 != 0), who ": weight was packed for a different precision")
+
+extern "C" int ns2_split_f32(const float* x, int ldx, int M, int d, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision,
+                             void* stream) {
+  ARGCHK(x && out_hi && prec_ok(precision), "ns2_split_f32: bad arguments");
+  ARGCHK(precision != 2 || !out_lo, "ns2_split_f32: precision 2 (fp16) has no lo plane");
+  HIPRET(launch_split(x, ldx, nullptr, 0, 0, 0, out_hi, out_lo, ldo, M, d, 0, (hipStream_t)stream, precision == 2));
   return NS2_OK;
 }
-extern "C" int ns2_join_f32(const uint16_t* hi, const uint16_t* lo, int ld, float* out, int ldo, int64_t M, int d, void* stream) {
-  ARGCHK(hi && out, "ns2_join_f32: null pointer");
-  HIPRET(launch_join(hi, lo, ld, out, ldo, (long)M, d, (hipStream_t)stream));
+extern "C" int ns2_join_f32(const uint16_t* hi, const uint16_t* lo, int ld, float* out, int ldo, int64_t M, int d, int precision,
+                            void* stream) {
+  ARGCHK(hi && out && prec_ok(precision), "ns2_join_f32: bad arguments");
+  ARGCHK(precision != 2 || !lo, "ns2_join_f32: precision 2 (fp16) has no lo plane");
+  HIPRET(launch_join(hi, lo, ld, out, ldo, (long)M, d, (hipStream_t)stream, precision == 2));
   return NS2_OK;
 }
 
@@ -81,6 +88,7 @@ extern "C" int ns2_linear_f32(const ns2_weight* w, const uint16_t* a_hi, const u
                               int dilation, int seq_len, const float* bias, const float* resid, int ldr, float* out, int ldo,
                               int pad_left, int act, int precision, void* stream) {
   ARGCHK(w && a_hi && out && prec_ok(precision), "ns2_linear_f32: bad arguments");
+  WFMT(w, precision, "ns2_linear_f32");
   ARGCHK(!w->geglu && !w->has_extra && (conv_taps == 0 ? w->taps == 1 : w->taps == conv_taps), "ns2_linear_f32: weight packing does not match");
   ARGCHK(lda >= w->cols_p, "ns2_linear_f32: lda smaller than the padded K");
   ARGCHK(pad_left >= -1 && pad_left < (conv_taps > 0 ? conv_taps : 1) && (act == 0 || act == 1), "ns2_linear_f32: bad pad_left / act");
@@ -91,6 +99,7 @@ extern "C" int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const
                                 int dilation, int seq_len, const float* bias, uint16_t* out_hi, uint16_t* out_lo, int ldo,
                                 int pad_left, int act, int precision, void* stream) {
   ARGCHK(w && a_hi && out_hi && prec_ok(precision), "ns2_linear_split: bad arguments");
+  WFMT(w, precision, "ns2_linear_split");
   ARGCHK(!w->geglu && !w->has_extra && (conv_taps == 0 ? w->taps == 1 : w->taps == conv_taps), "ns2_linear_split: weight packing does not match");
   ARGCHK(lda >= w->cols_p && (ldo & 1) == 0, "ns2_linear_split: bad leading dimensions");
   ARGCHK(pad_left >= -1 && pad_left < (conv_taps > 0 ? conv_taps : 1) && (act == 0 || act == 1), "ns2_linear_split: bad pad_left / act");
@@ -100,6 +109,7 @@ extern "C" int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const
 extern "C" int ns2_linear_geglu(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M,
                                 const float* packed_bias, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream) {
   ARGCHK(w && a_hi && out_hi && packed_bias && prec_ok(precision) && w->geglu, "ns2_linear_geglu: bad arguments");
+  WFMT(w, precision, "ns2_linear_geglu");
   ARGCHK(ldo * 2 == w->w.N, "ns2_linear_geglu: ldo must be round_up(f, 32)");
   return gemm_geglu(w->w, a_hi, a_lo, lda, M, packed_bias, out_hi, out_lo, ldo, precision, (hipStream_t)stream);
 }
@@ -120,6 +130,7 @@ extern "C" int ns2_linear_qkv(const ns2_weight* w, const uint16_t* a_hi, const u
                               int split_col, uint16_t* out_hi, uint16_t* out_lo, int ldo, uint16_t* vt_hi, uint16_t* vt_lo,
                               int vt_ld, int precision, void* stream) {
   ARGCHK(w && a_hi && out_hi && vt_hi && prec_ok(precision), "ns2_linear_qkv: bad arguments");
+  WFMT(w, precision, "ns2_linear_qkv");
   ARGCHK(seq_len > 0 && M % seq_len == 0 && (split_col % 32) == 0 && split_col < w->w.N && vt_ld >= seq_len && (vt_ld & 7) == 0,
          "ns2_linear_qkv: bad shapes");
   return gemm_qkv(w->w, a_hi, a_lo, lda, M, seq_len, split_col, out_hi, out_lo, ldo, vt_hi, vt_lo, vt_ld, precision, (hipStream_t)stream);
@@ -128,6 +139,7 @@ extern "C" int ns2_wavenet_block(const ns2_weight* w, const uint16_t* a_hi, cons
                                  int dilation, const float* conv_bias, const float* res_bias, const float* film, int film_ld,
                                  uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream) {
   ARGCHK(w && a_hi && out_hi && conv_bias && res_bias && film && prec_ok(precision), "ns2_wavenet_block: bad arguments");
+  WFMT(w, precision, "ns2_wavenet_block");
   ARGCHK(w->taps == 3 && w->has_extra && seq_len > 0, "ns2_wavenet_block: weight must be packed with taps=3 and extra1x1");
   return gemm_wavenet(w->w, a_hi, a_lo, lda, 0, M, seq_len, dilation, 0, 1, conv_bias, res_bias, 0, film, film_ld, 0, out_hi, out_lo,
                       ldo, 0, ldo, precision, (hipStream_t)stream);
@@ -149,27 +161,32 @@ extern "C" int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq
 }
 
 extern "C" int ns2_rmsnorm(const float* x, int ldx, int M, int d, int seq_len, const float* gamma, const float* cond, int cond_ld,
-                           uint16_t* out_hi, uint16_t* out_lo, int ldo, float* out_f32, int ldo_f, void* stream) {
-  ARGCHK(x && (out_hi || out_f32), "ns2_rmsnorm: bad arguments");
+                           uint16_t* out_hi, uint16_t* out_lo, int ldo, float* out_f32, int ldo_f, int precision, void* stream) {
+  ARGCHK(x && (out_hi || out_f32) && prec_ok(precision), "ns2_rmsnorm: bad arguments");
+  ARGCHK(precision != 2 || !out_lo, "ns2_rmsnorm: precision 2 (fp16) has no lo plane");
   ARGCHK(!cond || seq_len > 0, "ns2_rmsnorm: adaptive norm needs seq_len");
   NormArgs n;
   n.x = x; n.ldx = ldx; n.gamma = gamma; n.cond = cond; n.cond_ld = cond_ld;
-  n.out_hi = out_hi; n.out_lo = out_lo; n.ldo = out_hi ? ldo : d; n.out_f = out_f32; n.ldo_f = ldo_f; n.f16 = 0;
+  n.out_hi = out_hi; n.out_lo = out_lo; n.ldo = out_hi ? ldo : d; n.out_f = out_f32; n.ldo_f = ldo_f; n.f16 = precision == 2;
   n.M = M; n.d = d; n.seq_len = seq_len;
   HIPRET(launch_rmsnorm(n, (hipStream_t)stream));
   return NS2_OK;
 }
 
+extern "C" int64_t ns2_skinny_linear_workspace_bytes(int B, int K, int J) { return (int64_t)skinny_linear_workspace_bytes(B, K, J); }
 extern "C" int ns2_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out, int B,
-                                 int K, int J, int act, void* stream) {
+                                 int K, int J, int act, void* workspace, int64_t workspace_bytes, void* stream) {
   ARGCHK(in && wt && out, "ns2_skinny_linear: null pointer");
-  HIPRET(launch_skinny_linear(in, ld_in, wt, bias, out, ld_out, B, K, J, act, (hipStream_t)stream));
+  HIPRET(launch_skinny_linear(in, ld_in, wt, bias, out, ld_out, B, K, J, act, (float*)workspace,
+                              workspace ? (size_t)workspace_bytes : 0, (hipStream_t)stream));
   return NS2_OK;
 }
 extern "C" int ns2_time_embed(const float* times, const float* freqs, const float* wt, const float* bias, float* feat_ws,
-                              float* out, int ld_out, int B, int dim, int dt, void* stream) {
+                              float* out, int ld_out, int B, int dim, int dt, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
   ARGCHK(times && freqs && wt && feat_ws && out, "ns2_time_embed: null pointer");
-  HIPRET(launch_time_embed(times, freqs, wt, bias, feat_ws, out, ld_out, B, dim, dt, (hipStream_t)stream));
+  HIPRET(launch_time_embed(times, freqs, wt, bias, feat_ws, out, ld_out, B, dim, dt, (float*)workspace,
+                           workspace ? (size_t)workspace_bytes : 0, (hipStream_t)stream));
   return NS2_OK;
 }
 extern "C" int ns2_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int dim, int64_t pad_id, void* stream) {

@@ -134,24 +134,29 @@ hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, in
 }
 
 // ---------------------------------------------------------------- skinny linear: out[b,j] = act(in[b,:] . wt[:,j] + bias[j])
-// M = batch rows (<= 32 per pass), weight stored K-major so a wave streams it fully coalesced; the 32 batch rows of the
-// activation chunk sit in LDS and are read as broadcast ds_read_b128.  Weight-bandwidth bound: this is how all 56-68
-// time/prompt conditioning projections of one denoising step are produced at once (470 MB of fp32 weights at d=512).
-// To keep ~10 MB of loads in flight the K range is split over blockIdx.z (deterministic two-pass reduction, no atomics)
-// and 8 weight rows are fetched per lane before their FMAs.
-constexpr int SK_KC = 128;
+// M = batch rows (<= 32 per pass), weight stored K-major so a wave streams it fully coalesced with 16-B loads (a lane owns 4
+// adjacent output columns); the batch rows of the activation chunk sit in LDS and are read as broadcast ds_read_b128.
+// Weight-bandwidth bound: this is how all 56-68 time/prompt conditioning projections of one denoising step are produced at once
+// (470 MB of fp32 weights at d=512).  The K range is split over blockIdx.z so that >= ~2 blocks per CU stream concurrently
+// (also for the tiny time-embedding Linear, 513 x 2048, which used to run on 8 workgroups); partial sums go to a CALLER-OWNED
+// scratch (ns2_skinny_linear_workspace_bytes) and are combined in a fixed order by a second pass: deterministic, no atomics,
+// no library-owned buffer.
+constexpr int SK_KC = 64;          // K rows staged in LDS per chunk
+constexpr int SK_COLS = 1024;      // output columns per block (256 threads x 4)
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* in, int ld_in, const float* wt, const float* bias,
                                                             float* out, int ld_out, int B, int K, int J, int act,
                                                             int k_per_split, float* partial) {
   __shared__ __attribute__((aligned(16))) float s_in[32][SK_KC + 4];
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.x * SK_COLS + threadIdx.x * 4;
   const int b0 = blockIdx.y * 32;
   const int nb = min(32, B - b0);
-  const bool jok = j < J;
+  const bool jvec = (j + 3 < J) && ((J & 3) == 0);       // 16-B aligned full group
   const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
-  float acc[32];
+  float acc[32][4];
 #pragma unroll
-  for (int b = 0; b < 32; ++b) acc[b] = 0.f;
+  for (int b = 0; b < 32; ++b)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[b][e] = 0.f;
   for (int k0 = kbeg; k0 < kend; k0 += SK_KC) {
     __syncthreads();
     for (int i = threadIdx.x; i < SK_KC * 32; i += 256) {
@@ -163,39 +168,53 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* in, int
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < SK_KC; k += 8) {
-      float w[8];
+      float w[8][4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) w[e] = (jok && k0 + k + e < kend) ? wt[(long)(k0 + k + e) * J + j] : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        const long kr = k0 + k + e;
+        if (kr < kend && jvec) {
+          const float4 t = *reinterpret_cast<const float4*>(wt + kr * J + j);
+          w[e][0] = t.x; w[e][1] = t.y; w[e][2] = t.z; w[e][3] = t.w;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) w[e][c] = (kr < kend && j + c < J) ? wt[kr * J + j + c] : 0.f;
+        }
+      }
 #pragma unroll
       for (int b = 0; b < 32; ++b) {
         const float4 t = *reinterpret_cast<const float4*>(&s_in[b][k]);       // wave-uniform address: LDS broadcast
         const float4 u = *reinterpret_cast<const float4*>(&s_in[b][k + 4]);
-        acc[b] = fmaf(t.x, w[0], acc[b]);
-        acc[b] = fmaf(t.y, w[1], acc[b]);
-        acc[b] = fmaf(t.z, w[2], acc[b]);
-        acc[b] = fmaf(t.w, w[3], acc[b]);
-        acc[b] = fmaf(u.x, w[4], acc[b]);
-        acc[b] = fmaf(u.y, w[5], acc[b]);
-        acc[b] = fmaf(u.z, w[6], acc[b]);
-        acc[b] = fmaf(u.w, w[7], acc[b]);
+        const float x[8] = {t.x, t.y, t.z, t.w, u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[b][c] = fmaf(x[e], w[e][c], acc[b][c]);
       }
     }
   }
-  if (!jok) return;
-  if (partial) {                                            // [split][B][J]
+  if (j >= J) return;
 #pragma unroll
-    for (int b = 0; b < 32; ++b)
-      if (b < nb) partial[((long)blockIdx.z * B + b0 + b) * J + j] = acc[b];
-    return;
-  }
-  const float bj = bias ? bias[j] : 0.f;
+  for (int b = 0; b < 32; ++b) {
+    if (b >= nb) continue;
+    float v[4];
 #pragma unroll
-  for (int b = 0; b < 32; ++b)
-    if (b < nb) {
-      float v = acc[b] + bj;
-      if (act == 1) v = siluf(v);
-      out[(long)(b0 + b) * ld_out + j] = v;
+    for (int c = 0; c < 4; ++c) v[c] = acc[b][c];
+    if (partial) {                                          // [split][B][J]
+      float* dst = partial + ((long)blockIdx.z * B + b0 + b) * J + j;
+      if (jvec) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      else
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (j + c < J) dst[c] = v[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (j + c < J) {
+          float t = v[c] + (bias ? bias[j + c] : 0.f);
+          if (act == 1) t = siluf(t);
+          out[(long)(b0 + b) * ld_out + j + c] = t;
+        }
     }
+  }
 }
 
 __global__ void skinny_reduce_kernel(const float* partial, int nsplit, const float* bias, float* out, int ld_out, int B, int J,
@@ -210,30 +229,32 @@ __global__ void skinny_reduce_kernel(const float* partial, int nsplit, const flo
   out[(long)b * ld_out + j] = v;
 }
 
-static float* g_skinny_ws = nullptr;
-static size_t g_skinny_ws_bytes = 0;
+// K split: enough blocks to keep ~2 per CU streaming, in whole SK_KC chunks
+static void skinny_plan(int B, int K, int J, int* nsplit, int* kps) {
+  const long blocks = (long)((J + SK_COLS - 1) / SK_COLS) * ((B + 31) / 32);
+  int want = (int)((512 + blocks - 1) / blocks);
+  const int max_split = (K + SK_KC - 1) / SK_KC;
+  if (want > max_split) want = max_split;
+  if (want < 1) want = 1;
+  *kps = ((K + want - 1) / want + SK_KC - 1) / SK_KC * SK_KC;
+  *nsplit = (K + *kps - 1) / *kps;
+}
+size_t skinny_linear_workspace_bytes(int B, int K, int J) {
+  if (B <= 0 || K <= 0 || J <= 0) return 0;
+  int nsplit, kps;
+  skinny_plan(B, K, J, &nsplit, &kps);
+  return nsplit > 1 ? (size_t)nsplit * B * J * sizeof(float) : 0;
+}
 
 hipError_t launch_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out,
-                                int B, int K, int J, int act, hipStream_t s) {
+                                int B, int K, int J, int act, float* ws, size_t ws_bytes, hipStream_t s) {
   if (B <= 0 || K <= 0 || J <= 0) return hipErrorInvalidValue;
-  // split K only for the big weight-streaming case (>= 64 MB of weights); the scratch for the partial sums is a
-  // library-owned buffer grown on first use (never during graph capture: the first call is a warm-up)
-  int nsplit = 1;
-  if ((size_t)K * J * 4 >= (size_t)(64u << 20) && K >= 8 * SK_KC) nsplit = 8;
-  const int kps = ((K + nsplit - 1) / nsplit + SK_KC - 1) / SK_KC * SK_KC;
-  nsplit = (K + kps - 1) / kps;
-  float* partial = nullptr;
-  if (nsplit > 1) {
-    const size_t need = (size_t)nsplit * B * J * sizeof(float);
-    if (need > g_skinny_ws_bytes) {
-      if (g_skinny_ws) (void)hipFree(g_skinny_ws);
-      if (hipMalloc((void**)&g_skinny_ws, need) != hipSuccess) { g_skinny_ws = nullptr; g_skinny_ws_bytes = 0; return hipErrorOutOfMemory; }
-      g_skinny_ws_bytes = need;
-    }
-    partial = g_skinny_ws;
-  }
-  hipLaunchKernelGGL(skinny_linear_kernel, dim3((J + 255) / 256, (B + 31) / 32, nsplit), dim3(256), 0, s, in, ld_in, wt, bias,
-                     out, ld_out, B, K, J, act, kps, partial);
+  int nsplit, kps;
+  skinny_plan(B, K, J, &nsplit, &kps);
+  if (nsplit > 1 && (!ws || ws_bytes < (size_t)nsplit * B * J * sizeof(float))) { nsplit = 1; kps = (K + SK_KC - 1) / SK_KC * SK_KC; }
+  float* partial = nsplit > 1 ? ws : nullptr;               // no scratch -> one pass over the whole K (slower, still correct)
+  hipLaunchKernelGGL(skinny_linear_kernel, dim3((J + SK_COLS - 1) / SK_COLS, (B + 31) / 32, nsplit), dim3(256), 0, s, in, ld_in,
+                     wt, bias, out, ld_out, B, K, J, act, kps, partial);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || nsplit == 1) return e;
   const long n = (long)B * J;
@@ -260,12 +281,12 @@ __global__ void time_feat_kernel(const float* times, const float* freqs, float* 
 }
 
 hipError_t launch_time_embed(const float* times, const float* freqs, const float* wt, const float* bias, float* feat_ws,
-                             float* out, int ld_out, int B, int dim, int dt, hipStream_t s) {
+                             float* out, int ld_out, int B, int dim, int dt, float* ws, size_t ws_bytes, hipStream_t s) {
   const int K = dim + 1;
   hipLaunchKernelGGL(time_feat_kernel, dim3((B * K + 255) / 256), dim3(256), 0, s, times, freqs, feat_ws, B, dim);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return launch_skinny_linear(feat_ws, K, wt, bias, out, ld_out, B, K, dt, /*act=*/1, s);
+  return launch_skinny_linear(feat_ws, K, wt, bias, out, ld_out, B, K, dt, /*act=*/1, ws, ws_bytes, s);
 }
 
 // ---------------------------------------------------------------- small data movers

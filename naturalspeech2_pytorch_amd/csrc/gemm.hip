@@ -181,12 +181,10 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s) {
   const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
   const int nz = g.nz > 0 ? g.nz : 1;
   const size_t lds = 2 * 2 * (NSPLIT == 3 ? 2 : 1) * PLANE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NSPLIT, EPI, F16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static DynLdsAttr attr;
+  {
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<NSPLIT, EPI, F16>), (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((gemm_kernel<NSPLIT, EPI, F16>), dim3(ntn * ntm * nz), dim3(256), lds, s, g);
   return hipGetLastError();

@@ -39,8 +39,13 @@ __device__ unsigned long long g2_trace[8 * 64 * 10];
 #define STAMP(n)
 #endif
 
+// 256 B of zeros in device memory: the DMA source of every padded / out-of-sequence lane.  A module-scope __device__ array
+// exists once per device and needs no host-side allocation or bookkeeping (the library keeps no mutable host state).
+__device__ __attribute__((aligned(256))) bf16_t g2_zero_page[128];
+
 template <int NSPLIT, int EPI, bool F16>
-__global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g, const bf16_t* __restrict__ zero_page) {
+__global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
+  const bf16_t* zero_page = g2_zero_page;
   constexpr int NP = (NSPLIT == 3) ? 2 : 1;          // planes per operand (both inside one 128-B LDS row in exact mode)
   constexpr int BK = (NSPLIT == 3) ? 32 : 64;        // K-tile depth (logical elements)
   constexpr int RB = 128;                            // LDS row bytes: [hi32|lo32] (exact) or hi64 (fast)
@@ -254,30 +259,15 @@ extern "C" int ns2_debug_read_trace(unsigned long long* out) {
 }
 #endif
 
-static const bf16_t* zero_page() {
-  static bf16_t* p = nullptr;
-  if (!p) {
-    if (hipMalloc((void**)&p, 256) != hipSuccess) return nullptr;
-    (void)hipMemset(p, 0, 256);
-  }
-  return p;
-}
-
 template <int NSPLIT, int EPI, bool F16>
 static hipError_t launch2_one(const GemmArgs& g, hipStream_t s) {
   const int ntn = (g.N + G2_BN - 1) / G2_BN, ntm = (g.M + G2_BM - 1) / G2_BM;
   const int nz = g.nz > 0 ? g.nz : 1;
   const size_t lds = 8 * EPI_LDS_WAVE_BYTES;          // 144 KiB: 2 x 64 KiB K stages, reused as 8 x 18 KiB epilogue regions
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, F16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  const bf16_t* zp = zero_page();
-  if (!zp) return hipErrorOutOfMemory;
-  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, F16>), dim3(ntn * ntm * nz), dim3(512), lds, s, g, zp);
+  static DynLdsAttr attr;
+  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, F16>), (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, F16>), dim3(ntn * ntm * nz), dim3(512), lds, s, g);
   return hipGetLastError();
 }
 

@@ -174,10 +174,10 @@ static int pack_geglu_bias(std::vector<void*>* owned, float** out, const float* 
 }
 
 // op-level packing used by ns2_weight_pack (tests / non-Python hosts)
-int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, PackedW* out,
+int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, int f16, PackedW* out,
                        std::vector<void*>* owned, hipStream_t s) {
   const int Cp = rup(cols, 32);
-  const PackCtx pc{owned, true, 0};                  // op-level weights: interleaved bf16, serve precisions 1 and 3
+  const PackCtx pc{owned, !f16, f16};                // op-level weights: interleaved bf16 (serves precisions 1 and 3) or dense fp16 (2)
   if (geglu) return pack_geglu(pc, out, w, rows / 2, cols, s);
   const int T = taps + (extra ? 1 : 0);
   NSCHK(alloc_packed(pc, out, rows, T * Cp, Cp / 32));
@@ -473,6 +473,7 @@ static Planes take_planes(Carver& c, int64_t n, bool il, int f16) {
 
 struct Work {
   float *tfeat, *t, *condall, *xres, *tmp_f;
+  float* skinny_ws; size_t skinny_ws_bytes;     // split-K partial sums of the conditioning projections (caller-owned)
   Planes xs, h0, wA, wB, ssum, xn, qk, vt, o, ffh, ffc;
   int Nkp;
   // prepare_cond scratch
@@ -491,6 +492,10 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
   w->tfeat = c.take<float>((int64_t)B * (dim + 1));
   w->t = c.take<float>((int64_t)B * m->Tc);
   w->condall = c.take<float>((int64_t)B * m->Jtot);
+  w->skinny_ws_bytes = std::max(skinny_linear_workspace_bytes(B, m->Tc, m->Jtot),
+                                std::max(skinny_linear_workspace_bytes(B, dim + 1, m->dt),
+                                         skinny_linear_workspace_bytes(B, std::max(m->cfg.dim_prompt, 1), m->dt)));
+  w->skinny_ws = c.take<float>((int64_t)(w->skinny_ws_bytes / sizeof(float)));
   w->xres = c.take<float>(M * dim);
   w->xs = take_planes(c, M * dp, il, f16);
   w->h0 = take_planes(c, M * dp, il, f16);
@@ -625,7 +630,8 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
   } else {
     // to_prompt_cond: mean over n -> Linear -> SiLU (NS2:858-862)
     HIPCHK(launch_mean_rows(prompt, B, n_prompt, dprompt, w.pmean, s));
-    HIPCHK(launch_skinny_linear(w.pmean, dprompt, m->wt_prompt, m->b_prompt, cs.prompt_cond, m->dt, B, dprompt, m->dt, 1, s));
+    HIPCHK(launch_skinny_linear(w.pmean, dprompt, m->wt_prompt, m->b_prompt, cs.prompt_cond, m->dt, B, dprompt, m->dt, 1, w.skinny_ws,
+                                w.skinny_ws_bytes, s));
     // perceiver resampler (NS2:532-579)
     const int Nctx = w.Nctx;
     if (m->has_proj) {
@@ -736,12 +742,12 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
   char name[64];
 
   // ---- t = to_time_cond(times) [, prompt_cond]  (NS2:944-960), then every conditioning projection of the step at once
-  HIPCHK(launch_time_embed(times, m->freqs, m->wt_time, m->b_time, w.tfeat, w.t, m->Tc, B, dim, m->dt, s));
+  HIPCHK(launch_time_embed(times, m->freqs, m->wt_time, m->b_time, w.tfeat, w.t, m->Tc, B, dim, m->dt, w.skinny_ws, w.skinny_ws_bytes, s));
   if (cond)
     HIPCHK(hipMemcpy2DAsync(w.t + m->dt, (size_t)m->Tc * 4, cs.prompt_cond, (size_t)m->dt * 4, (size_t)m->dt * 4, B,
                             hipMemcpyDeviceToDevice, s));
   NSCHK(tap_f32(m, "t", w.t, (int64_t)B * m->Tc, s));
-  HIPCHK(launch_skinny_linear(w.t, m->Tc, m->wt_cond, m->b_cond, w.condall, Jtot, B, m->Tc, Jtot, 0, s));
+  HIPCHK(launch_skinny_linear(w.t, m->Tc, m->wt_cond, m->b_cond, w.condall, Jtot, B, m->Tc, Jtot, 0, w.skinny_ws, w.skinny_ws_bytes, s));
 
   // ---- x (+ aligned conditioning, NS2:976-992) -> split planes
   HIPCHK(launch_split(x, dim, cond ? cs.condadd : nullptr, dim, n_cond, cond ? cs.n_cond_valid : 0, w.xs.hi, w.xs.lo, dp, M, dim, N, s, w.xs.f16));

@@ -30,7 +30,7 @@ int gemm_wavenet(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int l
                  int dil_z, int nz, const float* b_conv, const float* b_res, long bias_zs, const float* film, int film_ld,
                  long film_zs, bf16_t* o_hi, bf16_t* o_lo, int ldo, long out_zs, int out_ncols, int prec, hipStream_t s);
 
-int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, PackedW* out,
+int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, int f16, PackedW* out,
                        std::vector<void*>* owned, hipStream_t s);
 std::vector<int> geglu_row_map(int f, int rows_p);
 

@@ -4,9 +4,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef uint16_t bf16_t;
 
 namespace ns2 {
+
+// Per-kernel "dynamic LDS size raised" flag, kept PER DEVICE (function attributes belong to the device's code object) and
+// safe under concurrent first calls from several host threads (one thread per device is the supported model; a duplicated
+// hipFuncSetAttribute is harmless).  This is the only host-side state a launcher keeps; it never allocates.
+struct DynLdsAttr {
+  static constexpr int kMaxDev = 64;
+  std::atomic<int> bytes[kMaxDev];
+  DynLdsAttr() { for (auto& b : bytes) b.store(0, std::memory_order_relaxed); }
+  hipError_t ensure(const void* fn, int lds) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < kMaxDev;
+    if (tracked && bytes[dev].load(std::memory_order_acquire) >= lds) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess && tracked) bytes[dev].store(lds, std::memory_order_release);
+    return e;
+  }
+};
 
 // split-plane operands: a lo plane implies the interleaved [hi32|lo32] row layout, i.e. lo == hi + 32 (ns2_common.h)
 inline bool planes_ok(const bf16_t* hi, const bf16_t* lo) { return lo == nullptr || lo == hi + 32; }
@@ -84,11 +105,13 @@ hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, in
 // LearnedSinusoidalPosEmb + Linear(d+1, dt) + SiLU (NS2:108-120, 839-843): times[B] -> out[B, ld_out] columns [0, dt)
 // wt is the Linear weight stored K-major [dim+1, dt]; feat_ws is a [B, dim+1] fp32 scratch.
 hipError_t launch_time_embed(const float* times, const float* freqs, const float* wt, const float* bias, float* feat_ws,
-                             float* out, int ld_out, int B, int dim, int dt, hipStream_t s);
+                             float* out, int ld_out, int B, int dim, int dt, float* ws, size_t ws_bytes, hipStream_t s);
 
 // out[b, j] = act( sum_k in[b,k] * wt[k, j] + bias[j] ), wt stored K-major ([K, J]); act 0 none, 1 SiLU
+// ws: caller-owned scratch of skinny_linear_workspace_bytes(B, K, J) for the split-K partial sums (null: no K split)
+size_t skinny_linear_workspace_bytes(int B, int K, int J);
 hipError_t launch_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out,
-                                int B, int K, int J, int act, hipStream_t s);
+                                int B, int K, int J, int act, float* ws, size_t ws_bytes, hipStream_t s);
 
 // batched fp32 [R, C] -> [C, R]
 hipError_t launch_transpose_f32(const float* in, int batch, int R, int C, float* out, hipStream_t s);

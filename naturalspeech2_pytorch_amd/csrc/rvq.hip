@@ -150,12 +150,10 @@ __global__ __launch_bounds__(256, 1) void rvq_encode_kernel(const RvqArgs a) {
 hipError_t launch_rvq_encode(const RvqArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.Q <= 0 || a.D != RV_D || a.C <= 0 || (a.C % RV_TILE)) return hipErrorInvalidValue;
   const size_t lds = 2 * RV_STAGE_F * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rvq_encode_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static DynLdsAttr attr;
+  {
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&rvq_encode_kernel), (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(rvq_encode_kernel, dim3((a.M + 127) / 128), dim3(256), lds, s, a);
   hipError_t e = hipGetLastError();

@@ -10,23 +10,21 @@ import torch
 from torch import nn
 
 from . import ops
-from .model import _NoParams
+from ._cache import PackedCache
+from .model import _NoParams, _PRECISIONS
 from .transformer import Transformer
 
 
-class _ConvStack:
-    """packed k-tap convs, re-packed when the parameters change."""
+class _ConvStack(PackedCache):
+    """packed k-tap convs, re-packed when the parameters change (by content); dropped by deepcopy / pickling."""
 
-    def __init__(self):
-        self.packed, self.sig = None, None
+    def __deepcopy__(self, memo):
+        return _ConvStack()
 
-    def get(self, convs):
-        sig = tuple((c.weight.data_ptr(), c.weight._version, c.bias.data_ptr(), c.bias._version) for c in convs)
-        if self.packed is None or self.sig != sig:
-            self.packed = [(ops.PackedWeight(c.weight.detach().float().contiguous()), c.bias.detach().float().contiguous())
-                           for c in convs]
-            self.sig = sig
-        return self.packed
+    def packed_for(self, convs, prec):
+        ts = [t for c in convs for t in (c.weight, c.bias)]
+        return self.get(ts, lambda: [(ops.PackedWeight(c.weight.detach().float().contiguous(), precision=prec),
+                                      c.bias.detach().float().contiguous()) for c in convs], extra=(prec,))
 
 
 class SpeechPromptEncoder(nn.Module):
@@ -35,6 +33,7 @@ class SpeechPromptEncoder(nn.Module):
         super().__init__()
         dims = [dim_codebook, *dims]
         self.dim, self.dim_out = dims[0], dims[-1]
+        assert precision in _PRECISIONS, f"precision must be one of {sorted(_PRECISIONS)}"
         self.kernel_size, self.padding, self.precision = kernel_size, padding, precision
         mods = [_NoParams()]
         for d_in, d_out in zip(dims[:-1], dims[1:]):
@@ -49,10 +48,10 @@ class SpeechPromptEncoder(nn.Module):
     def forward(self, x):
         assert x.shape[-1] == self.dim
         b, n, _ = x.shape
-        prec = 3 if self.precision == "exact" else 1
+        prec = _PRECISIONS[self.precision]
         convs = [m for m in self.conv if isinstance(m, nn.Conv1d)]
-        packed = self._stack.get(convs)
-        h = ops.split(x.reshape(b * n, self.dim).float().contiguous())
+        packed = self._stack.packed_for(convs, prec)
+        h = ops.split(x.reshape(b * n, self.dim).float().contiguous(), precision=prec)
         for i, (pw, bias) in enumerate(packed):
             kw = dict(bias=bias, conv_taps=self.kernel_size, dilation=1, seq_len=n, pad_left=self.padding, act=1, precision=prec)
             if i + 1 < len(packed):
@@ -72,6 +71,7 @@ class PhonemeEncoder(nn.Module):
         self.tokenizer = tokenizer
         self.token_emb = nn.Embedding(num_tokens + 1, dim)
         self.pad_id = num_tokens
+        assert precision in _PRECISIONS, f"precision must be one of {sorted(_PRECISIONS)}"
         self.kernel_size, self.dim_hidden, self.precision = kernel_size, dim_hidden, precision
         self.conv = nn.Sequential(_NoParams(), nn.Conv1d(dim, dim_hidden, kernel_size), _NoParams(), _NoParams(), _NoParams())
         self.transformer = Transformer(dim=dim_hidden, depth=depth, dim_head=dim_head, heads=heads, dropout=attn_dropout,
@@ -83,9 +83,9 @@ class PhonemeEncoder(nn.Module):
         if not torch.is_tensor(x):
             raise NotImplementedError("List[str] input needs the tokenizer / espeak front-end (out of scope); pass token ids")
         b, n = x.shape
-        prec = 3 if self.precision == "exact" else 1
+        prec = _PRECISIONS[self.precision]
         emb = ops.embedding(x, self.token_emb.weight.detach().float().contiguous(), self.pad_id)     # NS2:281-284
-        (pw, bias), = self._stack.get([self.conv[1]])
-        h = ops.linear_f32(pw, ops.split(emb.reshape(b * n, -1)), bias=bias, conv_taps=self.kernel_size, dilation=1, seq_len=n,
+        (pw, bias), = self._stack.packed_for([self.conv[1]], prec)
+        h = ops.linear_f32(pw, ops.split(emb.reshape(b * n, -1), precision=prec), bias=bias, conv_taps=self.kernel_size, dilation=1, seq_len=n,
                            pad_left=-1, act=1, precision=prec)                                        # CausalConv1d + SiLU
         return self.transformer(h.reshape(b, n, self.dim_hidden), mask=mask)

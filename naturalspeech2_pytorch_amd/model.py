@@ -5,7 +5,8 @@ Boundary kept from the reference:
   * constructor signature NS2:814-831, attributes `.dim`, `.condition_on_prompt`, `.cond_drop_prob`, `.device`;
   * `forward(x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None)` NS2:929-937 and
     `forward_with_cond_scale(*args, cond_scale=1., **kwargs)` NS2:914-927;
-  * `state_dict()` key names and shapes (checked against the reference's in tests/test_model_cpu.py), so
+  * `state_dict()` key names and shapes (checked against the reference's in tests/test_host_cpu.py::
+    test_state_dict_contract_matches_reference), so
     reference checkpoints load unchanged;  survives copy.deepcopy (EMA, NS2:1793-1798).
 
 The parameter-holder modules below exist only to own same-named parameters with the reference's default
@@ -20,6 +21,7 @@ from torch import nn
 
 from . import _lib
 from ._lib import ModelConfig, check
+from ._cache import tensors_fingerprint
 
 
 # ------------------------------------------------------------------------------------------ parameter holders
@@ -93,6 +95,7 @@ class _NativeState:
     def __init__(self):
         self.handle = None
         self.sig = None
+        self.fingerprint = None
         self.ws = None
         self.cond_cache = {}
         self.keepalive = None
@@ -113,14 +116,207 @@ class _NativeState:
             except Exception:
                 pass
         self.handle = None
+        self.sig = None
+        self.fingerprint = None
         self.cond_cache = {}
 
     def __del__(self):
         self.release()
 
 
+_CFG_KEYS = ("dim", "depth", "dim_head", "heads", "ff_mult", "wavenet_layers", "wavenet_stacks", "dim_cond_mult",
+             "condition_on_prompt", "dim_prompt", "num_latents_m", "resampler_depth")
+_PRECISIONS = {"exact": 3, "half": 2, "fast": 1}
+
+
+# ------------------------------------------------------------------------------------------ HIP execution mixin
+class HipDenoiserMixin:
+    """Runs `forward` / `forward_with_cond_scale` of an nn.Module that OWNS the reference `Model`'s parameters (the state_dict
+    key contract of SURVEY §8b) in libns2hip.  Used by this package's `Model` (parameter holders only) and by
+    `compat.HipBackedModel` (a subclass of the reference's own `Model` class, for use inside the reference's
+    `NaturalSpeech2`).  The host class provides `_forward_autograd` for the calls that need autograd."""
+
+    def _hip_init(self, cfg: dict, precision: str):
+        assert precision in _PRECISIONS, f"precision must be one of {sorted(_PRECISIONS)}"
+        assert set(cfg) == set(_CFG_KEYS)
+        self._hip_cfg = dict(cfg)
+        self.precision = precision
+        self._native = _NativeState()
+
+    # ---- cache invalidation (ADVICE r1): version counters do not see `.data` writes
+    def invalidate(self):
+        """drop the packed weights; the next inference forward re-packs from the current parameters"""
+        self._native.release()
+
+    def refresh_weights(self):
+        """re-pack iff the parameter CONTENTS changed since they were packed (one device reduction + one host read).
+        `NaturalSpeech2.sample` calls this once per sampling run, which covers EMA shadow models updated through `.data`."""
+        ns = self._native
+        if ns.handle is None:
+            return False
+        fp = tensors_fingerprint(list(self.parameters()))
+        if fp != ns.fingerprint:
+            ns.release()
+            return True
+        return False
+
+    def _apply(self, fn, *args, **kwargs):               # .to() / .cuda() / .float(): parameters move or are rewritten
+        out = super()._apply(fn, *args, **kwargs)
+        if getattr(self, "_native", None) is not None:
+            self._native.release()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        if getattr(self, "_native", None) is not None:
+            self._native.release()
+        return out
+
+    # ---- native plumbing
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.precision,)
+
+    def _ensure_native(self):
+        ns = self._native
+        sig = self._signature()
+        if ns.handle is not None and ns.sig == sig:
+            return ns
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.Ns2Error("Model parameters must live on an MI355X (cuda) device: the HIP path has no CPU fallback")
+        lib = _lib.load()
+        ns.release()
+        c = self._hip_cfg
+        cfg = ModelConfig(
+            dim=c["dim"], depth=c["depth"], dim_head=c["dim_head"], heads=c["heads"], ff_mult=c["ff_mult"],
+            wavenet_layers=c["wavenet_layers"], wavenet_stacks=c["wavenet_stacks"], dim_cond_mult=c["dim_cond_mult"],
+            condition_on_prompt=int(bool(c["condition_on_prompt"])), dim_prompt=int(c["dim_prompt"] or 0),
+            num_latents_m=c["num_latents_m"], resampler_depth=c["resampler_depth"], precision=_PRECISIONS[self.precision])
+        h = ctypes.c_void_p()
+        check(lib.ns2_model_create(ctypes.byref(cfg), ctypes.byref(h)), "ns2_model_create")
+        ns.handle = h
+        keep = []
+        with torch.cuda.device(dev):
+            for name, p in self.state_dict().items():
+                t = p.detach()
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    t = t.float().contiguous()
+                keep.append(t)
+                dims = (ctypes.c_int64 * t.ndim)(*t.shape)
+                check(lib.ns2_model_set_param(h, name.encode(), t.data_ptr(), t.ndim, dims), f"set_param {name}")
+            check(lib.ns2_model_finalize(h, torch.cuda.current_stream().cuda_stream), "ns2_model_finalize")
+        ns.keepalive = keep           # small vectors (biases, gammas, freqs) are read in place by the executor
+        ns.sig = sig
+        ns.fingerprint = tensors_fingerprint(list(self.parameters()))
+        ns.cond_cache = {}
+        return ns
+
+    def _workspace(self, ns, B, N, n_prompt, n_cond):
+        dev = next(self.parameters()).device
+        need = _lib.load().ns2_model_workspace_bytes(ns.handle, B, N, n_prompt, n_cond)
+        if ns.ws is None or ns.ws.numel() < need or ns.ws.device != dev:
+            ns.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return ns.ws
+
+    def _cond_state(self, ns, prompt, cond, drop, B, N):
+        key = (prompt.data_ptr(), prompt._version, tuple(prompt.shape), cond.data_ptr(), cond._version, tuple(cond.shape),
+               bool(drop), B, N)
+        hit = ns.cond_cache.get(bool(drop))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        lib = _lib.load()
+        n_p, n_c = prompt.shape[1], cond.shape[2]
+        nbytes = lib.ns2_model_cond_bytes(ns.handle, B, N, n_p, n_c)
+        state = torch.empty(nbytes, dtype=torch.uint8, device=prompt.device)
+        ws = self._workspace(ns, B, N, n_p, n_c)
+        check(lib.ns2_model_prepare_cond(ns.handle, prompt.data_ptr(), n_p, cond.data_ptr(), n_c, int(drop), B, N,
+                                         state.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+              "ns2_model_prepare_cond")
+        ns.cond_cache[bool(drop)] = (key, state, prompt, cond)     # keep the inputs alive with the cache entry
+        return state
+
+    def clear_cond_cache(self):
+        """forget the cached step-invariant conditioning (call when prompt / cond were rewritten in place through `.data`)"""
+        self._native.cond_cache = {}
+
+    # ---- forward (NS2:929-1000)
+    def forward(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None):
+        p = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(q.requires_grad for q in self.parameters()))
+        stochastic = self._hip_cfg["condition_on_prompt"] and p not in (0, 0., 1, 1.)
+        if needs_grad or stochastic:
+            # training (loss.backward(), NS2:1635/1886) and per-utterance stochastic conditioning dropout (a training /
+            # validation feature, NS2:79-85) run the differentiable PyTorch composite; sampling never gets here
+            return self._forward_autograd(x, times, prompt=prompt, prompt_mask=prompt_mask, cond=cond, cond_drop_prob=cond_drop_prob)
+        return self._forward_hip(x, times, prompt, prompt_mask, cond, cond_drop_prob)
+
+    @torch.no_grad()
+    def _forward_hip(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, out=None):
+        if prompt_mask is not None:
+            raise NotImplementedError("prompt_mask: no reference caller passes one (NS2:1333, 1410, 1635)")
+        p = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
+        conditional = bool(self._hip_cfg["condition_on_prompt"])
+        if conditional and p not in (0, 0., 1, 1.):
+            raise NotImplementedError("the HIP inference path supports cond_drop_prob 0 or 1 (what forward_with_cond_scale uses)")
+        dim = self._hip_cfg["dim"]
+        ns = self._ensure_native()
+        assert x.ndim == 3 and x.shape[-1] == dim, f"x must be [b, n, {dim}]"
+        B, N, _ = x.shape
+        xin = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+        t = times.to(device=xin.device, dtype=torch.float32).contiguous()
+        assert t.shape == (B,)
+        out = torch.empty_like(xin) if out is None else out
+        state_ptr, n_c = None, 0
+        if conditional:
+            assert prompt is not None and cond is not None, "conditional model needs prompt [b, n_p, dim_prompt] and cond [b, dim_prompt, n_c]"
+            pr = prompt if (prompt.dtype == torch.float32 and prompt.is_contiguous()) else prompt.float().contiguous()
+            cd = cond if (cond.dtype == torch.float32 and cond.is_contiguous()) else cond.float().contiguous()
+            state = self._cond_state(ns, pr, cd, p == 1, B, N)
+            state_ptr, n_c = state.data_ptr(), cd.shape[2]
+            ws = self._workspace(ns, B, N, pr.shape[1], n_c)
+        else:
+            ws = self._workspace(ns, B, N, 0, 0)
+        check(_lib.load().ns2_model_forward(ns.handle, xin.data_ptr(), t.data_ptr(), state_ptr, n_c, out.data_ptr(), B, N,
+                                            ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "ns2_model_forward")
+        return out if out.dtype == x.dtype else out.to(x.dtype)
+
+    def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
+        """NS2:914-927."""
+        logits = self.forward(*args, cond_drop_prob=0., **kwargs)
+        if cond_scale == 1.:
+            return logits
+        if not self._hip_cfg["condition_on_prompt"] and not torch.is_grad_enabled():
+            # an unconditional Model ignores cond_drop_prob, so the reference's second forward reproduces `logits` bit for
+            # bit and null + (logits - null) * s == logits exactly: skip it (deterministic kernels, see
+            # test_batch_independence_and_determinism)
+            return logits
+        null_logits = self.forward(*args, cond_drop_prob=1., **kwargs)
+        if logits.is_cuda and not torch.is_grad_enabled():
+            from . import ops
+            return ops.cfg_mix(logits, null_logits, cond_scale)
+        return null_logits + (logits - null_logits) * cond_scale
+
+    # ---- parity-test taps
+    def debug_forward(self, x, times, taps, prompt=None, cond=None, drop=False):
+        """forward + fp32 copies of intermediate buffers; taps: {name: numel}. Test-only helper."""
+        ns = self._ensure_native()
+        lib = _lib.load()
+        dev = next(self.parameters()).device
+        bufs = {k: torch.zeros(n, dtype=torch.float32, device=dev) for k, n in taps.items()}
+        for k, b in bufs.items():
+            check(lib.ns2_model_debug_tap(ns.handle, k.encode(), b.data_ptr(), b.numel()), "debug_tap")
+        try:
+            ns.cond_cache = {}
+            out = self._forward_hip(x, times, prompt=prompt, cond=cond, cond_drop_prob=1. if drop else 0.)
+            torch.cuda.synchronize()
+        finally:
+            for k in bufs:
+                lib.ns2_model_debug_tap(ns.handle, k.encode(), None, 0)
+        return out, bufs
+
+
 # ------------------------------------------------------------------------------------------ Model
-class Model(nn.Module):
+class Model(HipDenoiserMixin, nn.Module):
     def __init__(
         self,
         dim,
@@ -141,7 +337,6 @@ class Model(nn.Module):
         precision="exact",
     ):
         super().__init__()
-        assert precision in ("exact", "half", "fast")
         self.dim = dim
         self.depth = depth
         self.dim_head, self.heads, self.ff_mult = dim_head, heads, ff_mult
@@ -151,7 +346,6 @@ class Model(nn.Module):
         self.num_latents_m, self.resampler_depth = num_latents_m, resampler_depth
         self.cond_drop_prob = cond_drop_prob
         self.condition_on_prompt = condition_on_prompt
-        self.precision = precision
 
         dim_time = dim * dim_cond_mult
         self.to_time_cond = _seq(_SinusoidalWeights(dim), nn.Linear(dim + 1, dim_time), _NoParams())
@@ -210,139 +404,15 @@ class Model(nn.Module):
         tr.to_pred = _seq(_RMSNorm(dim), nn.Linear(dim, dim, bias=False))
         self.transformer = tr
 
-        self._native = _NativeState()
+        self._hip_init(dict(dim=dim, depth=depth, dim_head=dim_head, heads=heads, ff_mult=ff_mult, wavenet_layers=wavenet_layers,
+                            wavenet_stacks=wavenet_stacks, dim_cond_mult=dim_cond_mult, condition_on_prompt=condition_on_prompt,
+                            dim_prompt=dim_prompt, num_latents_m=num_latents_m, resampler_depth=resampler_depth), precision)
 
     # ------------------------------------------------------------------ reference attribute surface
     @property
     def device(self):
         return next(self.parameters()).device
 
-    # ------------------------------------------------------------------ native plumbing
-    def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.precision,)
-
-    def _ensure_native(self):
-        ns = self._native
-        sig = self._signature()
-        if ns.handle is not None and ns.sig == sig:
-            return ns
-        dev = self.device
-        if dev.type != "cuda":
-            raise _lib.Ns2Error("Model parameters must live on an MI355X (cuda) device: the HIP path has no CPU fallback")
-        lib = _lib.load()
-        ns.release()
-        cfg = ModelConfig(
-            dim=self.dim, depth=self.depth, dim_head=self.dim_head, heads=self.heads, ff_mult=self.ff_mult,
-            wavenet_layers=self.wavenet_layers, wavenet_stacks=self.wavenet_stacks, dim_cond_mult=self.dim_cond_mult_base,
-            condition_on_prompt=int(self.condition_on_prompt), dim_prompt=int(self.dim_prompt or 0),
-            num_latents_m=self.num_latents_m, resampler_depth=self.resampler_depth,
-            precision={"exact": 3, "half": 2, "fast": 1}[self.precision])
-        h = ctypes.c_void_p()
-        check(lib.ns2_model_create(ctypes.byref(cfg), ctypes.byref(h)), "ns2_model_create")
-        ns.handle = h
-        keep = []
-        with torch.cuda.device(dev):
-            for name, p in self.state_dict().items():
-                t = p.detach()
-                if t.dtype != torch.float32 or not t.is_contiguous():
-                    t = t.float().contiguous()
-                keep.append(t)
-                dims = (ctypes.c_int64 * t.ndim)(*t.shape)
-                check(lib.ns2_model_set_param(h, name.encode(), t.data_ptr(), t.ndim, dims), f"set_param {name}")
-            check(lib.ns2_model_finalize(h, torch.cuda.current_stream().cuda_stream), "ns2_model_finalize")
-        ns.keepalive = keep           # small vectors (biases, gammas, freqs) are read in place by the executor
-        ns.sig = sig
-        ns.cond_cache = {}
-        return ns
-
-    def _workspace(self, ns, B, N, n_prompt, n_cond):
-        need = _lib.load().ns2_model_workspace_bytes(ns.handle, B, N, n_prompt, n_cond)
-        if ns.ws is None or ns.ws.numel() < need or ns.ws.device != self.device:
-            ns.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return ns.ws
-
-    def _cond_state(self, ns, prompt, cond, drop, B, N):
-        key = (prompt.data_ptr(), prompt._version, tuple(prompt.shape), cond.data_ptr(), cond._version, tuple(cond.shape),
-               bool(drop), B, N)
-        hit = ns.cond_cache.get(bool(drop))
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        lib = _lib.load()
-        n_p, n_c = prompt.shape[1], cond.shape[2]
-        nbytes = lib.ns2_model_cond_bytes(ns.handle, B, N, n_p, n_c)
-        state = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        ws = self._workspace(ns, B, N, n_p, n_c)
-        check(lib.ns2_model_prepare_cond(ns.handle, prompt.data_ptr(), n_p, cond.data_ptr(), n_c, int(drop), B, N,
-                                         state.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
-              "ns2_model_prepare_cond")
-        ns.cond_cache[bool(drop)] = (key, state, prompt, cond)     # keep the inputs alive with the cache entry
-        return state
-
-    # ------------------------------------------------------------------ forward (NS2:929-1000)
-    def forward(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None):
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            from .autograd_path import model_forward_autograd
-            return model_forward_autograd(self, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)
-        return self._forward_hip(x, times, prompt, prompt_mask, cond, cond_drop_prob)
-
-    @torch.no_grad()
-    def _forward_hip(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, out=None):
-        if prompt_mask is not None:
-            raise NotImplementedError("prompt_mask: no reference caller passes one (NS2:1333, 1410, 1635)")
-        p = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
-        if p not in (0, 0., 1, 1.):
-            raise NotImplementedError("the HIP inference path supports cond_drop_prob 0 or 1 (what forward_with_cond_scale uses); "
-                                      "stochastic conditioning dropout is a training-time feature (autograd path)")
-        ns = self._ensure_native()
-        assert x.ndim == 3 and x.shape[-1] == self.dim, f"x must be [b, n, {self.dim}]"
-        B, N, _ = x.shape
-        xin = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
-        t = times.to(device=xin.device, dtype=torch.float32).contiguous()
-        assert t.shape == (B,)
-        out = torch.empty_like(xin) if out is None else out
-        state_ptr, n_c = None, 0
-        if self.condition_on_prompt:
-            assert prompt is not None and cond is not None, "conditional model needs prompt [b, n_p, dim_prompt] and cond [b, dim_prompt, n_c]"
-            pr = prompt if (prompt.dtype == torch.float32 and prompt.is_contiguous()) else prompt.float().contiguous()
-            cd = cond if (cond.dtype == torch.float32 and cond.is_contiguous()) else cond.float().contiguous()
-            state = self._cond_state(ns, pr, cd, p == 1, B, N)
-            state_ptr, n_c = state.data_ptr(), cd.shape[2]
-            ws = self._workspace(ns, B, N, pr.shape[1], n_c)
-        else:
-            ws = self._workspace(ns, B, N, 0, 0)
-        check(_lib.load().ns2_model_forward(ns.handle, xin.data_ptr(), t.data_ptr(), state_ptr, n_c, out.data_ptr(), B, N,
-                                            ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "ns2_model_forward")
-        return out if out.dtype == x.dtype else out.to(x.dtype)
-
-    def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
-        """NS2:914-927."""
-        logits = self.forward(*args, cond_drop_prob=0., **kwargs)
-        if cond_scale == 1.:
-            return logits
-        if not self.condition_on_prompt and not torch.is_grad_enabled():
-            # an unconditional Model ignores cond_drop_prob, so the reference's second forward reproduces `logits` bit for
-            # bit and null + (logits - null) * s == logits exactly: skip it (deterministic kernels, see
-            # test_batch_independence_and_determinism)
-            return logits
-        null_logits = self.forward(*args, cond_drop_prob=1., **kwargs)
-        if logits.is_cuda and not torch.is_grad_enabled():
-            from . import ops
-            return ops.cfg_mix(logits, null_logits, cond_scale)
-        return null_logits + (logits - null_logits) * cond_scale
-
-    # ------------------------------------------------------------------ parity-test taps
-    def debug_forward(self, x, times, taps, prompt=None, cond=None, drop=False):
-        """forward + fp32 copies of intermediate buffers; taps: {name: numel}. Test-only helper."""
-        ns = self._ensure_native()
-        lib = _lib.load()
-        bufs = {k: torch.zeros(n, dtype=torch.float32, device=self.device) for k, n in taps.items()}
-        for k, b in bufs.items():
-            check(lib.ns2_model_debug_tap(ns.handle, k.encode(), b.data_ptr(), b.numel()), "debug_tap")
-        try:
-            ns.cond_cache = {}
-            out = self._forward_hip(x, times, prompt=prompt, cond=cond, cond_drop_prob=1. if drop else 0.)
-            torch.cuda.synchronize()
-        finally:
-            for k in bufs:
-                lib.ns2_model_debug_tap(ns.handle, k.encode(), None, 0)
-        return out, bufs
+    def _forward_autograd(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None):
+        from .autograd_path import model_forward_autograd
+        return model_forward_autograd(self, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)

@@ -31,13 +31,20 @@ class Planes:
     """A split-plane matrix [rows, ld] held by the library's layout (csrc/ns2_common.h).
 
     With a lo plane ("interleaved", what precision 3 needs) `buf` is ONE bf16 tensor [rows, 2*ld]: every 32 logical columns
-    occupy a 128-byte line [hi(32) | lo(32)], so the lo pointer is the hi pointer + 32 elements.  Without (hi only,
-    precision 1) `buf` is the dense [rows, ld] hi plane.  `ld` is always the LOGICAL column count (a multiple of 32).
+    occupy a 128-byte line [hi(32) | lo(32)], so the lo pointer is the hi pointer + 32 elements.  Without (hi only) `buf` is
+    the dense [rows, ld] hi plane: bf16 for precision 1, IEEE half (`f16=True`) for precision 2.  `ld` is always the LOGICAL
+    column count (a multiple of 32).
     """
-    __slots__ = ("buf", "rows", "ld", "has_lo")
+    __slots__ = ("buf", "rows", "ld", "has_lo", "f16")
 
-    def __init__(self, buf: torch.Tensor, rows: int, ld: int, has_lo: bool):
-        self.buf, self.rows, self.ld, self.has_lo = buf, rows, ld, has_lo
+    def __init__(self, buf: torch.Tensor, rows: int, ld: int, has_lo: bool, f16: bool = False):
+        assert not (f16 and has_lo), "IEEE-half planes have no lo part"
+        self.buf, self.rows, self.ld, self.has_lo, self.f16 = buf, rows, ld, has_lo, f16
+
+    @property
+    def precision_ok(self):
+        """precisions this operand can be multiplied at"""
+        return (2,) if self.f16 else ((1, 3) if self.has_lo else (1,))
 
     @property
     def device(self):
@@ -63,19 +70,27 @@ class Planes:
         return Planes(self.hi_plane(), self.rows, self.ld, False)
 
 
-def empty_planes(rows: int, cols: int, device, lo: bool = True, zero: bool = False) -> Planes:
+def empty_planes(rows: int, cols: int, device, lo: bool = True, zero: bool = False, f16: bool = False) -> Planes:
+    lo = lo and not f16
     assert cols % 32 == 0 or not lo, "interleaved split planes come in 32-column blocks"
     alloc = torch.zeros if zero else torch.empty
-    return Planes(alloc(rows, cols * (2 if lo else 1), dtype=torch.bfloat16, device=device), rows, cols, lo)
+    dt = torch.float16 if f16 else torch.bfloat16
+    return Planes(alloc(rows, cols * (2 if lo else 1), dtype=dt, device=device), rows, cols, lo, f16)
 
 
-def split(x: torch.Tensor, ldo: Optional[int] = None, lo: bool = True) -> Planes:
-    """fp32 [M, d] -> bf16 split planes [M, ldo] (zero padded)."""
+def _pfmt(precision: int) -> dict:
+    """plane format a kernel writes at `precision`: 3 -> interleaved bf16 hi/lo, 1 -> (we still carry both planes, the
+    kernels read hi), 2 -> one IEEE-half plane"""
+    return dict(lo=precision != 2, f16=precision == 2)
+
+
+def split(x: torch.Tensor, ldo: Optional[int] = None, lo: bool = True, precision: int = 3) -> Planes:
+    """fp32 [M, d] -> split planes [M, ldo] (zero padded); precision 2 -> one IEEE-half plane."""
     x = _f32(x)
     M, d = x.shape
     ldo = ldo or round_up(d, 32)
-    out = empty_planes(M, ldo, x.device, lo)
-    check(_lib.load().ns2_split_f32(x.data_ptr(), d, M, d, out.hi, out.lo, ldo, _stream()), "ns2_split_f32")
+    out = empty_planes(M, ldo, x.device, lo, f16=precision == 2)
+    check(_lib.load().ns2_split_f32(x.data_ptr(), d, M, d, out.hi, out.lo, ldo, 2 if out.f16 else 3, _stream()), "ns2_split_f32")
     return out
 
 
@@ -83,16 +98,18 @@ def join(p: Planes, d: Optional[int] = None) -> torch.Tensor:
     M, ld = p.rows, p.ld
     d = d or ld
     out = torch.empty(M, d, dtype=torch.float32, device=p.device)
-    check(_lib.load().ns2_join_f32(p.hi, p.lo, ld, out.data_ptr(), d, M, d, _stream()), "ns2_join_f32")
+    check(_lib.load().ns2_join_f32(p.hi, p.lo, ld, out.data_ptr(), d, M, d, 2 if p.f16 else 3, _stream()), "ns2_join_f32")
     return out
 
 
 class PackedWeight:
     """Library-owned packed weight (ns2_weight)."""
 
-    def __init__(self, w: torch.Tensor, geglu: bool = False, extra1x1: Optional[torch.Tensor] = None):
+    def __init__(self, w: torch.Tensor, geglu: bool = False, extra1x1: Optional[torch.Tensor] = None, precision: int = 3):
+        """precision 1 / 3: interleaved bf16 planes (serve both); 2: dense IEEE half (serves precision 2 only)"""
         import ctypes
         w = _f32(w)
+        self.f16 = precision == 2
         self.rows, self.cols = w.shape[0], w.shape[1]
         self.taps = w.shape[2] if w.ndim == 3 else 1
         self.geglu = geglu
@@ -100,8 +117,8 @@ class PackedWeight:
         self.cols_p = round_up(self.cols, 32)
         h = ctypes.c_void_p()
         ex = _f32(extra1x1) if extra1x1 is not None else None
-        check(_lib.load().ns2_weight_pack(w.data_ptr(), self.rows, self.cols, self.taps, int(geglu), _p(ex), ctypes.byref(h),
-                                          _stream()), "ns2_weight_pack")
+        check(_lib.load().ns2_weight_pack(w.data_ptr(), self.rows, self.cols, self.taps, int(geglu), _p(ex), precision,
+                                          ctypes.byref(h), _stream()), "ns2_weight_pack")
         self.handle = h
 
     def __del__(self):
@@ -126,7 +143,7 @@ def linear_split(w: PackedWeight, a: Planes, bias=None, conv_taps=0, dilation=1,
                  act=0) -> Planes:
     M = a.rows
     ldo = ldo or round_up(w.rows, 32)
-    out = empty_planes(M, ldo, a.device)
+    out = empty_planes(M, ldo, a.device, **_pfmt(precision))
     check(_lib.load().ns2_linear_split(w.handle, a.hi, a.lo, a.ld, M, conv_taps, dilation, seq_len, _p(bias),
                                        out.hi, out.lo, ldo, pad_left, act, precision, _stream()), "ns2_linear_split")
     return out
@@ -143,7 +160,7 @@ def linear_geglu(w: PackedWeight, a: Planes, packed_bias: torch.Tensor, precisio
     M = a.rows
     f = w.rows // 2
     ldo = round_up(f, 32)
-    out = empty_planes(M, ldo, a.device)
+    out = empty_planes(M, ldo, a.device, **_pfmt(precision))
     check(_lib.load().ns2_linear_geglu(w.handle, a.hi, a.lo, a.ld, M, packed_bias.data_ptr(), out.hi,
                                        out.lo, ldo, precision, _stream()), "ns2_linear_geglu")
     return out
@@ -154,9 +171,9 @@ def linear_qkv(w: PackedWeight, a: Planes, seq_len: int, split_col: int, precisi
     M = a.rows
     B = M // seq_len
     vt_ld = round_up(seq_len, 32)
-    out = empty_planes(M, split_col, a.device)
+    out = empty_planes(M, split_col, a.device, **_pfmt(precision))
     vt_rows = w.rows - split_col
-    vt = empty_planes(B * vt_rows, vt_ld, a.device, zero=True)
+    vt = empty_planes(B * vt_rows, vt_ld, a.device, zero=True, **_pfmt(precision))
     check(_lib.load().ns2_linear_qkv(w.handle, a.hi, a.lo, a.ld, M, seq_len, split_col, out.hi,
                                      out.lo, split_col, vt.hi, vt.lo, vt_ld, precision, _stream()),
           "ns2_linear_qkv")
@@ -167,7 +184,7 @@ def wavenet_block(w: PackedWeight, a: Planes, seq_len: int, dilation: int, conv_
                   precision=3) -> Planes:
     M = a.rows
     ldo = round_up(w.rows, 32)
-    out = empty_planes(M, ldo, a.device)
+    out = empty_planes(M, ldo, a.device, **_pfmt(precision))
     check(_lib.load().ns2_wavenet_block(w.handle, a.hi, a.lo, a.ld, M, seq_len, dilation, conv_bias.data_ptr(),
                                         res_bias.data_ptr(), _f32(film).data_ptr(), film.shape[1], out.hi,
                                         out.lo, ldo, precision, _stream()), "ns2_wavenet_block")
@@ -177,7 +194,7 @@ def wavenet_block(w: PackedWeight, a: Planes, seq_len: int, dilation: int, conv_
 def attention(q: Planes, k: Planes, vt: Planes, B: int, H: int, Nq: int, Nk: int, q_col0=0, k_col0=0, scale=0.125,
               precision=3, key_mask: Optional[torch.Tensor] = None) -> Planes:
     """vt: transposed value planes [B * H*64, vt_ld]; key_mask: optional bool/uint8 [B, Nk], True = attend (ATT:92-94)."""
-    out = empty_planes(B * Nq, H * 64, q.device)
+    out = empty_planes(B * Nq, H * 64, q.device, **_pfmt(precision))
     km = None
     if key_mask is not None:
         km = key_mask.to(torch.uint8).contiguous()
@@ -188,14 +205,14 @@ def attention(q: Planes, k: Planes, vt: Planes, B: int, H: int, Nq: int, Nk: int
     return out
 
 
-def rmsnorm(x: torch.Tensor, seq_len: int = 0, gamma=None, cond=None, want_f32=False):
+def rmsnorm(x: torch.Tensor, seq_len: int = 0, gamma=None, cond=None, want_f32=False, precision: int = 3):
     x = _f32(x)
     M, d = x.shape
     ldo = round_up(d, 32)
-    out = empty_planes(M, ldo, x.device)
+    out = empty_planes(M, ldo, x.device, **_pfmt(precision))
     of = torch.empty(M, d, dtype=torch.float32, device=x.device) if want_f32 else None
     check(_lib.load().ns2_rmsnorm(x.data_ptr(), d, M, d, seq_len, _p(gamma), _p(cond), cond.shape[1] if cond is not None else 0,
-                                  out.hi, out.lo, ldo, _p(of), d, _stream()), "ns2_rmsnorm")
+                                  out.hi, out.lo, ldo, _p(of), d, precision, _stream()), "ns2_rmsnorm")
     return (out, of) if want_f32 else out
 
 
@@ -208,14 +225,20 @@ def embedding(ids: torch.Tensor, table: torch.Tensor, pad_id: int) -> torch.Tens
     return out
 
 
-def skinny_linear(x: torch.Tensor, wt: torch.Tensor, bias=None, act=0) -> torch.Tensor:
-    """x [B, K] @ wt [K, J] (+bias) ; act 1 = SiLU."""
+def _skinny_ws(B, K, J, device):
+    n = _lib.load().ns2_skinny_linear_workspace_bytes(B, K, J)
+    return torch.empty(max(n, 16), dtype=torch.uint8, device=device), n
+
+
+def skinny_linear(x: torch.Tensor, wt: torch.Tensor, bias=None, act=0, use_workspace=True) -> torch.Tensor:
+    """x [B, K] @ wt [K, J] (+bias) ; act 1 = SiLU.  The split-K scratch is caller-owned (here: a torch tensor)."""
     x, wt = _f32(x), _f32(wt)
     B, K = x.shape
     J = wt.shape[1]
     out = torch.empty(B, J, dtype=torch.float32, device=x.device)
-    check(_lib.load().ns2_skinny_linear(x.data_ptr(), K, wt.data_ptr(), _p(bias), out.data_ptr(), J, B, K, J, act, _stream()),
-          "ns2_skinny_linear")
+    ws, n = _skinny_ws(B, K, J, x.device) if use_workspace else (None, 0)
+    check(_lib.load().ns2_skinny_linear(x.data_ptr(), K, wt.data_ptr(), _p(bias), out.data_ptr(), J, B, K, J, act, _p(ws), n,
+                                        _stream()), "ns2_skinny_linear")
     return out
 
 
@@ -225,8 +248,9 @@ def time_embed(times: torch.Tensor, freqs: torch.Tensor, wt: torch.Tensor, bias:
     dt = wt.shape[1]
     feat = torch.empty(B, dim + 1, dtype=torch.float32, device=times.device)
     out = torch.empty(B, dt, dtype=torch.float32, device=times.device)
+    ws, n = _skinny_ws(B, dim + 1, dt, times.device)
     check(_lib.load().ns2_time_embed(_f32(times).data_ptr(), _f32(freqs).data_ptr(), _f32(wt).data_ptr(), _f32(bias).data_ptr(),
-                                     feat.data_ptr(), out.data_ptr(), dt, B, dim, dt, _stream()), "ns2_time_embed")
+                                     feat.data_ptr(), out.data_ptr(), dt, B, dim, dt, ws.data_ptr(), n, _stream()), "ns2_time_embed")
     return out
 
 

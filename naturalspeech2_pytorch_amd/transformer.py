@@ -7,7 +7,8 @@ import torch
 from torch import nn
 
 from . import ops
-from .model import _Attention, _RMSNorm, _feedforward
+from ._cache import PackedCache
+from .model import _Attention, _RMSNorm, _feedforward, _PRECISIONS
 
 
 class Transformer(nn.Module):
@@ -16,18 +17,19 @@ class Transformer(nn.Module):
         super().__init__()
         assert dim_head == 64, "the HIP attention kernel is specialised for dim_head 64 (the reference default)"
         self.dim, self.depth, self.heads, self.causal, self.dropout = dim, depth, heads, causal, dropout
+        assert precision in _PRECISIONS, f"precision must be one of {sorted(_PRECISIONS)}"
         self.precision = precision
         self.layers = nn.ModuleList([
             nn.ModuleList([_RMSNorm(dim), _Attention(dim, dim_head, heads), _RMSNorm(dim), _feedforward(dim, ff_mult, False)])
             for _ in range(depth)])
         self.norm = _RMSNorm(dim) if final_norm else nn.Identity()
-        self._packed = None
-        self._sig = None
+        self._cache = PackedCache()
 
     def _pack(self):
-        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if self._packed is not None and self._sig == sig:
-            return self._packed
+        return self._cache.get(self.parameters(), self._build_packed, extra=(self.precision,))
+
+    def _build_packed(self):
+        prec = _PRECISIONS[self.precision]
         packed = []
         for norm1, attn, norm2, ff in self.layers:
             wqkv = torch.cat((attn.to_q.weight, attn.to_kv.weight), dim=0).detach().float().contiguous()
@@ -35,11 +37,11 @@ class Transformer(nn.Module):
             f = w1.weight.shape[0] // 2
             packed.append(dict(
                 g1=norm1.gamma.detach().float().contiguous(), g2=norm2.gamma.detach().float().contiguous(),
-                qkv=ops.PackedWeight(wqkv), out=ops.PackedWeight(attn.to_out.weight.detach().float().contiguous()),
-                w1=ops.PackedWeight(w1.weight.detach().float().contiguous(), geglu=True),
+                qkv=ops.PackedWeight(wqkv, precision=prec),
+                out=ops.PackedWeight(attn.to_out.weight.detach().float().contiguous(), precision=prec),
+                w1=ops.PackedWeight(w1.weight.detach().float().contiguous(), geglu=True, precision=prec),
                 b1=ops.geglu_pack_bias(w1.bias.detach().float().contiguous(), f),
-                w2=ops.PackedWeight(w2.weight.detach().float().contiguous()), b2=w2.bias.detach().float().contiguous()))
-        self._packed, self._sig = packed, sig
+                w2=ops.PackedWeight(w2.weight.detach().float().contiguous(), precision=prec), b2=w2.bias.detach().float().contiguous()))
         return packed
 
     @torch.no_grad()
@@ -50,15 +52,15 @@ class Transformer(nn.Module):
         if self.training and self.dropout > 0:
             raise NotImplementedError("attention dropout is a training-time feature; the HIP path is inference-only")
         b, n, d = x.shape
-        prec = 3 if self.precision == "exact" else 1
+        prec = _PRECISIONS[self.precision]
         a = self.heads * 64
         h = x.reshape(b * n, d).float().contiguous()
         for pk in self._pack():
-            xn = ops.rmsnorm(h, gamma=pk["g1"])
+            xn = ops.rmsnorm(h, gamma=pk["g1"], precision=prec)
             qk, vt = ops.linear_qkv(pk["qkv"], xn, seq_len=n, split_col=2 * a, precision=prec)
             o = ops.attention(qk, qk, vt, b, self.heads, n, n, q_col0=0, k_col0=a, precision=prec, key_mask=mask)
             h = ops.linear_f32(pk["out"], o, resid=h, precision=prec)
-            xn = ops.rmsnorm(h, gamma=pk["g2"])
+            xn = ops.rmsnorm(h, gamma=pk["g2"], precision=prec)
             ffh = ops.linear_geglu(pk["w1"], xn, pk["b1"], precision=prec)
             h = ops.linear_f32(pk["w2"], ffh, bias=pk["b2"], resid=h, precision=prec)
         if isinstance(self.norm, _RMSNorm):

@@ -70,6 +70,18 @@ def fp8_cross(which):
         return y
     return f
 
+def f16_e5m2_cross(lo_fmt=torch.float8_e5m2):
+    """fp16 hi.hi on the f16 MFMA + both cross terms in ONE fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): hi8 = e5m2(x)
+    (the top byte of the fp16 word, RNE), lo8 = fmt((x - fp16(x)) * 2^12) with the constant 2^-12 applied as the MFMA's block scale"""
+    def q(x, fmt): return x.float().to(fmt).double()
+    def f(a, w, contract):
+        ah = a.float().to(FH).double(); wh = w.float().to(FH).double()
+        al = a.double() - ah; wl = w.double() - wh
+        a8, w8 = q(ah, torch.float8_e5m2), q(wh, torch.float8_e5m2)
+        al8, wl8 = q(al * 4096.0, lo_fmt) / 4096.0, q(wl * 4096.0, lo_fmt) / 4096.0
+        return contract(ah, wh) + contract(a8, wl8) + contract(al8, w8)
+    return f
+
 SCHEMES = [
     Scheme("bf16 x3  hi.hi+hi.lo+lo.hi (current exact)", 3.0, mk(BF, [(0, 0), (0, 1), (1, 0)])),
     Scheme("bf16 x1  hi.hi (current fast)", 1.0, mk(BF, [(0, 0)])),
@@ -82,6 +94,8 @@ SCHEMES = [
     Scheme("fp16 x1 GEMMs, fp16 x3 attention products", 1.2, mk(FH, [(0, 0)]), mk(FH, [(0, 0), (0, 1), (1, 0)])),
     Scheme("fp16 x3 GEMMs, fp16 x1 attention products", 2.8, mk(FH, [(0, 0), (0, 1), (1, 0)]), mk(FH, [(0, 0)])),
     Scheme("fp16 x1, but x3 for Linears writing the residual stream", 1.2, mk(FH, [(0, 0)]), None, mk(FH, [(0, 0), (0, 1), (1, 0)])),
+    Scheme("fp16 hi.hi + cross terms fp8 e5m2 x e5m2(lo*2^12)", 2.0, f16_e5m2_cross()),
+    Scheme("fp16 hi.hi + cross terms fp8 e5m2 x e4m3(lo*2^12)", 2.0, f16_e5m2_cross(torch.float8_e4m3fn)),
     Scheme("bf16 hi.hi + both cross terms on fp8(e4m3, MX32)", 2.0, fp8_cross("aw wa")),
     Scheme("bf16 hi.hi + both cross terms on fp8, one scale per row", 2.0, fp8_cross_row()),
     Scheme("bf16 hi.hi + lo.hi bf16 + hi.lo on fp8", 2.5, fp8_cross("aw")),
@@ -117,6 +131,7 @@ def main():
     ap.add_argument("--dim", type=int, default=128); ap.add_argument("--depth", type=int, default=6)
     ap.add_argument("--n", type=int, default=256); ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--seeds", type=int, default=2)
+    ap.add_argument("--times", type=float, default=None, help="fix the diffusion time of every utterance")
     ap.add_argument("--only", default="", help="comma-separated substrings of scheme names to run")
     a = ap.parse_args()
     global DIM
@@ -131,10 +146,12 @@ def main():
             m = Model(dim=a.dim, depth=a.depth)
             sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
             x = torch.randn(a.batch, a.n, a.dim); t = torch.rand(a.batch)
+            if a.times is not None: t = torch.full((a.batch,), a.times)
             with torch.no_grad(): ref = O.model_forward(sd, x, t).double()
             y = run(sd, x, t, sc, big_rows=a.batch * 8).double()
             errs.append(((y - ref).norm() / ref.norm()).item())
         rows.append((sc.name, sc.units, max(errs)))
+        print("    per seed: " + " ".join(f"{e:.2e}" for e in errs))
         print(f"  {sc.name:52s} MFMA units {sc.units:3.1f}   rel err (max over {a.seeds} seeds) {max(errs):.2e}", flush=True)
 
 if __name__ == "__main__":
