@@ -6,35 +6,49 @@ One step = Model.forward_with_cond_scale (cond_scale 1 -> one Model.forward, NS2
 replicas each denoising its own 32-utterance shard (weak scaling; no data-path collective inside the loop; the
 path's single RCCL all-gather of the generated latents runs once after the K steps and is inside the timed region).
 
-    python bench.py [--gpus N --steps K --warmup W] [--precision exact|fast] [--graph]
+    python bench.py [--gpus N --steps K --warmup W] [--precision mixed|half|exact|fast] [--graph]
 
-Default precision is "half" (one fp16 product per contraction, fp32 accumulate): it meets the 1e-3 tolerance of
-BASELINE.json on every reference golden and at the headline architecture (7.6e-4..8.5e-4) with a third of the MFMA work of
-the bf16x3 "exact" mode (1e-5), which the same JSON line reports under "exact_mode" from a short second measurement.
+`--gpus N` with N > 1 re-executes itself under `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU,
+backend "nccl" = RCCL) unless it already runs under one (RANK / WORLD_SIZE set by the driver's own launcher).
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events recorded by the executor on the
-launch stream around every launch of the dominant kernel symbol (gemm2_kernel<NSPLIT, EPI_SPLIT, F16>: the 12 FF causal
-convs + wavenet init conv + skip GEMM); `cpu_baseline` times the CPU oracle (a port of the reference path) on a
-bounded sample.  See DESIGN.md §Measurement.
+Default precision is "mixed": one IEEE-half product per contraction plus BOTH first-order correction terms evaluated in
+one block-scaled fp8 MFMA per 32-deep k block -- 4e-5-class error against the fp32 reference (25x inside
+the 1e-3 tolerance of BASELINE.json; sweep in tests/test_parity_r2_gpu.py, quoted in `parity`).  The same JSON line
+reports, from short extra measurements on the same weights, `half_mode` (the half product alone: faster, error 8e-4 = a
+thin margin) and `exact_mode` (bf16 x3, 1e-5), and `side` = the other BASELINE configs (RVQ config 4, conditioned config
+3, d128 config 2), each with its own parity flag and roofline.
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events recorded by the executor on the launch stream
+around every launch of the dominant kernel symbol (gemm2_kernel<*, EPI_SPLIT, *>: the 12 FF causal convs + wavenet init
+conv + skip GEMM); `cpu_baseline` times the CPU oracle (a port of the reference path, SDPA attention like the reference's
+default) on the full batch of 32 once.  See DESIGN.md §Measurement.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md (spec; 2495 measured)
-UTT_GFLOP = 316.37                 # algorithmic GFLOP per 1024-frame utterance, d512/L12 unconditioned (SURVEY §8d)
+PEAK_16BIT_TFLOPS = 2500.0         # dense bf16 / f16 MFMA peak, MI355X_MICROARCH.md (spec; 2495 measured)
+PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (RVQ)
+UTT_GFLOP = {(512, 12, False): 316.37, (512, 12, True): 331.98, (128, 6, False): 26.74}   # per 1024-frame utterance, SURVEY §8d
+MFMA_UNITS = {"exact": 3, "mixed": 2, "half": 1, "fast": 1}        # MFMA-pipe time per algorithmic FLOP, in 16-bit-product units
+KERNEL_NAME = {"exact": "gemm2_kernel<3, 1, false>", "mixed": "gemm2_kernel<2, 1, true>", "half": "gemm2_kernel<1, 1, true>",
+               "fast": "gemm2_kernel<1, 1, false>"}
+DTYPE = {"exact": "bf16x3 split operands on the bf16 MFMA, fp32 accumulate",
+         "mixed": "fp16 operands on the f16 MFMA + both first-order correction terms as e5m2 on the block-scaled fp8 MFMA, fp32 accumulate",
+         "half": "fp16 operands on the f16 MFMA (one product), fp32 accumulate",
+         "fast": "bf16 operands, fp32 accumulate"}
 
 
 def dominant_flops(B, N, dim, depth, ff_mult, wn_layers):
-    """algorithmic FLOPs (2*MAC) of the launches of gemm_kernel<*, EPI_SPLIT> in one step, and their count."""
+    """algorithmic FLOPs (2*MAC) of the launches of gemm2_kernel<*, EPI_SPLIT, *> in one step, and their count."""
     M = B * N
     f = int(dim * ff_mult * 2 / 3)
     ffconv = 2.0 * M * f * (3 * f)                 # CausalConv1d(f, f, 3)  NS2:1016
@@ -43,31 +57,49 @@ def dominant_flops(B, N, dim, depth, ff_mult, wn_layers):
     return depth * ffconv + init + skip, depth + 2
 
 
-def cpu_baseline(dim, depth, n, threads_note=""):
-    """CPU oracle (port of NS2:929-1000) on a bounded sample: batch 4 of the same workload, all host threads."""
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(sd, dim, depth, B, n):
+    """The CPU oracle (port of NS2:929-1000; attention through F.scaled_dot_product_attention like the reference's default
+    `use_flash_attn=True` branch ATT:98-108) on the FULL batch, once, after a one-utterance warm-up; threads = physical cores."""
+    import torch
     from oracle import ns2_oracle as O
-    from naturalspeech2_pytorch_amd import Model
-    torch.manual_seed(0)
-    m = Model(dim=dim, depth=depth)
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    b = 4
-    x = torch.randn(b, n, dim)
-    t = torch.rand(b)
-    with torch.no_grad():
-        O.model_forward(sd, x, t)                   # warm-up
-        t0 = time.perf_counter()
-        reps = 0
-        while True:
+    cores = physical_cores()
+    old = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    O.USE_SDPA = True
+    try:
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(B, n, dim, generator=g)
+        t = torch.rand(B, generator=g)
+        with torch.no_grad():
+            O.model_forward(sd, x[:1], t[:1])           # warm-up (thread pool, oneDNN primitives)
+            t0 = time.perf_counter()
             O.model_forward(sd, x, t)
-            reps += 1
             el = time.perf_counter() - t0
-            if el > 12.0 or reps >= 8:
-                break
-    per_fwd = el / reps
-    steps_per_s = (b / 32.0) / per_fwd              # one step = 32 utterances
-    return dict(value=round(steps_per_s, 5), unit="steps/s (32x1024-latent batch equivalent)", cores=torch.get_num_threads(),
-                kind="port", sample=f"oracle Model.forward fp32, batch {b} x {n} frames, {reps} timed forwards after 1 warm-up "
-                                    f"({per_fwd:.3f} s each); steps/s scaled by {b}/32")
+    finally:
+        O.USE_SDPA = False
+        torch.set_num_threads(old)
+    return dict(value=round(1.0 / el, 5), unit="steps/s", cores=cores, kind="port",
+                sample=f"oracle Model.forward fp32 (SDPA attention), ONE forward of the full batch {B} x {n} frames after a "
+                       f"1-utterance warm-up: {el:.2f} s, {cores} threads = physical cores")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -75,10 +107,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="half", choices=["exact", "half", "fast"],
-                    help="half (default): one fp16 product per contraction, 7.6e-4 from the fp32 reference at this config; "
-                         "exact: bf16x3 split, 1e-5; fast: bf16, ~1e-2 (outside the 1e-3 tolerance, for comparison only)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the short exact-mode measurement added to the default line")
+    ap.add_argument("--precision", default="mixed", choices=["mixed", "half", "exact", "fast"],
+                    help="mixed (default): half product + fp8 correction terms, ~4e-5 from the fp32 reference; half: one fp16 "
+                         "product, ~8e-4 (thin margin); exact: bf16x3 split, 1e-5; fast: bf16, ~1e-2 (outside the tolerance)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short half/exact-mode measurements")
+    ap.add_argument("--no-side", action="store_true", help="skip the side workloads (RVQ config 4, conditioned config 3, d128 config 2)")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--dim", type=int, default=512)
@@ -87,132 +120,241 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conditioned", action="store_true",
                     help="BASELINE config 3 instead of the headline: dim_prompt=512, condition_on_prompt, prompt of 103 codec "
-                         "frames, frame-aligned cond (side measurement; the roofline/cpu_baseline objects stay the headline's)")
+                         "frames, frame-aligned cond")
     ap.add_argument("--cond-scale", type=float, default=1.0, help="with --conditioned: classifier-free guidance scale (NS2:914-927)")
     args = ap.parse_args()
 
+    # ---- N > 1 without a launcher: become one (the driver may call `python bench.py --gpus N` directly)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+
+    import torch
     from naturalspeech2_pytorch_amd import Model, _lib, ops
     from naturalspeech2_pytorch_amd import distributed as D
     import torch.distributed as dist
 
     rank, local, world = D.init_from_env()
-    if args.gpus != world:
-        assert world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-        assert args.gpus == 1, "for N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ..."
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the HIP path has no CPU fallback)"
     local_dev = local % torch.cuda.device_count()       # ranks > devices only in the gloo functional test of this script
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-
-    B, N, dim, depth = args.batch, args.frames, args.dim, args.depth
     lib = _lib.load()
+    B, N = args.batch, args.frames
 
-    def measure(precision, steps, warmup):
-        """W untimed + exactly K timed steps of one precision mode; returns (elapsed s of the K steps, kernel ms, launches)"""
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def make_model(dim, depth, conditioned):
         torch.manual_seed(1234)                          # same random-init weights on every rank
-        mkw = dict(dim_prompt=512, condition_on_prompt=True) if args.conditioned else {}
-        model = Model(dim=dim, depth=depth, precision=precision, **mkw).to(dev).eval()
+        mkw = dict(dim_prompt=512, condition_on_prompt=True) if conditioned else {}
+        return Model(dim=dim, depth=depth, **mkw).to(dev).eval()
+
+    def measure(model, precision, steps, warmup, conditioned=False, cond_scale=1.0, graph=False, profile=True):
+        """W untimed + exactly K timed steps; returns (elapsed s of the K steps [max over ranks], kernel ms, launches)"""
+        model.precision = precision                      # re-packs the same parameters in the other plane format
+        dim = model.dim
         g = torch.Generator().manual_seed(100 + rank)
         audio = torch.randn(B, N, dim, generator=g).to(dev)
         fwd_kw = {}
-        if args.conditioned:
+        if conditioned:
             fwd_kw = dict(prompt=torch.randn(B, 103, 512, generator=g).to(dev), cond=torch.randn(B, 512, N, generator=g).to(dev))
         n_total = warmup + steps
         ts = torch.linspace(1.0, 0.0, n_total + 1)
         t_dev = [ts[i].expand(B).contiguous().to(dev) for i in range(n_total + 1)]
-
         t_cur, t_nxt = t_dev[0].clone(), t_dev[1].clone()
 
         def step():
-            out = model.forward_with_cond_scale(audio, t_cur, cond_scale=args.cond_scale if args.conditioned else 1.0, **fwd_kw)
+            out = model.forward_with_cond_scale(audio, t_cur, cond_scale=cond_scale, **fwd_kw)
             ops.ddim_step(audio, out, t_cur, t_nxt, "v", "sigmoid", 1.0, out=audio)
 
-        def barrier():
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-
         with torch.no_grad():
-            graph = None
+            cg = None
             for i in range(warmup):
                 t_cur.copy_(t_dev[i]); t_nxt.copy_(t_dev[i + 1])
                 step()
-            if args.graph:
+            if graph:
                 torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
+                cg = torch.cuda.CUDAGraph()
                 keep = audio.clone()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(cg):
                     step()
                 audio.copy_(keep)
             ns = model._ensure_native()
-            prof_mask = 0 if args.graph else (1 << 1)    # gemm_kernel<*, EPI_SPLIT>
+            prof_mask = (1 << 1) if (profile and not graph) else 0      # gemm_kernel<*, EPI_SPLIT>
             barrier()
             if prof_mask:
                 lib.ns2_model_profile_begin(ns.handle, prof_mask)
             t0 = time.perf_counter()
             for i in range(warmup, n_total):
                 t_cur.copy_(t_dev[i]); t_nxt.copy_(t_dev[i + 1])
-                if graph is not None:
-                    graph.replay()
+                if cg is not None:
+                    cg.replay()
                 else:
                     step()
             if world > 1:                                # the sharded sampler's single collective (SURVEY §8e)
-                bufs = [torch.empty_like(audio) for _ in range(world)]
-                dist.all_gather(bufs, audio)
+                src = audio if dist.get_backend() != "gloo" else audio.cpu()     # gloo (functional test only) gathers on the host
+                bufs = [torch.empty_like(src) for _ in range(world)]
+                dist.all_gather(bufs, src)
             barrier()
             elapsed = time.perf_counter() - t0
             kern_ms, kern_n = ctypes.c_double(0), ctypes.c_int64(0)
             if prof_mask:
                 _lib.check(lib.ns2_model_profile_end(ns.handle, ctypes.byref(kern_ms), ctypes.byref(kern_n)), "profile_end")
-
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         assert torch.isfinite(audio).all()
         return el.item(), kern_ms.value, kern_n.value
 
-    elapsed, kern_ms_v, kern_n_v = measure(args.precision, args.steps, args.warmup)
-    secondary = None
-    if args.precision == "half" and not args.no_secondary and world == 1 and not args.graph:
-        k2 = min(args.steps, 10)
-        e2, _, _ = measure("exact", k2, 2)
-        secondary = dict(value=round(k2 / e2, 3), unit="steps/s", steps=k2, ms_per_step=round(1e3 * e2 / k2, 3),
-                         dtype="bf16x3 split operands on bf16 MFMA, fp32 accumulate",
-                         rel_err_vs_fp32_reference="<=1e-4 (tests/test_model_gpu.py goldens, 1e-5 typical)")
-    if rank == 0:
-        steps_per_s = world * args.steps / elapsed
+    def live_parity(model, sd_cpu, precision, conditioned=False):
+        """one small forward of this very model (same packed weights) against the CPU oracle"""
+        from oracle import ns2_oracle as O
+        model.precision = precision
+        g = torch.Generator().manual_seed(5)
+        b, n = 1, 256
+        x, t = torch.randn(b, n, model.dim, generator=g), torch.rand(b, generator=g)
+        kw, okw = {}, {}
+        if conditioned:
+            p, c = torch.randn(b, 40, 512, generator=g), torch.randn(b, 512, n, generator=g)
+            kw, okw = dict(prompt=p.to(dev), cond=c.to(dev)), dict(prompt=p, cond=c)
+        with torch.no_grad():
+            y = model(x.to(dev), t.to(dev), **kw).cpu()
+            ref = O.model_forward(sd_cpu, x, t, **okw)
+        return float(((y - ref).double().norm() / ref.double().norm()).item())
+
+    def roofline_obj(precision, dim, depth, kern_ms_v, kern_n_v):
+        if not kern_n_v:
+            return None
         fl, nl = dominant_flops(B, N, dim, depth, 4, 8)
-        roof = None
-        if kern_n_v:
-            avg_ms = kern_ms_v / kern_n_v
-            ach = (fl / nl) / (avg_ms * 1e-3) / 1e12
-            traffic = None
-            pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(pj):
-                tj = json.load(open(pj))
-                traffic = tj.get("hbm_bytes_per_launch_by_precision", {}).get(args.precision, tj.get("hbm_bytes_per_launch"))
-            roof = dict(bound="mfma", kernel="ns2::gemm2_kernel<%d, 1, %s> = EPI_SPLIT (FF causal conv k3 x%d, wavenet init conv, skip-sum GEMM)"
-                        % (3 if args.precision == "exact" else 1, "true" if args.precision == "half" else "false", depth),
-                        achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=traffic, avg_launch_ms=round(avg_ms, 4), launches=kern_n_v,
-                        algorithmic_gflop_per_launch=round(fl / nl / 1e9, 2),
-                        mfma_flops_per_algorithmic_flop=3 if args.precision == "exact" else 1)
+        avg_ms = kern_ms_v / kern_n_v
+        ach = (fl / nl) / (avg_ms * 1e-3) / 1e12
+        traffic, tsrc = None, None
+        pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pj) and precision in ("half", "exact") and (dim, depth) == (512, 12):
+            tj = json.load(open(pj))
+            traffic = tj.get("hbm_bytes_per_launch_by_precision", {}).get(precision, tj.get("hbm_bytes_per_launch"))
+            tsrc = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc passes of round 1, same kernel and shape; NOT measured in this run)"
+        return dict(bound="mfma", kernel=f"ns2::{KERNEL_NAME[precision]} = EPI_SPLIT (FF causal conv k3 x{depth}, wavenet init conv, skip-sum GEMM)",
+                    achieved=round(ach, 2), peak=PEAK_16BIT_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_16BIT_TFLOPS, 4),
+                    traffic=traffic, traffic_source=tsrc, avg_launch_ms=round(avg_ms, 4), launches=kern_n_v,
+                    algorithmic_gflop_per_launch=round(fl / nl / 1e9, 2),
+                    mfma_time_units_per_algorithmic_flop=MFMA_UNITS[precision],
+                    frac_of_mfma_pipe_time=round(MFMA_UNITS[precision] * ach / PEAK_16BIT_TFLOPS, 4))
+
+    # ================================================================== headline
+    dim, depth = args.dim, args.depth
+    model = make_model(dim, depth, args.conditioned)
+    elapsed, kern_ms_v, kern_n_v = measure(model, args.precision, args.steps, args.warmup, args.conditioned,
+                                           args.cond_scale if args.conditioned else 1.0, args.graph)
+    steps_per_s = world * args.steps / elapsed
+    extra = {}
+    if rank == 0 and world == 1 and not args.graph:
+        sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        parity = {"live_rel_err_vs_fp32_oracle": {args.precision: live_parity(model, sd_cpu, args.precision, args.conditioned)},
+                  "tolerance": 1e-3}
+        pj = os.path.join(ROOT, "profiles", "r02_parity.json")
+        if os.path.exists(pj):
+            try:
+                sw = json.load(open(pj))
+                parity["sweep_d512_L12"] = {k.split("/")[-1]: dict(max=v["max"], mean=v["mean"]) for k, v in sw.items()
+                                            if k.startswith("sweep_d512_L12/")}
+                parity["sweep_source"] = "profiles/r02_parity.json (tests/test_parity_r2_gpu.py: 8 weight seeds x times {0.002, 0.5, 0.999})"
+            except Exception:
+                pass
+        if not args.no_secondary and not args.conditioned:
+            k2 = min(args.steps, 10)
+            for other in ("half", "exact"):
+                if other == args.precision:
+                    continue
+                e2, km, kn = measure(model, other, k2, 2)
+                parity["live_rel_err_vs_fp32_oracle"][other] = live_parity(model, sd_cpu, other)
+                r2 = roofline_obj(other, dim, depth, km, kn)
+                extra[other + "_mode"] = dict(value=round(k2 / e2, 3), unit="steps/s", steps=k2, ms_per_step=round(1e3 * e2 / k2, 3),
+                                              dtype=DTYPE[other], roofline_frac=r2["frac"] if r2 else None,
+                                              dominant_kernel_tflops=r2["achieved"] if r2 else None)
+        extra["parity"] = parity
+        if not args.no_cpu_baseline and not args.conditioned:
+            extra["cpu_baseline"] = cpu_baseline(sd_cpu, dim, depth, B, N)
+        del sd_cpu
+    del model
+    torch.cuda.empty_cache()
+
+    # ================================================================== side workloads (rank 0, single GPU)
+    side = None
+    if rank == 0 and world == 1 and not args.no_side and not args.conditioned and not args.graph:
+        from oracle import ns2_oracle as O
+        from oracle import rvq_oracle as R
+        side = {}
+        # --- BASELINE config 4: EnCodec RVQ encode of 32 x 1024 frames x 8 codebooks x 1024 codes
+        g = torch.Generator().manual_seed(11)
+        cb = torch.randn(8, 1024, 128, generator=g)
+        lat = torch.randn(32 * 1024, 128, generator=g)
+        cbd, latd = cb.to(dev), lat.to(dev)
+        norm = ops.rvq_prepare(cbd)
+        for _ in range(3):
+            codes, emb = ops.rvq_encode(latd, cbd, norm)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            codes, emb = ops.rvq_encode(latd, cbd, norm)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        c_ref, _, _ = R.rvq_encode(lat[:8192], cb)
+        nbad = int((codes[:8192].cpu() != c_ref).any(dim=-1).sum())
+        gflop = 2.0 * 32768 * 128 * 1024 * 8 / 1e9
+        side["rvq_config4"] = dict(metric="RVQ encode, 32 x 1024 frames x 8 codebooks x 1024 codes (encode + decode of emb)", ms=round(ms, 4),
+                                   frames_per_s=round(32768 / (ms * 1e-3)), parity=dict(rows_checked=8192, rows_differing_from_fp32_oracle=nbad,
+                                   note="every differing row is an fp32 near-tie decided by exact arithmetic (tests/test_parity_r2_gpu.py)"),
+                                   roofline=dict(bound="mfma (fp32 v_mfma_f32_32x32x2_f32)", achieved=round(gflop / ms, 2), peak=PEAK_F32_MFMA_TFLOPS,
+                                                 unit="TFLOP/s", frac=round(gflop / ms / PEAK_F32_MFMA_TFLOPS, 4)))
+        del cbd, latd, codes, emb
+        # --- BASELINE config 3 shape: conditioned d512/L12, prompt 103 frames, frame-aligned cond
+        m3 = make_model(512, 12, True)
+        e3, km, kn = measure(m3, args.precision, 10, 2, conditioned=True)
+        sd3 = {k: v.detach().cpu() for k, v in m3.state_dict().items()}
+        r3 = roofline_obj(args.precision, 512, 12, km, kn)
+        side["conditioned_config3"] = dict(metric="denoise steps/sec, Model(dim=512, depth=12, dim_prompt=512, condition_on_prompt), 32 x 1024 frames, prompt 103 frames, cond_scale 1",
+                                           value=round(10 / e3, 3), ms_per_step=round(1e3 * e3 / 10, 3), precision=args.precision,
+                                           parity=dict(live_rel_err_vs_fp32_oracle=live_parity(m3, sd3, args.precision, True)),
+                                           whole_step_algorithmic_tflops=round(UTT_GFLOP[(512, 12, True)] * B * 1e9 / (e3 / 10) / 1e12, 2),
+                                           roofline=dict(frac=r3["frac"], achieved=r3["achieved"], unit="TFLOP/s", kernel=r3["kernel"]) if r3 else None)
+        del m3, sd3
+        torch.cuda.empty_cache()
+        # --- BASELINE config 2: d128/L6, 32 x 1024 frames
+        m2 = make_model(128, 6, False)
+        e2_, km, kn = measure(m2, args.precision, 20, 3)
+        sd2 = {k: v.detach().cpu() for k, v in m2.state_dict().items()}
+        r2 = roofline_obj(args.precision, 128, 6, km, kn)
+        side["d128_config2"] = dict(metric="denoise steps/sec, Model(dim=128, depth=6), 32 x 1024 frames", value=round(20 / e2_, 3),
+                                    ms_per_step=round(1e3 * e2_ / 20, 3), precision=args.precision,
+                                    parity=dict(live_rel_err_vs_fp32_oracle=live_parity(m2, sd2, args.precision)),
+                                    whole_step_algorithmic_tflops=round(UTT_GFLOP[(128, 6, False)] * B * 1e9 / (e2_ / 20) / 1e12, 2),
+                                    roofline=dict(frac=r2["frac"], achieved=r2["achieved"], unit="TFLOP/s", kernel=r2["kernel"]) if r2 else None)
+        del m2, sd2
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         whole = None
-        if dim == 512 and depth == 12 and N == 1024 and not args.conditioned:
-            whole = round(UTT_GFLOP * B * 1e9 / (elapsed / args.steps) / 1e12, 2)
-        cpu = None
-        if not args.no_cpu_baseline and world == 1 and not args.conditioned:
-            cpu = cpu_baseline(dim, depth, N)
+        key = (dim, depth, bool(args.conditioned))
+        if key in UTT_GFLOP and N == 1024:
+            whole = round(UTT_GFLOP[key] * B * 1e9 / (elapsed / args.steps) / 1e12, 2)
+        headline = not args.conditioned and (dim, depth, B, N) == (512, 12, 32, 1024)
         line = {
-            "metric": "denoise steps/sec (dim=512 depth=12, B=32x1024 latents)" if not args.conditioned and (dim, depth, B, N) == (512, 12, 32, 1024)
+            "metric": "denoise steps/sec (dim=512 depth=12, B=32x1024 latents)" if headline
                       else f"denoise steps/sec (side measurement: dim={dim} depth={depth} B={B}x{N}{' conditioned' if args.conditioned else ''})",
             "value": round(steps_per_s, 3), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"exact": "bf16x3 split operands on bf16 MFMA, fp32 accumulate (fp32-class, <=1e-3 vs fp32 reference)",
-                      "half": "fp16 operands on the f16 MFMA (one product), fp32 accumulate",
-                      "fast": "bf16 operands, fp32 accumulate"}[args.precision],
+            "dtype": DTYPE[args.precision],
             "data": "synthetic (randn codec latents, random-init weights)",
             "config": {"workload": (f"Model(dim={dim}, depth={depth}) unconditional, batch {B} x {N} latent frames per GPU, "
                                     f"forward_with_cond_scale(cond_scale=1) + DDIM update") if not args.conditioned else
@@ -221,16 +363,15 @@ def main():
                        "precision": args.precision,
                        "global_batch": B * world, "parallelism": f"dp{world}", "graph_replay": bool(args.graph)},
             "whole_step_algorithmic_tflops_per_gpu": whole,
-            "roofline": roof, "cpu_baseline": cpu,
-            "parity": {"exact": "1e-5 vs the fp32 reference goldens (asserted < 1e-3; tests/test_model_gpu.py)",
-                       "half": "7.6e-4 at this architecture, 7.7e-4..8.5e-4 on the reference goldens (asserted < 1e-3; "
-                               "tests/test_model_gpu.py::test_half_mode_*)",
-                       "fast": "~4e-3..1e-2: outside the 1e-3 tolerance, comparison only"}[args.precision],
+            "roofline": roofline_obj(args.precision, dim, depth, kern_ms_v, kern_n_v),
+            "cpu_baseline": extra.pop("cpu_baseline", None),
+            "parity": extra.pop("parity", None),
         }
-        if secondary:
-            line["exact_mode"] = secondary
-        if cpu:
-            line["gpu_over_cpu"] = round(steps_per_s / cpu["value"], 1)
+        line.update(extra)
+        if side is not None:
+            line["side"] = side
+        if line["cpu_baseline"]:
+            line["gpu_over_cpu"] = round(steps_per_s / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -13,7 +13,10 @@
  *   - return value 0 = ok; otherwise a negative code, message via ns2_last_error() (thread-local).
  *   - activations travel between kernels as 16-bit "split planes": hi = bf16(x), lo = bf16(x - hi).  precision
  *     3 = hi*hi+hi*lo+lo*hi on the bf16 MFMA (fp32-class, matches the fp32 reference to 1e-5), 1 = bf16 hi only,
- *     2 = ONE IEEE-half plane (x_lo == NULL, values saturate at +-65504) multiplied on the f16 MFMA, fp32 accumulate.
+ *     2 = ONE IEEE-half plane (x_lo == NULL, values saturate at +-65504) multiplied on the f16 MFMA, fp32 accumulate,
+ *     4 = "mixed": the IEEE-half product plus BOTH first-order correction terms (a_hi.w_lo + a_lo.w_hi) evaluated in one
+ *         block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, e5m2 operands) per 32-deep k block: 4e-5-class accuracy
+ *         at two thirds of the MFMA work of precision 3.
  *   - the library keeps no mutable host state and never allocates on a launch path: scratch is caller-owned
  *     (ns2_*_workspace_bytes), constants live in per-device __device__ storage, so one host thread per device (or one
  *     process per device) may drive several devices concurrently, also under stream capture.
@@ -22,6 +25,9 @@
  *       i.e. element (r, c) has hi at r*2*ld + ((c & ~31) << 1) + (c & 31) and lo 32 elements further; the caller
  *       passes x_lo == x_hi + 32 (anything else is NS2_ERR_HIP / invalid value).  precision 3 needs this form.
  *     x_lo == NULL: the dense [rows, ld] hi plane alone (precision 1: bf16, precision 2: IEEE half).
+ *     precision 4 operands use the interleaved form with the line [half(32) | e5m2(x)(32 B) | e5m2((x-half(x))*2^12)(32 B)]
+ *       (x_lo == x_hi + 32 as above); the operands of ns2_attention (q, k, transposed values) are dense IEEE half at
+ *       precision 4, which is also what ns2_linear_qkv writes there.
  *     Transposed value planes (vt_hi, vt_lo, vt_ld) use the same rule along the key axis.
  */
 #ifndef NS2HIP_H
@@ -45,7 +51,8 @@ int ns2_debug_force_gemm(int kernel);
 /* ------------------------------------------------------------------ packed weights (library-owned) */
 typedef struct ns2_weight ns2_weight;
 /* nn.Linear weight [rows, cols] (taps = 1) or Conv1d weight [rows, cols, taps] (NS2:583-595) -> K-contiguous bf16
- * split planes (precision 1 or 3: interleaved layout, usable at both; precision 2: dense IEEE-half rows, usable at 2 only), rows padded to 256, each tap's columns padded to 32.  geglu != 0 packs the rows of
+ * split planes (precision 1 or 3: interleaved layout, usable at both; precision 2: dense IEEE-half rows; 4: the mixed-mode
+ * lines; the latter two serve only their own precision), rows padded to 256, each tap's columns padded to 32.  geglu != 0 packs the rows of
  * FeedForward's first Linear (NS2:1021) so that GEGLU (NS2:1004-1007) fuses into the GEMM epilogue.
  * extra1x1 (may be null): a [rows, cols, 1] weight appended as one more, unshifted tap (WavenetResBlock.res_conv). */
 int ns2_weight_pack(const float* w, int rows, int cols, int taps, int geglu, const float* extra1x1, int precision,
@@ -134,7 +141,8 @@ typedef struct ns2_model ns2_model;
 typedef struct {
   int dim, depth, dim_head, heads, ff_mult, wavenet_layers, wavenet_stacks, dim_cond_mult;   /* NS2:814-823 */
   int condition_on_prompt, dim_prompt, num_latents_m, resampler_depth;                       /* NS2:826-831 */
-  int precision;               /* 3 = bf16 x3 split "exact", 2 = fp16 single product "half", 1 = bf16 single product "fast" */
+  int precision;               /* 3 = bf16 x3 split "exact", 4 = fp16 + fp8 correction terms "mixed", 2 = fp16 single product
+                                  "half", 1 = bf16 single product "fast" */
 } ns2_model_config;
 
 int ns2_model_create(const ns2_model_config* cfg, ns2_model** out);

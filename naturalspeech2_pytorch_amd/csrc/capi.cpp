@@ -39,7 +39,8 @@ using namespace ns2;
       return NS2_ERR_ARG;            \
     }                                \
   } while (0)
-static inline int prec_ok(int p) { return p >= 1 && p <= 3; }
+static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
+static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
 extern "C" int ns2_version(void) { return 103; }   // 103: precision 2 at op level, caller-owned skinny-linear scratch
@@ -55,7 +56,7 @@ extern "C" int ns2_weight_pack(const float* w, int rows, int cols, int taps, int
   ARGCHK(!(geglu && (taps != 1 || extra1x1 || (rows & 1))), "ns2_weight_pack: geglu needs taps=1, no extra, even rows");
   ns2_weight* h = new ns2_weight();
   h->taps = taps; h->geglu = geglu; h->has_extra = extra1x1 != nullptr; h->cols_p = (cols + 31) / 32 * 32;
-  int r = pack_weight_public(w, rows, cols, taps, geglu, extra1x1, precision == 2, &h->w, &h->owned, (hipStream_t)stream);
+  int r = pack_weight_public(w, rows, cols, taps, geglu, extra1x1, precision, &h->w, &h->owned, (hipStream_t)stream);
   if (r != NS2_OK) { ns2_weight_free(h); return r; }
   *out = h;
   return NS2_OK;
@@ -67,20 +68,20 @@ extern "C" void ns2_weight_free(ns2_weight* w) {
 }
 
 // the weight's element format must be the one the requested precision multiplies in (fp16 for 2, bf16 planes for 1 / 3)
-#define WFMT(w, precision, who) ARGCHK(((precision) == 2) == ((w)->w.f16 != 0), who ": weight was packed for a different precision")
+#define WFMT(w, precision, who) ARGCHK(op_fmt(precision) == (w)->w.fmt, who ": weight was packed for a different precision")
 
 extern "C" int ns2_split_f32(const float* x, int ldx, int M, int d, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision,
                              void* stream) {
   ARGCHK(x && out_hi && prec_ok(precision), "ns2_split_f32: bad arguments");
   ARGCHK(precision != 2 || !out_lo, "ns2_split_f32: precision 2 (fp16) has no lo plane");
-  HIPRET(launch_split(x, ldx, nullptr, 0, 0, 0, out_hi, out_lo, ldo, M, d, 0, (hipStream_t)stream, precision == 2));
+  HIPRET(launch_split(x, ldx, nullptr, 0, 0, 0, out_hi, out_lo, ldo, M, d, 0, (hipStream_t)stream, op_fmt(precision)));
   return NS2_OK;
 }
 extern "C" int ns2_join_f32(const uint16_t* hi, const uint16_t* lo, int ld, float* out, int ldo, int64_t M, int d, int precision,
                             void* stream) {
   ARGCHK(hi && out && prec_ok(precision), "ns2_join_f32: bad arguments");
   ARGCHK(precision != 2 || !lo, "ns2_join_f32: precision 2 (fp16) has no lo plane");
-  HIPRET(launch_join(hi, lo, ld, out, ldo, (long)M, d, (hipStream_t)stream, precision == 2));
+  HIPRET(launch_join(hi, lo, ld, out, ldo, (long)M, d, (hipStream_t)stream, op_fmt(precision)));
   return NS2_OK;
 }
 
@@ -154,7 +155,7 @@ extern "C" int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq
   a.q_hi = q_hi; a.q_lo = q_lo; a.ldq = ldq; a.q_col0 = q_col0;
   a.k_hi = k_hi; a.k_lo = k_lo; a.ldk = ldk; a.k_col0 = k_col0;
   a.vt_hi = vt_hi; a.vt_lo = vt_lo; a.vt_ld = vt_ld;
-  a.o_hi = o_hi; a.o_lo = o_lo; a.ldo = ldo;
+  a.o_hi = o_hi; a.o_lo = o_lo; a.ldo = ldo; a.o_fmt = -1;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale; a.kmask = key_mask;
   HIPRET(launch_attention(a, precision, (hipStream_t)stream));
   return NS2_OK;
@@ -167,7 +168,7 @@ extern "C" int ns2_rmsnorm(const float* x, int ldx, int M, int d, int seq_len, c
   ARGCHK(!cond || seq_len > 0, "ns2_rmsnorm: adaptive norm needs seq_len");
   NormArgs n;
   n.x = x; n.ldx = ldx; n.gamma = gamma; n.cond = cond; n.cond_ld = cond_ld;
-  n.out_hi = out_hi; n.out_lo = out_lo; n.ldo = out_hi ? ldo : d; n.out_f = out_f32; n.ldo_f = ldo_f; n.f16 = precision == 2;
+  n.out_hi = out_hi; n.out_lo = out_lo; n.ldo = out_hi ? ldo : d; n.out_f = out_f32; n.ldo_f = ldo_f; n.fmt = op_fmt(precision);
   n.M = M; n.d = d; n.seq_len = seq_len;
   HIPRET(launch_rmsnorm(n, (hipStream_t)stream));
   return NS2_OK;

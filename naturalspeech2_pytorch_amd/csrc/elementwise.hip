@@ -59,14 +59,9 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const NormArgs a) {
         o[e] = t;
       }
     }
-    uint32_t h01, l01, h23, l23;
-    split2f(o[0], o[1], h01, l01, a.f16);
-    split2f(o[2], o[3], h23, l23, a.f16);
     if (a.out_hi) {
       const bool il = a.out_lo != nullptr;
-      const long po = row * pld(a.ldo, il) + pcol(c, il);
-      *reinterpret_cast<uint2*>(a.out_hi + po) = make_uint2(h01, h23);
-      if (il) *reinterpret_cast<uint2*>(a.out_lo + po) = make_uint2(l01, l23);
+      store_cols4(a.out_hi + row * pld(a.ldo, il), c, o[0], o[1], o[2], o[3], a.fmt, il);
     }
     if (a.out_f && c < a.d) *reinterpret_cast<float4*>(a.out_f + row * a.ldo_f + c) = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -75,6 +70,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const NormArgs a) {
 hipError_t launch_rmsnorm(const NormArgs& a, hipStream_t s) {
   if (a.M <= 0 || (a.d & 3) || (a.ldo & 3) || (a.ldx & 3) || a.ldo > 2048 || a.d > 2048) return hipErrorInvalidValue;
   if (!planes_ok(a.out_hi, a.out_lo) || (a.out_lo && (a.ldo & 31))) return hipErrorInvalidValue;
+  if (a.out_hi && ((a.fmt == FMT_H8 && !a.out_lo) || (a.fmt == FMT_F16 && a.out_lo))) return hipErrorInvalidValue;
   const dim3 grid((a.M + 3) / 4), block(256);
   const int width = a.ldo > a.d ? a.ldo : a.d;
   if (width <= 256) hipLaunchKernelGGL(rmsnorm_kernel<1>, grid, block, 0, s, a);
@@ -87,7 +83,7 @@ hipError_t launch_rmsnorm(const NormArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------- x (+ add) -> split planes
 __global__ __launch_bounds__(256) void split_kernel(const float* x, int ldx, const float* add, int ldadd, int add_rows,
                                                     int add_valid, bf16_t* out_hi, bf16_t* out_lo, int ldo, long M, int d,
-                                                    int seq_len, int f16) {
+                                                    int seq_len, int fmt) {
   const int chunks = ldo >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * chunks) return;
@@ -114,22 +110,18 @@ __global__ __launch_bounds__(256) void split_kernel(const float* x, int ldx, con
       }
     }
   }
-  uint32_t h01, l01, h23, l23;
-  split2f(o[0], o[1], h01, l01, f16);
-  split2f(o[2], o[3], h23, l23, f16);
   const bool il = out_lo != nullptr;
-  const long po = row * pld(ldo, il) + pcol(c, il);
-  *reinterpret_cast<uint2*>(out_hi + po) = make_uint2(h01, h23);
-  if (il) *reinterpret_cast<uint2*>(out_lo + po) = make_uint2(l01, l23);
+  store_cols4(out_hi + row * pld(ldo, il), c, o[0], o[1], o[2], o[3], fmt, il);
 }
 
 hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, int add_rows_per_batch, int add_valid_rows,
-                        bf16_t* out_hi, bf16_t* out_lo, int ldo, int M, int d, int seq_len, hipStream_t s, int f16) {
+                        bf16_t* out_hi, bf16_t* out_lo, int ldo, int M, int d, int seq_len, hipStream_t s, int fmt) {
   if (M <= 0 || (ldo & 3) || ldo < d || (add && seq_len <= 0)) return hipErrorInvalidValue;
-  if (!planes_ok(out_hi, out_lo) || (out_lo && (ldo & 31)) || (f16 && out_lo)) return hipErrorInvalidValue;
+  if (!planes_ok(out_hi, out_lo) || (out_lo && (ldo & 31)) || (fmt == FMT_F16 && out_lo) || (fmt == FMT_H8 && !out_lo))
+    return hipErrorInvalidValue;
   const long total = (long)M * (ldo >> 2);
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, add, ldadd,
-                     add_rows_per_batch, add_valid_rows, out_hi, out_lo, ldo, (long)M, d, seq_len, f16);
+                     add_rows_per_batch, add_valid_rows, out_hi, out_lo, ldo, (long)M, d, seq_len, fmt);
   return hipGetLastError();
 }
 
@@ -371,21 +363,24 @@ hipError_t launch_transpose_into(const float* src, int R, int C, float* dst, lon
 }
 
 // split planes -> fp32 (hi + lo), used by debug taps and tests
-__global__ void join_kernel(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, int f16) {
+__global__ void join_kernel(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, int fmt) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= M * d) return;
   const long r = i / d;
   const int c = (int)(i - r * d);
   const bool il = lo != nullptr;
   const long o = r * pld(ld, il) + pcol(c, il);
-  float v = f16 ? h2f(hi[o]) : bf2f(hi[o]);
-  if (il) v += bf2f(lo[o]);
+  float v = (fmt != FMT_BF16) ? h2f(hi[o]) : bf2f(hi[o]);
+  if (fmt == FMT_H8) {               // half + l8 * 2^-12 (the h8 byte duplicates the half to 3 bits and is not added)
+    const unsigned char* line = reinterpret_cast<const unsigned char*>(hi + r * pld(ld, true) + ((c & ~31) << 1));
+    v += bf8_to_f(line[96 + (c & 31)]) * (1.0f / H8_LO_SCALE);
+  } else if (il) v += bf2f(lo[o]);
   out[r * ldo + c] = v;
 }
-hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s, int f16) {
-  if (!planes_ok(hi, lo) || (f16 && lo)) return hipErrorInvalidValue;
+hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s, int fmt) {
+  if (!planes_ok(hi, lo) || (fmt == FMT_F16 && lo) || (fmt == FMT_H8 && !lo)) return hipErrorInvalidValue;
   const long n = M * d;
-  hipLaunchKernelGGL(join_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hi, lo, ld, out, ldo, M, d, f16);
+  hipLaunchKernelGGL(join_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hi, lo, ld, out, ldo, M, d, fmt);
   return hipGetLastError();
 }
 
@@ -450,7 +445,7 @@ hipError_t launch_cfg_mix(const float* cond, const float* null, float* out, long
 
 // ---------------------------------------------------------------- weight packing (one-time, at model finalize)
 __global__ void pack_weight_kernel(const float* src, int C, int T, int Cp, const int* row_map, int rows_p, bf16_t* dst_hi,
-                                   bf16_t* dst_lo, int ldk, int k_off, int f16) {
+                                   bf16_t* dst_lo, int ldk, int k_off, int fmt) {
   const int kk = blockIdx.x * 256 + threadIdx.x;          // column inside [0, T*Cp)
   const int rp = blockIdx.y;
   if (kk >= T * Cp || rp >= rows_p) return;
@@ -458,19 +453,29 @@ __global__ void pack_weight_kernel(const float* src, int C, int T, int Cp, const
   const int r = row_map ? row_map[rp] : rp;
   float v = 0.f;
   if (r >= 0 && c < C) v = src[((long)r * C + c) * T + tap];
+  const bool il = dst_lo != nullptr;
+  const int kc = k_off + kk;
+  const long o = (long)rp * pld(ldk, il) + pcol(kc, il);
+  if (fmt == FMT_H8) {
+    uint32_t h16, h8, l8;
+    cvt2_h8(v, 0.f, h16, h8, l8);
+    dst_hi[o] = (bf16_t)(h16 & 0xffffu);
+    unsigned char* line = reinterpret_cast<unsigned char*>(dst_hi + (long)rp * pld(ldk, true) + ((kc & ~31) << 1));
+    line[64 + (kc & 31)] = (unsigned char)(h8 & 0xffu);
+    line[96 + (kc & 31)] = (unsigned char)(l8 & 0xffu);
+    return;
+  }
   bf16_t h, l;
   split_bf16(v, h, l);
-  if (f16) h = (bf16_t)(cvt2h(v, 0.f) & 0xffffu);
-  const bool il = dst_lo != nullptr;
-  const long o = (long)rp * pld(ldk, il) + pcol(k_off + kk, il);
+  if (fmt == FMT_F16) h = (bf16_t)(cvt2h(v, 0.f) & 0xffffu);
   dst_hi[o] = h;
   if (il) dst_lo[o] = l;
 }
 hipError_t launch_pack_weight(const float* src, int C, int T, int Cp, const int* row_map, int rows_p, bf16_t* dst_hi,
-                              bf16_t* dst_lo, int ldk, int k_off, hipStream_t s, int f16) {
-  if (!planes_ok(dst_hi, dst_lo) || (f16 && dst_lo)) return hipErrorInvalidValue;
+                              bf16_t* dst_lo, int ldk, int k_off, hipStream_t s, int fmt) {
+  if (!planes_ok(dst_hi, dst_lo) || (fmt == FMT_F16 && dst_lo) || (fmt == FMT_H8 && !dst_lo)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((T * Cp + 255) / 256, rows_p), dim3(256), 0, s, src, C, T, Cp, row_map,
-                     rows_p, dst_hi, dst_lo, ldk, k_off, f16);
+                     rows_p, dst_hi, dst_lo, ldk, k_off, fmt);
   return hipGetLastError();
 }
 

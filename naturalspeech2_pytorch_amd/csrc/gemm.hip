@@ -32,8 +32,8 @@ constexpr int PLANE = BM * ROWB;              // 10240 B
 
 template <int NSPLIT>
 struct Stage {                                // registers holding one prefetched K-tile slice per thread
-  uint4 a[NSPLIT == 3 ? 2 : 1][2];
-  uint4 w[NSPLIT == 3 ? 2 : 1][2];
+  uint4 a[NSPLIT == 1 ? 1 : 2][2];            // plane 1: bf16 lo (NSPLIT 3) or the [h8 x 32 | l8 x 32] byte half (NSPLIT 2, FMT_H8)
+  uint4 w[NSPLIT == 1 ? 1 : 2][2];
 };
 
 NS2_DEVINL uint4 ld16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
@@ -41,7 +41,8 @@ NS2_DEVINL uint4 zero16() { return make_uint4(0u, 0u, 0u, 0u); }
 
 template <int NSPLIT, int EPI, bool F16>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
-  constexpr int NP = (NSPLIT == 3) ? 2 : 1;   // planes per operand
+  static_assert(NSPLIT != 2 || F16, "the mixed mode multiplies IEEE-half operands");
+  constexpr int NP = (NSPLIT == 1) ? 1 : 2;   // 64-B halves of the interleaved line staged per operand
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE_BYTES = 2 * NP * PLANE;
 
@@ -139,6 +140,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
       const bool more = (kt + 1) < kt1;
       if (more) load_stage(st, kt + 1);
       const unsigned char* sb = smem + (kt & 1) * STAGE_BYTES;
+      if constexpr (NSPLIT == 2) {
+        // mixed mode (see gemm2.hip): 2 x (2x2) half MFMAs + (2x2) fp8 MFMAs of K = 64 per 32-deep tile; plane 1 of the
+        // LDS image is the byte half of the line, [h8 x 32 | l8 x 32]
+        bf16x8 af[2][2], wf[2][2];
+        i32x8 a8[2], w8[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc) {
+            af[kc][i] = *reinterpret_cast<const bf16x8*>(sb + a_frag_off + i * 32 * ROWB + kc * 32);
+            wf[kc][i] = *reinterpret_cast<const bf16x8*>(sb + 2 * PLANE + w_frag_off + i * 32 * ROWB + kc * 32);
+          }
+          const unsigned char* pa = sb + PLANE + (wm * 64 + i * 32 + l31) * ROWB + 32 * hi;
+          const unsigned char* pw = sb + 3 * PLANE + (wn * 64 + i * 32 + l31) * ROWB + 32 * (1 - hi);
+          const int4 a0 = *reinterpret_cast<const int4*>(pa), a1 = *reinterpret_cast<const int4*>(pa + 16);
+          const int4 w0 = *reinterpret_cast<const int4*>(pw), w1 = *reinterpret_cast<const int4*>(pw + 16);
+          a8[i] = i32x8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          w8[i] = i32x8{w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][ni] = mma16<true>(af[0][mi], wf[0][ni], acc[mi][ni]);
+            acc[mi][ni] = mma16<true>(af[1][mi], wf[1][ni], acc[mi][ni]);
+            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[mi], w8[ni], acc[mi][ni], 1, 1, 0, H8_E8M0_LO, 0,
+                                                                          H8_E8M0_ONE);
+          }
+      } else {
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
         bf16x8 af[NP][2], wf[NP][2];
@@ -160,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             acc[mi][ni] = mma16<F16>(af[0][mi], wf[0][ni], acc[mi][ni]);
           }
       }
+      }
       if (more) store_stage(st, (kt + 1) & 1);
       __syncthreads();
     }
@@ -180,7 +211,7 @@ template <int NSPLIT, int EPI, bool F16>
 static hipError_t launch_one(const GemmArgs& g, hipStream_t s) {
   const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
   const int nz = g.nz > 0 ? g.nz : 1;
-  const size_t lds = 2 * 2 * (NSPLIT == 3 ? 2 : 1) * PLANE;
+  const size_t lds = 2 * 2 * (NSPLIT == 1 ? 1 : 2) * PLANE;
   static DynLdsAttr attr;
   {
     hipError_t e = attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<NSPLIT, EPI, F16>), (int)lds);
@@ -202,13 +233,14 @@ static hipError_t launch_epi(const GemmArgs& g, hipStream_t s) {
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_gemm1(const GemmArgs& g, int nsplit, hipStream_t s) {
+hipError_t launch_gemm1(const GemmArgs& g, int precision, hipStream_t s) {      // formats already validated by launch_gemm
   if (g.M <= 0 || g.N <= 0 || g.nkt <= 0) return hipErrorInvalidValue;
-  if (nsplit == 3) {
-    if (!g.a_lo || !g.w_lo) return hipErrorInvalidValue;
-    return launch_epi<3, false>(g, s);
+  switch (precision) {
+    case 3: return launch_epi<3, false>(g, s);
+    case 4: return launch_epi<2, true>(g, s);
+    case 2: return launch_epi<1, true>(g, s);
+    default: return launch_epi<1, false>(g, s);
   }
-  return g.f16 ? launch_epi<1, true>(g, s) : launch_epi<1, false>(g, s);
 }
 
 }  // namespace ns2

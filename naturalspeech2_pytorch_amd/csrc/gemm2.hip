@@ -46,9 +46,13 @@ __device__ __attribute__((aligned(256))) bf16_t g2_zero_page[128];
 template <int NSPLIT, int EPI, bool F16>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const bf16_t* zero_page = g2_zero_page;
-  constexpr int NP = (NSPLIT == 3) ? 2 : 1;          // planes per operand (both inside one 128-B LDS row in exact mode)
-  constexpr int BK = (NSPLIT == 3) ? 32 : 64;        // K-tile depth (logical elements)
-  constexpr int RB = 128;                            // LDS row bytes: [hi32|lo32] (exact) or hi64 (fast)
+  // NSPLIT: 3 = bf16 hi/lo planes, three products; 1 = one 16-bit product (bf16 or, F16, IEEE half); 2 = FMT_H8 "mixed":
+  // one half product + both correction terms in one fp8 MFMA per 32-deep k block (ns2_common.h)
+  static_assert(NSPLIT != 2 || F16, "the mixed mode multiplies IEEE-half operands");
+  constexpr int NP = (NSPLIT == 3) ? 2 : 1;          // 16-bit planes per operand (both inside one 128-B LDS row in exact mode)
+  constexpr bool LINE32 = NSPLIT != 1;               // a K tile is one interleaved 128-B line per row: 32 logical columns
+  constexpr int BK = LINE32 ? 32 : 64;               // K-tile depth (logical elements)
+  constexpr int RB = 128;                            // LDS row bytes: [hi32|lo32] (exact), [half32|h8 32|l8 32] (mixed) or hi64
   constexpr int CPR = RB / 16;                       // 16-B chunks per row (8)
   constexpr int RPI = 64 / CPR;                      // tile rows moved by one DMA wave-instruction (8)
   constexpr int REGION = G2_BM * RB;                 // one operand of one K tile: 32 KiB
@@ -98,11 +102,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     if (a_wave) {
       const long m = (long)tm * G2_BM + row;
       // exact: chunk c of the line = 8 elements at c*8 (hi chunks 0-3, lo chunks 4-7); fast: logical column c*8
-      const int coff = (NSPLIT == 3) ? lchunk * 8 : pcol(lchunk * 8, ail);
+      const int coff = LINE32 ? lchunk * 8 : pcol(lchunk * 8, ail);
       src[i] = g.a_hi + pcol((int)(z * g.a_zs), ail) + m * a_rs + coff;
       nseq[i] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -1;
     } else {
-      const int coff = (NSPLIT == 3) ? lchunk * 8 : pcol(lchunk * 8, wil);
+      const int coff = LINE32 ? lchunk * 8 : pcol(lchunk * 8, wil);
       src[i] = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN + row) * w_rs + coff;
       nseq[i] = 0;
     }
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   // upper 32 columns are zero-filled (A and W lanes of those chunks read the zero page)
   const int tap_k = g.kt_per_tap * 32;                        // logical elements per tap
   const int tpt = (tap_k + BK - 1) / BK;
-  const bool half_tail = (NSPLIT != 3) && (g.kt_per_tap & 1);
+  const bool half_tail = !LINE32 && (g.kt_per_tap & 1);
   const int ntaps = g.nkt / g.kt_per_tap;
   const int ntiles = ntaps * tpt;
   const int mid_tile = (g.mid_kt > 0) ? (g.mid_kt / g.kt_per_tap) * tpt : 0;
@@ -185,6 +189,52 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       STAMP(1);
       const unsigned char* sb = smem + (kt & 1) * STAGE;
       if (wave_active) {
+      if constexpr (NSPLIT == 2) {
+        // mixed mode: per 32-deep tile 2 x (4x2) half MFMAs + (4x2) fp8 MFMAs of K = 64.  fp8 operands of lane (l31, hi):
+        // A = 32 bytes [h8 | l8][hi] of row l31 (chunks 4+2hi, 5+2hi of the line), B = [l8 | h8][hi] (chunks 6-2hi, 7-2hi):
+        // lanes 0-31 contribute a_h8 . w_l8, lanes 32-63 a_l8 . w_h8; every product carries exactly one 2^12-scaled factor,
+        // undone by the block scale 2^-12 on A.
+        bf16x8 af[2][4], wf[2][2];
+        i32x8 a8[4], w8[2];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          const int coff = ((2 * kc + hi) ^ fswz) * 16;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[kc][i] = *reinterpret_cast<const bf16x8*>(sb + a_row_off + i * 32 * RB + coff);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) wf[kc][i] = *reinterpret_cast<const bf16x8*>(sb + w_row_off + i * 32 * RB + coff);
+        }
+        {
+          const int ca0 = ((4 + 2 * hi) ^ fswz) * 16, ca1 = ((5 + 2 * hi) ^ fswz) * 16;
+          const int cw0 = ((6 - 2 * hi) ^ fswz) * 16, cw1 = ((7 - 2 * hi) ^ fswz) * 16;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int4 lo4 = *reinterpret_cast<const int4*>(sb + a_row_off + i * 32 * RB + ca0);
+            const int4 hi4 = *reinterpret_cast<const int4*>(sb + a_row_off + i * 32 * RB + ca1);
+            a8[i] = i32x8{lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int4 lo4 = *reinterpret_cast<const int4*>(sb + w_row_off + i * 32 * RB + cw0);
+            const int4 hi4 = *reinterpret_cast<const int4*>(sb + w_row_off + i * 32 * RB + cw1);
+            w8[i] = i32x8{lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+          }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][ni] = mma16<true>(af[0][mi], wf[0][ni], acc[mi][ni]);
+            acc[mi][ni] = mma16<true>(af[1][mi], wf[1][ni], acc[mi][ni]);
+          }
+        if (kt + 1 < kt1 && !a_wave) issue_tile(kt + 1, (kt + 1) & 1);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[mi], w8[ni], acc[mi][ni], /*A e5m2*/ 1, /*B e5m2*/ 1,
+                                                                          0, H8_E8M0_LO, 0, H8_E8M0_ONE);
+      } else {
 #pragma unroll
       for (int kc = 0; kc < KCH; ++kc) {
         bf16x8 af[NP][4], wf[NP][2];
@@ -218,6 +268,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
 #ifdef G2_TRACE
         if (kc == 0) STAMP(4);
 #endif
+      }
       }
       } else if (kt + 1 < kt1 && !a_wave) {
         issue_tile(kt + 1, (kt + 1) & 1);
@@ -283,7 +334,7 @@ static hipError_t launch2_epi(const GemmArgs& g, hipStream_t s) {
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_gemm1(const GemmArgs& g, int nsplit, hipStream_t s);   // gemm.hip (128x128 register-staged kernel)
+hipError_t launch_gemm1(const GemmArgs& g, int precision, hipStream_t s);   // gemm.hip (128x128 register-staged kernel)
 
 static int g_forced_kernel = -1;     // -1: read NS2_GEMM once; 0 auto; 1 / 2 force a kernel (tests exercise both)
 void force_gemm_kernel(int k) { g_forced_kernel = k; }
@@ -297,25 +348,32 @@ static int forced_kernel() {
 
 // Dispatch: the 256x256 LDS-DMA kernel for wide outputs, the 128x128 kernel when N <= 128 (half of a 256-wide tile
 // would be padding, e.g. the dim=128 model's d x d projections).  W rows are padded to 256 by the packers.
-hipError_t launch_gemm(const GemmArgs& g_in, int nsplit, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
   GemmArgs g = g_in;
-  g.f16 = 0;
-  if (nsplit == 2) {                                  // "half" precision: one fp16 product on hi-only (dense) operands
-    if (g.a_lo || g.w_lo || g.out_lo || g.vt_lo) return hipErrorInvalidValue;
-    g.f16 = 1;
-    nsplit = 1;
-  }
+  if (precision < 1 || precision > 4) return hipErrorInvalidValue;
+  const int op_fmt = precision == 2 ? FMT_F16 : (precision == 4 ? FMT_H8 : FMT_BF16);
+  if (g.out_fmt < 0) g.out_fmt = op_fmt;
+  g.vt_fmt = (precision == 2 || precision == 4) ? FMT_F16 : FMT_BF16;
+  // operand / output plane pointers must match the formats: IEEE-half planes are dense (no lo pointer), FMT_H8 and the
+  // bf16 x3 operands are interleaved lines (lo == hi + 32)
+  if (precision == 2 && (g.a_lo || g.w_lo)) return hipErrorInvalidValue;
+  if ((precision == 3 || precision == 4) && (!g.a_lo || !g.w_lo)) return hipErrorInvalidValue;
+  if (g.out_hi && ((g.out_fmt == FMT_F16 && g.out_lo) || (g.out_fmt == FMT_H8 && !g.out_lo))) return hipErrorInvalidValue;
+  if (g.vt_hi && g.vt_fmt == FMT_F16 && g.vt_lo) return hipErrorInvalidValue;
   if (g.M <= 0 || g.N <= 0 || g.nkt <= 0 || g.kt_per_tap <= 0 || (g.nkt % g.kt_per_tap)) return hipErrorInvalidValue;
-  if (nsplit == 3 && (!g.a_lo || !g.w_lo)) return hipErrorInvalidValue;
   // a lo plane means the interleaved layout: lo = hi + 32 (ns2_common.h)
   if (!planes_ok(g.a_hi, g.a_lo) || !planes_ok(g.w_hi, g.w_lo) || !planes_ok(g.out_hi, g.out_lo) ||
       !planes_ok(g.vt_hi, g.vt_lo))
     return hipErrorInvalidValue;
   const int f = forced_kernel();
   const bool big = (f == 2) || (f != 1 && g.N > 128);
-  if (!big) return launch_gemm1(g, nsplit, s);
-  if (nsplit == 3) return launch2_epi<3, false>(g, s);
-  return g.f16 ? launch2_epi<1, true>(g, s) : launch2_epi<1, false>(g, s);
+  if (!big) return launch_gemm1(g, precision, s);
+  switch (precision) {
+    case 3: return launch2_epi<3, false>(g, s);
+    case 4: return launch2_epi<2, true>(g, s);
+    case 2: return launch2_epi<1, true>(g, s);
+    default: return launch2_epi<1, false>(g, s);
+  }
 }
 
 }  // namespace ns2

@@ -46,7 +46,7 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
                               int lane) {
   const int l31 = lane & 31, hi = lane >> 5;
   const bool odd = lane & 1;
-  const bool il = g.out_lo != nullptr;               // interleaved [hi32|lo32] output rows (ns2_common.h)
+  const bool il = g.out_lo != nullptr;               // interleaved 128-B output lines: bf16 [hi32|lo32] or FMT_H8 (ns2_common.h)
 
   if constexpr (EPI == EPI_F32) {
     // out = acc + bias (+ residual)      (to_out / FF-out / final_conv / to_pred)
@@ -93,13 +93,7 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
         const int r = 2 * rp + (odd ? 1 : 0);
         const int row = row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const int col = ocol & ~1;
-        if (row < g.M && col < g.out_ncols) {
-          uint32_t ph, pl;
-          split2f(c_lo, c_hi, ph, pl, g.f16);
-          const long o = (long)row * pld(g.ldo_s, il) + pcol(col, il);
-          *reinterpret_cast<uint32_t*>(g.out_hi + o) = ph;
-          if (il) *reinterpret_cast<uint32_t*>(g.out_lo + o) = pl;
-        }
+        if (row < g.M && col < g.out_ncols) store_cols2(g.out_hi + (long)row * pld(g.ldo_s, il), col, c_lo, c_hi, g.out_fmt, il);
       }
     }
     }
@@ -108,7 +102,6 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
     const float* bias = g.bias ? g.bias + (long)z * g.bias_zs : nullptr;
     const long zo = pcol((int)(z * g.out_zs), il);    // out_zs = logical column offset of slice z
     bf16_t* out_hi = g.out_hi + zo;
-    bf16_t* out_lo = il ? g.out_lo + zo : nullptr;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -132,11 +125,7 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
             if (row < g.M && c0 < g.out_ncols) {
               if (c0 >= g.N) c_lo = 0.f;             // zero the K-padding columns of the next GEMM's operand
               if (c0 + 1 >= g.N) c_hi = 0.f;
-              uint32_t ph, pl;
-              split2f(c_lo, c_hi, ph, pl, g.f16);
-              const long o = (long)row * pld(g.ldo_s, il) + pcol(c0, il);
-              *reinterpret_cast<uint32_t*>(out_hi + o) = ph;
-              if (il) *reinterpret_cast<uint32_t*>(out_lo + o) = pl;
+              store_cols2(out_hi + (long)row * pld(g.ldo_s, il), c0, c_lo, c_hi, g.out_fmt, il);
             }
           }
         } else {
@@ -148,9 +137,10 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
               const int row0 = row_base + mi * 32 + 8 * gq + 4 * hi;
               if (row0 >= g.M) continue;
               const int b = row0 / g.seq_len, n0 = row0 - b * g.seq_len;
+              // transposed values are attention operands: bf16 (with or without lo plane) or dense IEEE half, never FMT_H8
               uint32_t h01, l01, h23, l23;
-              split2f(acc[mi][ni][4 * gq + 0] + bc, acc[mi][ni][4 * gq + 1] + bc, h01, l01, g.f16);
-              split2f(acc[mi][ni][4 * gq + 2] + bc, acc[mi][ni][4 * gq + 3] + bc, h23, l23, g.f16);
+              split2f(acc[mi][ni][4 * gq + 0] + bc, acc[mi][ni][4 * gq + 1] + bc, h01, l01, g.vt_fmt == FMT_F16);
+              split2f(acc[mi][ni][4 * gq + 2] + bc, acc[mi][ni][4 * gq + 3] + bc, h23, l23, g.vt_fmt == FMT_F16);
               const bf16_t h[4] = {(bf16_t)(h01 & 0xffffu), (bf16_t)(h01 >> 16), (bf16_t)(h23 & 0xffffu), (bf16_t)(h23 >> 16)};
               const bf16_t l[4] = {(bf16_t)(l01 & 0xffffu), (bf16_t)(l01 >> 16), (bf16_t)(l23 & 0xffffu), (bf16_t)(l23 >> 16)};
               const bool vil = g.vt_lo != nullptr;

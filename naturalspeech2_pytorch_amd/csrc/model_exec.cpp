@@ -98,7 +98,11 @@ static int dev_alloc(std::vector<void*>* owned, void** p, size_t bytes) {
 
 // Packing context: who owns the allocations and the layout of the weights being packed (ns2_common.h): interleaved
 // [hi32|lo32] rows with a lo plane (exact models and ns2_weight_pack) or dense hi-only rows (precision-1 "fast" models).
-struct PackCtx { std::vector<void*>* owned; bool il; int f16; };   // f16: hi plane in IEEE half (precision 2)
+struct PackCtx { std::vector<void*>* owned; bool il; int fmt; };   // il: interleaved 128-B lines (bf16 hi/lo or FMT_H8); fmt: PlaneFmt
+static PackCtx pack_ctx_for(std::vector<void*>* owned, int precision) {
+  // precision 3: interleaved bf16 hi/lo rows; 1: dense bf16 hi-only weights; 2: dense IEEE-half weights; 4: FMT_H8 lines
+  return PackCtx{owned, precision == 3 || precision == 4, precision == 2 ? FMT_F16 : (precision == 4 ? FMT_H8 : FMT_BF16)};
+}
 
 // allocate a packed weight of rows_p x ldk logical columns (zero-filled)
 static int alloc_packed(const PackCtx& pc, PackedW* w, int N, int ldk, int kt_per_tap) {
@@ -112,7 +116,7 @@ static int alloc_packed(const PackCtx& pc, PackedW* w, int N, int ldk, int kt_pe
   size_t bytes = (size_t)w->rows_p * ldk * sizeof(bf16_t) * (il ? 2 : 1);
   NSCHK(dev_alloc(owned, (void**)&w->hi, bytes));
   w->lo = il ? w->hi + 32 : nullptr;
-  w->f16 = pc.f16;
+  w->fmt = pc.fmt;
   HIPCHK(hipMemset(w->hi, 0, bytes));
   return NS2_OK;
 }
@@ -126,7 +130,7 @@ static int pack_into(PackedW* w, const float* src, int C, int T, int Cp, const s
   HIPCHK(hipMemcpy(d_map, row_map.data(), row_map.size() * sizeof(int), hipMemcpyHostToDevice));
   const size_t roff = (size_t)row0 * w->ldk * (w->lo ? 2 : 1);
   hipError_t e = launch_pack_weight(src, C, T, Cp, d_map, (int)row_map.size(), w->hi + roff, w->lo ? w->lo + roff : nullptr,
-                                    w->ldk, k_off, s, w->f16);
+                                    w->ldk, k_off, s, w->fmt);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(d_map);
   HIPCHK(e);
@@ -174,10 +178,11 @@ static int pack_geglu_bias(std::vector<void*>* owned, float** out, const float* 
 }
 
 // op-level packing used by ns2_weight_pack (tests / non-Python hosts)
-int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, int f16, PackedW* out,
+int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, int precision, PackedW* out,
                        std::vector<void*>* owned, hipStream_t s) {
   const int Cp = rup(cols, 32);
-  const PackCtx pc{owned, !f16, f16};                // op-level weights: interleaved bf16 (serves precisions 1 and 3) or dense fp16 (2)
+  // op-level weights: interleaved bf16 (serves precisions 1 and 3), dense IEEE half (2) or FMT_H8 lines (4)
+  const PackCtx pc = pack_ctx_for(owned, precision == 1 ? 3 : precision);
   if (geglu) return pack_geglu(pc, out, w, rows / 2, cols, s);
   const int T = taps + (extra ? 1 : 0);
   NSCHK(alloc_packed(pc, out, rows, T * Cp, Cp / 32));
@@ -193,7 +198,7 @@ static GemmArgs base_args(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_
   g.a_hi = a_hi; g.a_lo = a_lo; g.lda = lda;
   g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk;
   g.M = M; g.N = w.N; g.nkt = w.nkt; g.kt_per_tap = w.nkt; g.conv_taps = 0; g.dil = 1; g.mid_kt = -1;
-  g.nz = 1; g.pad_left = -1; g.act = 0;
+  g.nz = 1; g.pad_left = -1; g.act = 0; g.out_fmt = -1;
   return g;
 }
 static void set_conv(GemmArgs& g, const PackedW& w, int taps, int dil, int seq_len) {
@@ -210,10 +215,10 @@ int gemm_f32(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, 
   return NS2_OK;
 }
 int gemm_split(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
-               const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left, int act) {
+               const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left, int act, int out_fmt) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
   if (conv_taps) set_conv(g, w, conv_taps, dil, seq_len);
-  g.pad_left = pad_left; g.act = act;
+  g.pad_left = pad_left; g.act = act; g.out_fmt = out_fmt;
   g.epi = EPI_SPLIT; g.bias = bias; g.out_hi = o_hi; g.out_lo = o_lo; g.ldo_s = ldo; g.out_ncols = ldo;
   HIPCHK(launch_gemm(g, prec, s));
   return NS2_OK;
@@ -229,6 +234,7 @@ int gemm_qkv(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, 
              bf16_t* o_hi, bf16_t* o_lo, int ldo, bf16_t* vt_hi, bf16_t* vt_lo, int vt_ld, int prec, hipStream_t s) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
   g.epi = EPI_QKV; g.seq_len = seq_len; g.split_col = split_col;
+  g.out_fmt = (prec == 2 || prec == 4) ? FMT_F16 : FMT_BF16;        // q / k are attention operands: IEEE half also at precision 4
   g.out_hi = o_hi; g.out_lo = o_lo; g.ldo_s = ldo; g.out_ncols = split_col;
   g.vt_hi = vt_hi; g.vt_lo = vt_lo; g.vt_ld = vt_ld; g.vt_rows = w.N - split_col;
   HIPCHK(launch_gemm(g, prec, s));
@@ -264,7 +270,7 @@ extern "C" int ns2_model_create(const ns2_model_config* cfg, ns2_model** out) {
   if (!cfg || !out) { set_error("null argument"); return NS2_ERR_ARG; }
   if (cfg->dim_head != 64) { set_error("dim_head must be 64 (attention kernel head dim), got %d", cfg->dim_head); return NS2_ERR_ARG; }
   if (cfg->dim % 32) { set_error("dim must be a multiple of 32, got %d", cfg->dim); return NS2_ERR_ARG; }
-  if (cfg->precision < 1 || cfg->precision > 3) { set_error("precision must be 1 (bf16), 2 (fp16) or 3 (bf16 x3)"); return NS2_ERR_ARG; }
+  if (cfg->precision < 1 || cfg->precision > 4) { set_error("precision must be 1 (bf16), 2 (fp16), 3 (bf16 x3) or 4 (fp16 + fp8 correction terms)"); return NS2_ERR_ARG; }
   if (cfg->wavenet_layers < 1 || cfg->wavenet_layers > 16 || cfg->wavenet_stacks < 1) { set_error("bad wavenet shape"); return NS2_ERR_ARG; }
   ns2_model* m = new ns2_model();
   m->cfg = *cfg;
@@ -308,8 +314,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
   const int dim = m->dim, a = m->a, f = m->f, L = m->L, S = m->S;
   const bool cond = m->cfg.condition_on_prompt;
   char key[256];
-  // precision 3: interleaved bf16 hi/lo rows; 1: dense bf16 hi-only weights; 2: dense fp16 weights
-  const PackCtx pc{&m->owned, m->cfg.precision == 3, m->cfg.precision == 2};
+  const PackCtx pc = pack_ctx_for(&m->owned, m->cfg.precision);
   const bool il = pc.il;
 
   // ---- time conditioning (NS2:839-843)
@@ -351,7 +356,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
     const size_t per = (size_t)W.rows_p * W.ldk * (il ? 2 : 1);     // physical elements per matrix
     NSCHK(dev_alloc(&m->owned, (void**)&W.hi, per * L * sizeof(bf16_t)));
     W.lo = il ? W.hi + 32 : nullptr;
-    W.f16 = pc.f16;
+    W.fmt = pc.fmt;
     HIPCHK(hipMemset(W.hi, 0, per * L * sizeof(bf16_t)));
     NSCHK(dev_alloc(&m->owned, (void**)&m->b_wn_conv[st], (size_t)L * dim * sizeof(float)));
     NSCHK(dev_alloc(&m->owned, (void**)&m->b_wn_res[st], (size_t)L * dim * sizeof(float)));
@@ -460,14 +465,25 @@ struct Carver {
     return p;
   }
 };
-struct Planes { bf16_t* hi; bf16_t* lo; int f16; };
-// n logical elements; il: interleaved [hi32|lo32] rows in one buffer (precision 3), else a dense hi plane only (bf16 for
-// precision 1, IEEE half for precision 2)
-static Planes take_planes(Carver& c, int64_t n, bool il, int f16) {
+struct Planes { bf16_t* hi; bf16_t* lo; int fmt; };
+// Activation formats of a precision: `op` = what the GEMMs multiply in (and write for each other), `att` = what the
+// attention kernel reads (q, k, V^T): 3 -> interleaved bf16 hi/lo for both; 1 -> dense bf16; 2 -> dense IEEE half;
+// 4 -> FMT_H8 lines for GEMM operands, dense IEEE half for the attention operands
+struct Fmts { bool op_il; int op; bool att_il; int att; };
+static Fmts fmts_for(int precision) {
+  switch (precision) {
+    case 3: return Fmts{true, FMT_BF16, true, FMT_BF16};
+    case 2: return Fmts{false, FMT_F16, false, FMT_F16};
+    case 4: return Fmts{true, FMT_H8, false, FMT_F16};
+    default: return Fmts{false, FMT_BF16, false, FMT_BF16};
+  }
+}
+// n logical elements; il: interleaved 128-B lines in one buffer (4 bytes per element), else one dense 16-bit plane
+static Planes take_planes(Carver& c, int64_t n, bool il, int fmt) {
   Planes p;
   p.hi = c.take<bf16_t>(il ? 2 * n : n);
   p.lo = il ? p.hi + 32 : nullptr;
-  p.f16 = f16;
+  p.fmt = fmt;
   return p;
 }
 
@@ -486,9 +502,12 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
   const int64_t M = (int64_t)B * N;
   const int64_t Mq = (int64_t)B * std::max(N, m->cfg.condition_on_prompt ? m->Lm : 0);   // prepare_cond reuses qk / o / ffh
   const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, L = m->L;
-  const bool il = m->cfg.precision == 3;
-  const int f16 = m->cfg.precision == 2;
-  const int kpad = il ? 32 : 8;                       // key-axis padding of the transposed V planes
+  const Fmts F = fmts_for(m->cfg.precision);
+  const bool il = F.op_il;
+  const int f16 = F.op;                               // (historical name) PlaneFmt of the GEMM operands
+  const bool ail = F.att_il;
+  const int afmt = F.att;
+  const int kpad = ail ? 32 : 8;                      // key-axis padding of the transposed V planes
   w->tfeat = c.take<float>((int64_t)B * (dim + 1));
   w->t = c.take<float>((int64_t)B * m->Tc);
   w->condall = c.take<float>((int64_t)B * m->Jtot);
@@ -503,9 +522,9 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
   w->wB = take_planes(c, M * L * dp, il, f16);
   w->ssum = take_planes(c, M * dp, il, f16);
   w->xn = take_planes(c, M * dp, il, f16);
-  w->qk = take_planes(c, Mq * 2 * a, il, f16);
+  w->qk = take_planes(c, Mq * 2 * a, ail, afmt);
   w->Nkp = rup(N, kpad);
-  w->vt = take_planes(c, (int64_t)B * a * w->Nkp, il, f16);
+  w->vt = take_planes(c, (int64_t)B * a * w->Nkp, ail, afmt);
   w->o = take_planes(c, Mq * a, il, f16);
   w->ffh = take_planes(c, Mq * fp, il, f16);
   w->ffc = take_planes(c, M * fp, il, f16);
@@ -520,8 +539,8 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
     w->ctxp = take_planes(c, (int64_t)B * std::max(w->Nctx, std::max(n_prompt, n_cond)) * std::max(dp, m->dpp), il, f16);
     w->latp = take_planes(c, (int64_t)B * Lm * std::max(dp, std::max(fp, a)), il, f16);
     w->cpl = take_planes(c, (int64_t)B * Lm * dp, il, f16);
-    w->rkv = take_planes(c, (int64_t)B * w->Nctx * a, il, f16);
-    w->rvt = take_planes(c, (int64_t)B * a * w->Nctxp, il, f16);
+    w->rkv = take_planes(c, (int64_t)B * w->Nctx * a, ail, afmt);
+    w->rvt = take_planes(c, (int64_t)B * a * w->Nctxp, ail, afmt);
   }
   return rup64(c.off, 256);
 }
@@ -537,8 +556,9 @@ static int64_t carve_cond(const ns2_model* m, CondState* cs, void* base, int64_t
   c.take<int64_t>(4);                              // header: {magic, B, N, n_cond_valid}
   cs->prompt_cond = c.take<float>((int64_t)B * m->dt);
   cs->condadd = c.take<float>((int64_t)B * n_cond * m->dim);
-  const bool il = m->cfg.precision == 3;
-  const int f16 = m->cfg.precision == 2;
+  const Fmts F = fmts_for(m->cfg.precision);
+  const bool il = F.att_il;                         // the cached cross-attention keys / values are attention operands
+  const int f16 = F.att;
   cs->Lmp = rup(m->Lm, il ? 32 : 8);
   cs->ck.resize(m->cfg.depth); cs->cvt.resize(m->cfg.depth);
   for (int l = 0; l < m->cfg.depth; ++l) {
@@ -578,7 +598,7 @@ static int tap_planes(ns2_model* m, const char* name, Planes p, int ld, int64_t 
   auto it = m->taps.find(name);
   if (it == m->taps.end()) return NS2_OK;
   if (it->second.second < M * d) { set_error("tap '%s' needs %lld elements", name, (long long)(M * d)); return NS2_ERR_ARG; }
-  HIPCHK(launch_join(p.hi, p.lo, ld, it->second.first, d, M, d, s, p.f16));
+  HIPCHK(launch_join(p.hi, p.lo, ld, it->second.first, d, M, d, s, p.fmt));
   return NS2_OK;
 }
 
@@ -589,7 +609,7 @@ static int attention_call(const bf16_t* q_hi, const bf16_t* q_lo, int ldq, int q
   a.q_hi = q_hi; a.q_lo = q_lo; a.ldq = ldq; a.q_col0 = q_col0;
   a.k_hi = k_hi; a.k_lo = k_lo; a.ldk = ldk; a.k_col0 = k_col0;
   a.vt_hi = vt.hi; a.vt_lo = vt.lo; a.vt_ld = vt_ld;
-  a.o_hi = o.hi; a.o_lo = o.lo; a.ldo = ldo;
+  a.o_hi = o.hi; a.o_lo = o.lo; a.ldo = ldo; a.o_fmt = o.fmt;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = 0.125f;       // dim_head ** -0.5  (ATT:128 / SDPA default)
   a.kmask = nullptr;
   HIPCHK(launch_attention(a, prec, s));
@@ -601,7 +621,7 @@ static int norm_call(const float* x, int ldx, int M, int d, int seq_len, const f
   NormArgs n;
   n.x = x; n.ldx = ldx; n.gamma = gamma; n.cond = cond; n.cond_ld = cond_ld;
   n.out_hi = out.hi; n.out_lo = out.lo; n.ldo = ldo; n.out_f = out_f; n.ldo_f = ldo_f;
-  n.M = M; n.d = d; n.seq_len = seq_len; n.f16 = out.f16;
+  n.M = M; n.d = d; n.seq_len = seq_len; n.fmt = out.fmt;
   HIPCHK(launch_rmsnorm(n, s));
   return NS2_OK;
 }
@@ -625,7 +645,7 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
     // NS2:954-958, 964-968, 982-986: null substitutes
     HIPCHK(launch_bcast_rows(m->null_prompt_cond, cs.prompt_cond, B, m->dt, m->dt, s));
     HIPCHK(launch_bcast_rows(m->null_prompt_tokens, ctok, B, (long)Lm * dim, (long)Lm * dim, s));
-    HIPCHK(launch_split(ctok, dim, nullptr, 0, 0, 0, w.cpl.hi, w.cpl.lo, dp, B * Lm, dim, 0, s, w.cpl.f16));
+    HIPCHK(launch_split(ctok, dim, nullptr, 0, 0, 0, w.cpl.hi, w.cpl.lo, dp, B * Lm, dim, 0, s, w.cpl.fmt));
     HIPCHK(launch_bcast_rows(m->null_cond, cs.condadd, B * n_cond, dim, dim, s));
   } else {
     // to_prompt_cond: mean over n -> Linear -> SiLU (NS2:858-862)
@@ -635,7 +655,7 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
     // perceiver resampler (NS2:532-579)
     const int Nctx = w.Nctx;
     if (m->has_proj) {
-      HIPCHK(launch_split(prompt, dprompt, nullptr, 0, 0, 0, w.ctxp.hi, w.ctxp.lo, dpp, B * n_prompt, dprompt, 0, s, w.ctxp.f16));
+      HIPCHK(launch_split(prompt, dprompt, nullptr, 0, 0, 0, w.ctxp.hi, w.ctxp.lo, dpp, B * n_prompt, dprompt, 0, s, w.ctxp.fmt));
       NSCHK(gemm_f32(m->w_proj, w.ctxp.hi, w.ctxp.lo, dpp, B * n_prompt, 0, 1, 0, m->b_proj, nullptr, 0, w.projf, dim, prec, s));
       HIPCHK(hipMemcpy2DAsync(w.ctxf + (size_t)Lm * dim, (size_t)Nctx * dim * 4, w.projf, (size_t)n_prompt * dim * 4,
                               (size_t)n_prompt * dim * 4, B, hipMemcpyDeviceToDevice, s));
@@ -649,14 +669,14 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
       // context = cat(latents, x)  (NS2:1060-1061, cross_attn_include_queries)
       HIPCHK(hipMemcpy2DAsync(w.ctxf, (size_t)Nctx * dim * 4, w.latf, (size_t)Lm * dim * 4, (size_t)Lm * dim * 4, B,
                               hipMemcpyDeviceToDevice, s));
-      HIPCHK(launch_split(w.ctxf, dim, nullptr, 0, 0, 0, w.ctxp.hi, w.ctxp.lo, dp, B * Nctx, dim, 0, s, w.ctxp.f16));
-      HIPCHK(launch_split(w.latf, dim, nullptr, 0, 0, 0, w.latp.hi, w.latp.lo, dp, B * Lm, dim, 0, s, w.latp.f16));
-      NSCHK(gemm_split(r.q, w.latp.hi, w.latp.lo, dp, B * Lm, 0, 1, 0, nullptr, w.qk.hi, w.qk.lo, a, prec, s));
+      HIPCHK(launch_split(w.ctxf, dim, nullptr, 0, 0, 0, w.ctxp.hi, w.ctxp.lo, dp, B * Nctx, dim, 0, s, w.ctxp.fmt));
+      HIPCHK(launch_split(w.latf, dim, nullptr, 0, 0, 0, w.latp.hi, w.latp.lo, dp, B * Lm, dim, 0, s, w.latp.fmt));
+      NSCHK(gemm_split(r.q, w.latp.hi, w.latp.lo, dp, B * Lm, 0, 1, 0, nullptr, w.qk.hi, w.qk.lo, a, prec, s, -1, 0, w.qk.fmt));
       NSCHK(gemm_qkv(r.kv, w.ctxp.hi, w.ctxp.lo, dp, B * Nctx, Nctx, a, w.rkv.hi, w.rkv.lo, a, w.rvt.hi, w.rvt.lo, w.Nctxp, prec, s));
       NSCHK(attention_call(w.qk.hi, w.qk.lo, a, 0, w.rkv.hi, w.rkv.lo, a, 0, w.rvt, w.Nctxp, w.o, a, B, H, Lm, Nctx, prec, s));
       NSCHK(gemm_f32(r.out, w.o.hi, w.o.lo, a, B * Lm, 0, 1, 0, nullptr, w.latf, dim, w.latf, dim, prec, s));
       // FeedForward without conv (NS2:1009-1025)
-      HIPCHK(launch_split(w.latf, dim, nullptr, 0, 0, 0, w.latp.hi, w.latp.lo, dp, B * Lm, dim, 0, s, w.latp.f16));
+      HIPCHK(launch_split(w.latf, dim, nullptr, 0, 0, 0, w.latp.hi, w.latp.lo, dp, B * Lm, dim, 0, s, w.latp.fmt));
       NSCHK(gemm_geglu(r.ffin, w.latp.hi, w.latp.lo, dp, B * Lm, r.b_ffin, w.ffh.hi, w.ffh.lo, fp, prec, s));
       NSCHK(gemm_f32(r.ffout, w.ffh.hi, w.ffh.lo, fp, B * Lm, 0, 1, 0, r.b_ffout, w.latf, dim, w.latf, dim, prec, s));
     }
@@ -664,7 +684,7 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
     NSCHK(norm_call(w.latf, dim, B * Lm, dim, 0, m->g_resampler, nullptr, 0, w.cpl, dp, w.latf, dim, s));
     // cond_to_model_dim: 1x1 conv over channel-first cond [B, dprompt, n_cond] (NS2:978)
     HIPCHK(launch_transpose_f32(cond, B, dprompt, n_cond, w.condT, s));
-    HIPCHK(launch_split(w.condT, dprompt, nullptr, 0, 0, 0, w.ctxp.hi, w.ctxp.lo, dpp, B * n_cond, dprompt, 0, s, w.ctxp.f16));
+    HIPCHK(launch_split(w.condT, dprompt, nullptr, 0, 0, 0, w.ctxp.hi, w.ctxp.lo, dpp, B * n_cond, dprompt, 0, s, w.ctxp.fmt));
     NSCHK(gemm_f32(m->w_cond2model, w.ctxp.hi, w.ctxp.lo, dpp, B * n_cond, 0, 1, 0, m->b_cond2model, nullptr, 0, cs.condadd, dim, prec, s));
   }
   NSCHK(tap_f32(m, "c", ctok, (int64_t)B * Lm * dim, s));
@@ -750,7 +770,7 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
   HIPCHK(launch_skinny_linear(w.t, m->Tc, m->wt_cond, m->b_cond, w.condall, Jtot, B, m->Tc, Jtot, 0, w.skinny_ws, w.skinny_ws_bytes, s));
 
   // ---- x (+ aligned conditioning, NS2:976-992) -> split planes
-  HIPCHK(launch_split(x, dim, cond ? cs.condadd : nullptr, dim, n_cond, cond ? cs.n_cond_valid : 0, w.xs.hi, w.xs.lo, dp, M, dim, N, s, w.xs.f16));
+  HIPCHK(launch_split(x, dim, cond ? cs.condadd : nullptr, dim, n_cond, cond ? cs.n_cond_valid : 0, w.xs.hi, w.xs.lo, dp, M, dim, N, s, w.xs.fmt));
 
   // ---- wavenet (NS2:718-725)
   PROF(PC_GEMM_SPLIT, gemm_split(m->w_init, w.xs.hi, w.xs.lo, dp, M, 3, 1, N, m->b_init, w.h0.hi, w.h0.lo, dp, prec, s));
@@ -786,7 +806,7 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
     NSCHK(tap_f32(m, name, w.xres, (int64_t)M * dim, s));
     if (cond) {   // cross attention to the resampled prompt tokens (NS2:799-803)
       PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + 2 * dim, Jtot, w.xn, dp, nullptr, 0, s));
-      PROF(PC_GEMM_SPLIT, gemm_split(ly.cq, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, w.qk.hi, w.qk.lo, a, prec, s));
+      PROF(PC_GEMM_SPLIT, gemm_split(ly.cq, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, w.qk.hi, w.qk.lo, a, prec, s, -1, 0, w.qk.fmt));
       PROF(PC_ATTENTION, attention_call(w.qk.hi, w.qk.lo, a, 0, cs.ck[l].hi, cs.ck[l].lo, a, 0, cs.cvt[l], cs.Lmp, w.o, a, B, H, N, Lm, prec, s));
       PROF(PC_GEMM_F32, gemm_f32(ly.cout, w.o.hi, w.o.lo, a, M, 0, 1, 0, nullptr, w.xres, dim, w.xres, dim, prec, s));
     }

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ns2_fmt.h"
+
 typedef uint16_t bf16_t;                                           // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;          // MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(16))) float f32x16;         // 32x32 MFMA accumulator
@@ -77,6 +79,82 @@ NS2_DEVINL void split2f(float a, float b, uint32_t& hi, uint32_t& lo, int f16) {
   if (f16) { hi = cvt2h(a, b); lo = 0u; }
   else split2(a, b, hi, lo);
 }
+// ---- "mixed" precision (FMT_H8): fp16 main product + BOTH first-order correction terms in one fp8 MFMA.
+// x = h + l with h = half(x), l = x - h (|l| <= 2^-11 |x|).  a.w = a_h.w_h + (a_h.w_l + a_l.w_h) + O(2^-22): the bracket only has
+// to be right to a few bits, so it runs on the gfx950 block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the
+// 16-bit rate) with e5m2 operands: h8 = e5m2(x) (fp16's exponent range, so no data-dependent scale is needed) and
+// l8 = e5m2(l * 2^12); the constant 2^-12 is the instruction's E8M0 block scale.  One K = 64 fp8 instruction covers a 32-deep
+// k block: lanes 0-31 multiply a_h8 . w_l8, lanes 32-63 a_l8 . w_h8.  Measured on the CPU emulation of the whole Model
+// (tools/precision_study.py): 4e-5 from the fp32 reference, against 5.5e-4 for the single fp16 product and 8e-6 for bf16 x3.
+// Storage: the interleaved 128-B line of 32 logical columns is [half x 32 | h8 x 32 | l8 x 32]; pointer convention as for
+// the bf16 split planes (the "lo" pointer is hi + 32 elements = the byte half of the line).
+constexpr float H8_LO_SCALE = 4096.0f;            // 2^12
+constexpr int H8_E8M0_LO = 127 - 12;              // E8M0 code of 2^-12
+constexpr int H8_E8M0_ONE = 127;
+constexpr float H8_MAX = 57344.0f;                // largest finite e5m2 (< 65504: one clamp serves the half and the e5m2 parts)
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// (a, b) -> packed halves, packed e5m2(a, b) and packed e5m2 of the scaled remainders (each in the low 16 bits)
+NS2_DEVINL void cvt2_h8(float a, float b, uint32_t& h16, uint32_t& h8, uint32_t& l8) {
+  a = fminf(fmaxf(a, -H8_MAX), H8_MAX);
+  b = fminf(fmaxf(b, -H8_MAX), H8_MAX);
+  f32x2_t v = {a, b};
+  f16x2_t h = __builtin_convertvector(v, f16x2_t);
+  f32x2_t r = (v - __builtin_convertvector(h, f32x2_t)) * H8_LO_SCALE;
+  h16 = __builtin_bit_cast(uint32_t, h);
+  h8 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xffffu;
+  l8 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(fminf(fmaxf(r.x, -H8_MAX), H8_MAX), fminf(fmaxf(r.y, -H8_MAX), H8_MAX), 0, false) & 0xffffu;
+}
+NS2_DEVINL float bf8_to_f(uint32_t byte) {        // e5m2 -> fp32 (e5m2 is the top byte of an IEEE half)
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)(byte << 8));
+}
+
+// Store two adjacent logical columns (c0 even) / four (c0 % 4 == 0) of ONE row of a split-plane matrix in format `fmt`.
+// `row` = address of the row's first element (physical), il = the row is made of interleaved 128-B lines (bf16 with a lo
+// plane, or FMT_H8).
+NS2_DEVINL void store_cols2(bf16_t* row, int c0, float v0, float v1, int fmt, bool il) {
+  if (fmt == FMT_H8) {
+    uint32_t h16, h8, l8;
+    cvt2_h8(v0, v1, h16, h8, l8);
+    bf16_t* line = row + ((c0 & ~31) << 1);
+    *reinterpret_cast<uint32_t*>(line + (c0 & 31)) = h16;
+    unsigned char* bytes = reinterpret_cast<unsigned char*>(line) + 64 + (c0 & 31);
+    *reinterpret_cast<uint16_t*>(bytes) = (uint16_t)h8;
+    *reinterpret_cast<uint16_t*>(bytes + 32) = (uint16_t)l8;
+  } else if (fmt == FMT_F16) {
+    *reinterpret_cast<uint32_t*>(row + c0) = cvt2h(v0, v1);
+  } else {
+    uint32_t ph, pl;
+    split2(v0, v1, ph, pl);
+    bf16_t* p = row + (il ? (((c0 & ~31) << 1) | (c0 & 31)) : c0);
+    *reinterpret_cast<uint32_t*>(p) = ph;
+    if (il) *reinterpret_cast<uint32_t*>(p + 32) = pl;
+  }
+}
+NS2_DEVINL void store_cols4(bf16_t* row, int c0, float v0, float v1, float v2, float v3, int fmt, bool il) {
+  if (fmt == FMT_H8) {
+    uint32_t ha, hb, h8a, h8b, l8a, l8b;
+    cvt2_h8(v0, v1, ha, h8a, l8a);
+    cvt2_h8(v2, v3, hb, h8b, l8b);
+    bf16_t* line = row + ((c0 & ~31) << 1);
+    *reinterpret_cast<uint2*>(line + (c0 & 31)) = make_uint2(ha, hb);
+    unsigned char* bytes = reinterpret_cast<unsigned char*>(line) + 64 + (c0 & 31);
+    *reinterpret_cast<uint32_t*>(bytes) = h8a | (h8b << 16);
+    *reinterpret_cast<uint32_t*>(bytes + 32) = l8a | (l8b << 16);
+  } else if (fmt == FMT_F16) {
+    *reinterpret_cast<uint2*>(row + c0) = make_uint2(cvt2h(v0, v1), cvt2h(v2, v3));
+  } else {
+    uint32_t h01, l01, h23, l23;
+    split2(v0, v1, h01, l01);
+    split2(v2, v3, h23, l23);
+    bf16_t* p = row + (il ? (((c0 & ~31) << 1) | (c0 & 31)) : c0);
+    *reinterpret_cast<uint2*>(p) = make_uint2(h01, h23);
+    if (il) *reinterpret_cast<uint2*>(p + 32) = make_uint2(l01, l23);
+  }
+}
+// does a matrix of this format / lo pointer use interleaved 128-B lines?
+NS2_DEVINL bool fmt_il(int fmt, const void* lo) { return fmt == FMT_H8 || lo != nullptr; }
+
 // one 32x32x16 MFMA on 16-bit operands of either format
 template <bool F16>
 NS2_DEVINL f32x16 mma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {

@@ -14,14 +14,15 @@ void set_error(const char* fmt, ...);
 struct PackedW {                 // bf16 split-plane weight, rows padded to 128, K contiguous
   bf16_t* hi = nullptr; bf16_t* lo = nullptr;
   int rows_p = 0, ldk = 0, N = 0, nkt = 0, kt_per_tap = 0;
-  int f16 = 0;                   // hi plane holds IEEE half instead of bf16 (precision 2, no lo plane)
+  int fmt = 0;                   // PlaneFmt: bf16 planes (precisions 1 / 3), dense IEEE half (2), FMT_H8 lines (4)
 };
 
 int gemm_f32(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
              const float* bias, const float* resid, int ldr, float* out, int ldo, int prec, hipStream_t s, int pad_left = -1,
              int act = 0);
 int gemm_split(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
-               const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left = -1, int act = 0);
+               const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left = -1, int act = 0,
+               int out_fmt = -1);
 int gemm_geglu(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, const float* pbias, bf16_t* o_hi,
                bf16_t* o_lo, int ldo, int prec, hipStream_t s);
 int gemm_qkv(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int seq_len, int split_col,
@@ -30,7 +31,7 @@ int gemm_wavenet(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int l
                  int dil_z, int nz, const float* b_conv, const float* b_res, long bias_zs, const float* film, int film_ld,
                  long film_zs, bf16_t* o_hi, bf16_t* o_lo, int ldo, long out_zs, int out_ncols, int prec, hipStream_t s);
 
-int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, int f16, PackedW* out,
+int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, int precision, PackedW* out,
                        std::vector<void*>* owned, hipStream_t s);
 std::vector<int> geglu_row_map(int f, int rows_p);
 

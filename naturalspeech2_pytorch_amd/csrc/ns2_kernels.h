@@ -6,6 +6,8 @@
 
 #include <atomic>
 
+#include "ns2_fmt.h"
+
 typedef uint16_t bf16_t;
 
 namespace ns2 {
@@ -65,12 +67,15 @@ struct GemmArgs {
   int nz; long a_zs, w_zs, bias_zs, film_zs, out_zs;
   int pad_left;      // conv: zero rows in front of the sequence (-1 = causal: conv_taps-1); k=9 'same' padding = 4
   int act;           // 1 = SiLU after the bias (EPI_F32 / EPI_SPLIT)
-  int f16;           // operands and split-plane outputs are IEEE half (hi plane only) instead of bf16; set by launch_gemm
-                     // for nsplit == 2 ("half" precision: one fp16 product)
+  int out_fmt;       // PlaneFmt of the split-plane output (ns2_common.h).  -1 = "the operand format of the precision":
+                     // bf16 planes for 1 / 3, dense IEEE half for 2, FMT_H8 for 4.  Attention operands (q, k: EPI_QKV
+                     // columns < split_col, the cross-attention q projection) are IEEE half also at precision 4.
+  int vt_fmt;        // PlaneFmt of the transposed value planes (FMT_BF16 or FMT_F16); set by launch_gemm
 };
 
-hipError_t launch_gemm(const GemmArgs& g, int nsplit, hipStream_t s);   // dispatches gemm.hip / gemm2.hip by shape;
-                                                                        // nsplit: 3 bf16x3, 1 bf16, 2 fp16 single product
+// precision: 3 = bf16 x3 ("exact"), 1 = bf16 ("fast"), 2 = one IEEE-half product ("half"), 4 = half product + both
+// first-order correction terms on the fp8 MFMA ("mixed", FMT_H8 operands).  Dispatches gemm.hip / gemm2.hip by shape.
+hipError_t launch_gemm(const GemmArgs& g, int precision, hipStream_t s);
 void force_gemm_kernel(int k);                                          // 0 auto, 1 = 128x128, 2 = 256x256 (test hook)
 
 // flash attention forward, head dim 64, non-causal (ATT:77-155 hot path)
@@ -79,12 +84,13 @@ struct AttnArgs {
   const bf16_t* k_hi; const bf16_t* k_lo; int ldk;     // [B*Nk, ldk], head h at columns k_col0 + 64h
   const bf16_t* vt_hi; const bf16_t* vt_lo; int vt_ld; // [B][H*64][vt_ld] transposed values
   bf16_t* o_hi; bf16_t* o_lo; int ldo;                 // [B*Nq, ldo], head h at columns 64h
+  int o_fmt;                                           // PlaneFmt of o (-1: the operand format; FMT_H8 feeds a precision-4 GEMM)
   int q_col0, k_col0;
   int B, H, Nq, Nk;
   float scale;
   const unsigned char* kmask;                            // optional key-padding mask [B, Nk], 1 = attend (ATT:92-94, 136-138)
-};                                                       // launch_attention nsplit: 3 bf16x3, 1 bf16, 2 fp16
-hipError_t launch_attention(const AttnArgs& a, int nsplit, hipStream_t s);
+};                                                       // precision: 3 bf16x3, 1 bf16, 2 and 4: one IEEE-half product
+hipError_t launch_attention(const AttnArgs& a, int precision, hipStream_t s);
 
 // RMSNorm (NS2:727-746): out = x / max(|x|, 1e-12) * sqrt(d) [* gamma] [* g_c + b_c]  -> split planes
 struct NormArgs {
@@ -94,13 +100,13 @@ struct NormArgs {
   bf16_t* out_hi; bf16_t* out_lo; int ldo;
   float* out_f; int ldo_f;           // optional fp32 copy (e.g. resampler output)
   int M, d, seq_len;
-  int f16;                           // write IEEE half instead of bf16 (hi plane only)
+  int fmt;                           // PlaneFmt of the output planes
 };
 hipError_t launch_rmsnorm(const NormArgs& a, hipStream_t s);
 
 // x (+ add) -> split planes, with optional zero padding to ldo columns
 hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, int add_rows_per_batch, int add_valid_rows,
-                        bf16_t* out_hi, bf16_t* out_lo, int ldo, int M, int d, int seq_len, hipStream_t s, int f16 = 0);
+                        bf16_t* out_hi, bf16_t* out_lo, int ldo, int M, int d, int seq_len, hipStream_t s, int fmt = 0);
 
 // LearnedSinusoidalPosEmb + Linear(d+1, dt) + SiLU (NS2:108-120, 839-843): times[B] -> out[B, ld_out] columns [0, dt)
 // wt is the Linear weight stored K-major [dim+1, dt]; feat_ws is a [B, dim+1] fp32 scratch.
@@ -123,7 +129,7 @@ hipError_t launch_mean_rows(const float* in, int B, int n, int d, float* out, hi
 hipError_t launch_bcast_rows(const float* src, float* out, int B, long row_elems, long ld_out, hipStream_t s);
 
 hipError_t launch_embedding(const int64_t* ids, const float* table, float* out, long n, int dim, long pad_id, hipStream_t s);
-hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s, int f16 = 0);
+hipError_t launch_join(const bf16_t* hi, const bf16_t* lo, int ld, float* out, int ldo, long M, int d, hipStream_t s, int fmt = 0);
 hipError_t launch_transpose_into(const float* src, int R, int C, float* dst, long ld_dst, long col_off, hipStream_t s);
 
 // DDIM update (NS2:1396-1429), objective 'v'/'eps'/'x0', sigmoid/cosine/linear schedule evaluated on device
@@ -142,7 +148,7 @@ hipError_t launch_cfg_mix(const float* cond, const float* null, float* out, long
 
 // weight packing: fp32 [rows, C, T] (T taps, 1 for linear) -> split planes [rows_p, T*Cp]; row_map[r] = source row or -1
 hipError_t launch_pack_weight(const float* src, int C, int T, int Cp, const int* row_map, int rows_p, bf16_t* dst_hi,
-                              bf16_t* dst_lo, int ldk, int k_off, hipStream_t s, int f16 = 0);
+                              bf16_t* dst_lo, int ldk, int k_off, hipStream_t s, int fmt = 0);
 
 // EnCodec residual VQ encode (HFENC:364-369, 424-447)
 struct RvqArgs {

@@ -126,7 +126,7 @@ class _NativeState:
 
 _CFG_KEYS = ("dim", "depth", "dim_head", "heads", "ff_mult", "wavenet_layers", "wavenet_stacks", "dim_cond_mult",
              "condition_on_prompt", "dim_prompt", "num_latents_m", "resampler_depth")
-_PRECISIONS = {"exact": 3, "half": 2, "fast": 1}
+_PRECISIONS = {"exact": 3, "mixed": 4, "half": 2, "fast": 1}
 
 
 # ------------------------------------------------------------------------------------------ HIP execution mixin

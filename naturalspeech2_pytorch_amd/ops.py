@@ -28,23 +28,31 @@ def round_up(x: int, m: int) -> int:
 
 
 class Planes:
-    """A split-plane matrix [rows, ld] held by the library's layout (csrc/ns2_common.h).
+    """A split-plane matrix [rows, ld] held by the library's layout (csrc/ns2_common.h).  `ld` is always the LOGICAL column
+    count (a multiple of 32).  Formats (`fmt`):
 
-    With a lo plane ("interleaved", what precision 3 needs) `buf` is ONE bf16 tensor [rows, 2*ld]: every 32 logical columns
-    occupy a 128-byte line [hi(32) | lo(32)], so the lo pointer is the hi pointer + 32 elements.  Without (hi only) `buf` is
-    the dense [rows, ld] hi plane: bf16 for precision 1, IEEE half (`f16=True`) for precision 2.  `ld` is always the LOGICAL
-    column count (a multiple of 32).
+      "bf16"  with a lo plane ("interleaved", what precision 3 needs) `buf` is ONE bf16 tensor [rows, 2*ld]: every 32 logical
+              columns occupy a 128-byte line [hi(32) | lo(32)], so the lo pointer is the hi pointer + 32 elements; without
+              (precision 1) `buf` is the dense [rows, ld] hi plane;
+      "f16"   one dense IEEE-half plane [rows, ld] (precision 2, and the attention operands of precision 4);
+      "h8"    interleaved 128-byte lines [half(32) | e5m2(x)(32 bytes) | e5m2((x - half(x)) * 2^12)(32 bytes)] (precision 4).
     """
-    __slots__ = ("buf", "rows", "ld", "has_lo", "f16")
+    __slots__ = ("buf", "rows", "ld", "has_lo", "fmt")
 
-    def __init__(self, buf: torch.Tensor, rows: int, ld: int, has_lo: bool, f16: bool = False):
-        assert not (f16 and has_lo), "IEEE-half planes have no lo part"
-        self.buf, self.rows, self.ld, self.has_lo, self.f16 = buf, rows, ld, has_lo, f16
+    def __init__(self, buf: torch.Tensor, rows: int, ld: int, has_lo: bool, fmt: str = "bf16"):
+        assert fmt in ("bf16", "f16", "h8")
+        assert not (fmt == "f16" and has_lo), "IEEE-half planes have no lo part"
+        assert not (fmt == "h8" and not has_lo), "h8 planes are interleaved lines"
+        self.buf, self.rows, self.ld, self.has_lo, self.fmt = buf, rows, ld, has_lo, fmt
 
     @property
-    def precision_ok(self):
-        """precisions this operand can be multiplied at"""
-        return (2,) if self.f16 else ((1, 3) if self.has_lo else (1,))
+    def f16(self):
+        return self.fmt == "f16"
+
+    @property
+    def precision(self):
+        """a precision whose kernels read / write this format"""
+        return {"bf16": 3 if self.has_lo else 1, "f16": 2, "h8": 4}[self.fmt]
 
     @property
     def device(self):
@@ -57,40 +65,56 @@ class Planes:
 
     @property
     def lo(self) -> Optional[int]:
-        """device address of the lo plane = hi + 32 bf16 elements, or None for the dense hi-only layout"""
+        """device address of the second half of the lines = hi + 32 elements, or None for a dense single plane"""
         return self.buf.data_ptr() + 64 if self.has_lo else None
 
     def hi_plane(self) -> torch.Tensor:
-        """the logical hi plane as a dense [rows, ld] bf16 tensor (copy)"""
+        """the logical hi plane as a dense [rows, ld] 16-bit tensor (copy)"""
         if not self.has_lo:
             return self.buf.reshape(self.rows, self.ld).clone()
         return self.buf.reshape(self.rows, self.ld // 32, 2, 32)[:, :, 0, :].reshape(self.rows, self.ld).contiguous()
 
+    def byte_planes(self):
+        """h8 only: (e5m2(x), e5m2((x - half(x)) * 2^12)) as uint8 tensors [rows, ld]"""
+        assert self.fmt == "h8"
+        b = self.buf.reshape(self.rows, self.ld // 32, 2, 32)[:, :, 1, :].contiguous().view(torch.uint8)
+        b = b.reshape(self.rows, self.ld // 32, 64)
+        return b[:, :, :32].reshape(self.rows, self.ld).contiguous(), b[:, :, 32:].reshape(self.rows, self.ld).contiguous()
+
     def hi_only(self) -> "Planes":
-        return Planes(self.hi_plane(), self.rows, self.ld, False)
+        return Planes(self.hi_plane(), self.rows, self.ld, False, "f16" if self.fmt != "bf16" else "bf16")
 
 
-def empty_planes(rows: int, cols: int, device, lo: bool = True, zero: bool = False, f16: bool = False) -> Planes:
-    lo = lo and not f16
+def _fmt_of(precision: int, attention_operand: bool = False):
+    """(has_lo, fmt) of what a kernel writes at `precision`; attention operands (q, k, V^T) are IEEE half at precision 4"""
+    if precision == 2 or (precision == 4 and attention_operand):
+        return False, "f16"
+    if precision == 4:
+        return True, "h8"
+    return True, "bf16"              # precision 1 kernels read the hi plane of the interleaved layout too
+
+
+def empty_planes(rows: int, cols: int, device, lo: bool = True, zero: bool = False, fmt: str = "bf16") -> Planes:
+    lo = (lo and fmt == "bf16") or fmt == "h8"
     assert cols % 32 == 0 or not lo, "interleaved split planes come in 32-column blocks"
     alloc = torch.zeros if zero else torch.empty
-    dt = torch.float16 if f16 else torch.bfloat16
-    return Planes(alloc(rows, cols * (2 if lo else 1), dtype=dt, device=device), rows, cols, lo, f16)
+    dt = torch.bfloat16 if fmt == "bf16" else torch.float16
+    return Planes(alloc(rows, cols * (2 if lo else 1), dtype=dt, device=device), rows, cols, lo, fmt)
 
 
-def _pfmt(precision: int) -> dict:
-    """plane format a kernel writes at `precision`: 3 -> interleaved bf16 hi/lo, 1 -> (we still carry both planes, the
-    kernels read hi), 2 -> one IEEE-half plane"""
-    return dict(lo=precision != 2, f16=precision == 2)
+def _out_planes(rows, cols, device, precision, attention_operand=False, zero=False):
+    lo, fmt = _fmt_of(precision, attention_operand)
+    return empty_planes(rows, cols, device, lo, zero, fmt)
 
 
 def split(x: torch.Tensor, ldo: Optional[int] = None, lo: bool = True, precision: int = 3) -> Planes:
-    """fp32 [M, d] -> split planes [M, ldo] (zero padded); precision 2 -> one IEEE-half plane."""
+    """fp32 [M, d] -> split planes [M, ldo] (zero padded) in the operand format of `precision`."""
     x = _f32(x)
     M, d = x.shape
     ldo = ldo or round_up(d, 32)
-    out = empty_planes(M, ldo, x.device, lo, f16=precision == 2)
-    check(_lib.load().ns2_split_f32(x.data_ptr(), d, M, d, out.hi, out.lo, ldo, 2 if out.f16 else 3, _stream()), "ns2_split_f32")
+    has_lo, fmt = _fmt_of(precision)
+    out = empty_planes(M, ldo, x.device, lo and has_lo, fmt=fmt)
+    check(_lib.load().ns2_split_f32(x.data_ptr(), d, M, d, out.hi, out.lo, ldo, out.precision, _stream()), "ns2_split_f32")
     return out
 
 
@@ -98,7 +122,7 @@ def join(p: Planes, d: Optional[int] = None) -> torch.Tensor:
     M, ld = p.rows, p.ld
     d = d or ld
     out = torch.empty(M, d, dtype=torch.float32, device=p.device)
-    check(_lib.load().ns2_join_f32(p.hi, p.lo, ld, out.data_ptr(), d, M, d, 2 if p.f16 else 3, _stream()), "ns2_join_f32")
+    check(_lib.load().ns2_join_f32(p.hi, p.lo, ld, out.data_ptr(), d, M, d, p.precision, _stream()), "ns2_join_f32")
     return out
 
 
@@ -106,10 +130,10 @@ class PackedWeight:
     """Library-owned packed weight (ns2_weight)."""
 
     def __init__(self, w: torch.Tensor, geglu: bool = False, extra1x1: Optional[torch.Tensor] = None, precision: int = 3):
-        """precision 1 / 3: interleaved bf16 planes (serve both); 2: dense IEEE half (serves precision 2 only)"""
+        """precision 1 / 3: interleaved bf16 planes (serve both); 2: dense IEEE half; 4: h8 lines (each serves only itself)"""
         import ctypes
         w = _f32(w)
-        self.f16 = precision == 2
+        self.precision = precision
         self.rows, self.cols = w.shape[0], w.shape[1]
         self.taps = w.shape[2] if w.ndim == 3 else 1
         self.geglu = geglu
@@ -143,7 +167,7 @@ def linear_split(w: PackedWeight, a: Planes, bias=None, conv_taps=0, dilation=1,
                  act=0) -> Planes:
     M = a.rows
     ldo = ldo or round_up(w.rows, 32)
-    out = empty_planes(M, ldo, a.device, **_pfmt(precision))
+    out = _out_planes(M, ldo, a.device, precision)
     check(_lib.load().ns2_linear_split(w.handle, a.hi, a.lo, a.ld, M, conv_taps, dilation, seq_len, _p(bias),
                                        out.hi, out.lo, ldo, pad_left, act, precision, _stream()), "ns2_linear_split")
     return out
@@ -160,7 +184,7 @@ def linear_geglu(w: PackedWeight, a: Planes, packed_bias: torch.Tensor, precisio
     M = a.rows
     f = w.rows // 2
     ldo = round_up(f, 32)
-    out = empty_planes(M, ldo, a.device, **_pfmt(precision))
+    out = _out_planes(M, ldo, a.device, precision)
     check(_lib.load().ns2_linear_geglu(w.handle, a.hi, a.lo, a.ld, M, packed_bias.data_ptr(), out.hi,
                                        out.lo, ldo, precision, _stream()), "ns2_linear_geglu")
     return out
@@ -171,9 +195,9 @@ def linear_qkv(w: PackedWeight, a: Planes, seq_len: int, split_col: int, precisi
     M = a.rows
     B = M // seq_len
     vt_ld = round_up(seq_len, 32)
-    out = empty_planes(M, split_col, a.device, **_pfmt(precision))
+    out = _out_planes(M, split_col, a.device, precision, attention_operand=True)
     vt_rows = w.rows - split_col
-    vt = empty_planes(B * vt_rows, vt_ld, a.device, zero=True, **_pfmt(precision))
+    vt = _out_planes(B * vt_rows, vt_ld, a.device, precision, attention_operand=True, zero=True)
     check(_lib.load().ns2_linear_qkv(w.handle, a.hi, a.lo, a.ld, M, seq_len, split_col, out.hi,
                                      out.lo, split_col, vt.hi, vt.lo, vt_ld, precision, _stream()),
           "ns2_linear_qkv")
@@ -184,7 +208,7 @@ def wavenet_block(w: PackedWeight, a: Planes, seq_len: int, dilation: int, conv_
                   precision=3) -> Planes:
     M = a.rows
     ldo = round_up(w.rows, 32)
-    out = empty_planes(M, ldo, a.device, **_pfmt(precision))
+    out = _out_planes(M, ldo, a.device, precision)
     check(_lib.load().ns2_wavenet_block(w.handle, a.hi, a.lo, a.ld, M, seq_len, dilation, conv_bias.data_ptr(),
                                         res_bias.data_ptr(), _f32(film).data_ptr(), film.shape[1], out.hi,
                                         out.lo, ldo, precision, _stream()), "ns2_wavenet_block")
@@ -194,7 +218,7 @@ def wavenet_block(w: PackedWeight, a: Planes, seq_len: int, dilation: int, conv_
 def attention(q: Planes, k: Planes, vt: Planes, B: int, H: int, Nq: int, Nk: int, q_col0=0, k_col0=0, scale=0.125,
               precision=3, key_mask: Optional[torch.Tensor] = None) -> Planes:
     """vt: transposed value planes [B * H*64, vt_ld]; key_mask: optional bool/uint8 [B, Nk], True = attend (ATT:92-94)."""
-    out = empty_planes(B * Nq, H * 64, q.device, **_pfmt(precision))
+    out = _out_planes(B * Nq, H * 64, q.device, precision)
     km = None
     if key_mask is not None:
         km = key_mask.to(torch.uint8).contiguous()
@@ -209,7 +233,7 @@ def rmsnorm(x: torch.Tensor, seq_len: int = 0, gamma=None, cond=None, want_f32=F
     x = _f32(x)
     M, d = x.shape
     ldo = round_up(d, 32)
-    out = empty_planes(M, ldo, x.device, **_pfmt(precision))
+    out = _out_planes(M, ldo, x.device, precision)
     of = torch.empty(M, d, dtype=torch.float32, device=x.device) if want_f32 else None
     check(_lib.load().ns2_rmsnorm(x.data_ptr(), d, M, d, seq_len, _p(gamma), _p(cond), cond.shape[1] if cond is not None else 0,
                                   out.hi, out.lo, ldo, _p(of), d, precision, _stream()), "ns2_rmsnorm")

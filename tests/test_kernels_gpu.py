@@ -1,7 +1,9 @@
 """GPU parity tests of each HIP kernel family against plain torch fp32/fp64 restatements of the reference ops
-(called through the C ABI via naturalspeech2_pytorch_amd.ops).  Tolerances: precision 3 ("exact", bf16x3 split)
-must be fp32-class (<= 2e-5 relative L2 per op, vs the 1e-3 end-to-end budget of BASELINE.json); precision 1
-("fast", single bf16) is bf16-class."""
+(called through the C ABI via naturalspeech2_pytorch_amd.ops).  Per-op tolerances (relative L2) against the fp64
+result on the operand values the kernel sees: precision 3 ("exact", bf16x3 split) fp32-class 2e-5; precision 4 ("mixed":
+IEEE-half product + both correction terms on the fp8 MFMA) 8e-5; precision 2 ("half", one IEEE-half product) 8e-4 (only
+the weight rounding shows, the activations are compared as rounded); precision 1 ("fast", single bf16) bf16-class.
+Every GEMM-family and attention test runs at all four precisions and on both GEMM kernels."""
 import math
 import os
 
@@ -19,7 +21,8 @@ from oracle import rvq_oracle as R  # noqa: E402
 from tests.golden.gen import make_input  # noqa: E402
 
 DEV = torch.device("cuda:0")
-TOL = {3: 2e-5, 1: 2e-2}
+TOL = {3: 2e-5, 4: 8e-5, 2: 8e-4, 1: 2e-2}
+PRECS = [3, 4, 2, 1]
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -35,6 +38,11 @@ def rnd(*shape, seed=0, scale=1.0):
 
 def exact(p):        # value the kernels see for a split operand
     return ops.join(p).double()
+
+
+def asplit(x, prec, ldo=None):
+    """attention operands (q, k, V^T): IEEE half also at precision 4 (include/ns2hip.h)"""
+    return ops.split(x, ldo=ldo, precision=2 if prec == 4 else prec)
 
 
 @pytest.fixture(params=[1, 2], ids=["gemm128", "gemm256"])
@@ -76,15 +84,15 @@ def test_split_plane_layout_contract():
     assert rc != 0 and b"invalid" in lib.ns2_last_error().lower()  # lo pointer that is not hi + 32 elements is rejected
 
 
-@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("M,K,N", [(300, 96, 200), (1024, 512, 512), (128, 64, 64), (4096, 352, 128), (77, 1376, 512), (600, 1376, 300), (512, 96, 1365)])
 def test_linear_f32(M, K, N, prec, gemm_kernel):
     x = rnd(M, K, seed=2)
     w = rnd(N, K, seed=3, scale=1 / math.sqrt(K))
     b = rnd(N, seed=4)
     r = rnd(M, N, seed=5)
-    pw = ops.PackedWeight(w)
-    a = ops.split(x)
+    pw = ops.PackedWeight(w, precision=prec)
+    a = ops.split(x, precision=prec)
     y = ops.linear_f32(pw, a, bias=b, resid=r, precision=prec)
     ref = exact(a)[:, :K] @ w.double().t() + b.double() + r.double()
     e = rel(y, ref)
@@ -101,20 +109,20 @@ def conv_ref(x_bnc, w, b, dil):
     return F.conv1d(xt, w.double(), b.double() if b is not None else None, dilation=dil).transpose(1, 2)
 
 
-@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B,N,Cin,Cout,dil", [(3, 200, 96, 80, 1), (2, 300, 100, 100, 4), (2, 1024, 64, 64, 128), (1, 50, 170, 170, 1)])
 def test_causal_conv(B, N, Cin, Cout, dil, prec, gemm_kernel):
     x = rnd(B * N, Cin, seed=6)
     w = rnd(Cout, Cin, 3, seed=7, scale=1 / math.sqrt(3 * Cin))
     b = rnd(Cout, seed=8)
-    pw = ops.PackedWeight(w)
-    a = ops.split(x)
+    pw = ops.PackedWeight(w, precision=prec)
+    a = ops.split(x, precision=prec)
     ref = conv_ref(exact(a)[:, :Cin].reshape(B, N, Cin), w, b, dil).reshape(B * N, Cout)
     y = ops.linear_f32(pw, a, bias=b, conv_taps=3, dilation=dil, seq_len=N, precision=prec)
     e = rel(y, ref)
     assert e < TOL[prec], f"rel err {e}"
     ys = ops.linear_split(pw, a, bias=b, conv_taps=3, dilation=dil, seq_len=N, precision=prec)
-    assert rel(ops.join(ys, Cout), ref) < TOL[prec] + 1e-5
+    assert rel(ops.join(ys, Cout), ref) < TOL[prec] + (5e-4 if prec == 2 else 1e-5)       # + the output's own rounding
     assert ops.join(ys)[:, Cout:].abs().sum().item() == 0.0
 
 
@@ -145,41 +153,43 @@ def test_embedding_padding_ids():
     assert torch.equal(out, table[ids.masked_fill(ids < 0, 10)])
 
 
-@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("M,K,f", [(256, 64, 170), (500, 128, 341), (1024, 512, 1365)])
 def test_geglu(M, K, f, prec, gemm_kernel):
     x = rnd(M, K, seed=9)
     w = rnd(2 * f, K, seed=10, scale=1 / math.sqrt(K))
     b = rnd(2 * f, seed=11)
-    pw = ops.PackedWeight(w, geglu=True)
+    pw = ops.PackedWeight(w, geglu=True, precision=prec)
     pb = ops.geglu_pack_bias(b, f)
-    a = ops.split(x)
+    a = ops.split(x, precision=prec)
     out = ops.linear_geglu(pw, a, pb, precision=prec)
     h = exact(a)[:, :K] @ w.double().t() + b.double()
     ref = F.gelu(h[:, f:]) * h[:, :f]                              # NS2:1006-1007: first half x, second half gate
     assert out.ld == ops.round_up(f, 32)
     e = rel(ops.join(out, f), ref)
-    assert e < TOL[prec] + 1e-5, f"rel err {e}"
+    assert e < TOL[prec] + (5e-4 if prec == 2 else 1e-5), f"rel err {e}"
     assert ops.join(out)[:, f:].abs().sum().item() == 0.0
 
 
-@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B,N,K", [(2, 200, 64), (3, 135, 128), (2, 1024, 512)])
 def test_qkv(B, N, K, prec, gemm_kernel):
     a_dim = 512
     x = rnd(B * N, K, seed=12)
     w = rnd(3 * a_dim, K, seed=13, scale=1 / math.sqrt(K))
-    pw = ops.PackedWeight(w)
-    a = ops.split(x)
+    pw = ops.PackedWeight(w, precision=prec)
+    a = ops.split(x, precision=prec)
     qk, vt = ops.linear_qkv(pw, a, seq_len=N, split_col=2 * a_dim, precision=prec)
     ref = exact(a)[:, :K] @ w.double().t()
-    assert rel(ops.join(qk), ref[:, : 2 * a_dim]) < TOL[prec] + 1e-5
+    otol = TOL[prec] + (5e-4 if prec in (2, 4) else 1e-5)         # q / k / V^T are written as IEEE half at precisions 2 and 4
+    assert (qk.fmt, vt.fmt) == ({3: "bf16", 1: "bf16", 2: "f16", 4: "f16"}[prec],) * 2
+    assert rel(ops.join(qk), ref[:, : 2 * a_dim]) < otol
     v = ops.join(vt).reshape(B, a_dim, vt.ld)[:, :, :N]           # [B, a, N]
     vref = ref[:, 2 * a_dim:].reshape(B, N, a_dim).transpose(1, 2)
-    assert rel(v, vref) < TOL[prec] + 1e-5
+    assert rel(v, vref) < otol
 
 
-@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B,N,C,dil", [(2, 200, 64, 2), (2, 300, 128, 64), (1, 1024, 512, 128)])
 def test_wavenet_block(B, N, C, dil, prec, gemm_kernel):
     x = rnd(B * N, C, seed=14)
@@ -187,8 +197,8 @@ def test_wavenet_block(B, N, C, dil, prec, gemm_kernel):
     wr = rnd(C, C, 1, seed=16, scale=1 / math.sqrt(C))
     bc, br = rnd(C, seed=17), rnd(C, seed=18)
     film = rnd(B, 2 * C, seed=19)
-    pw = ops.PackedWeight(wc, extra1x1=wr)
-    a = ops.split(x)
+    pw = ops.PackedWeight(wc, extra1x1=wr, precision=prec)
+    a = ops.split(x, precision=prec)
     out = ops.wavenet_block(pw, a, N, dil, bc, br, film, precision=prec)
     xe = exact(a)[:, :C].reshape(B, N, C)
     h = conv_ref(xe, wc, bc, dil)
@@ -197,7 +207,7 @@ def test_wavenet_block(B, N, C, dil, prec, gemm_kernel):
     h = h.tanh() * h.sigmoid()
     ref = (h + conv_ref(xe, wr, br, 1)).reshape(B * N, C)          # NS2:627-636
     e = rel(ops.join(out, C), ref)
-    assert e < TOL[prec] + 1e-5, f"rel err {e}"
+    assert e < TOL[prec] + (5e-4 if prec == 2 else 1e-5), f"rel err {e}"
 
 
 def attn_ref(q, k, v, scale):
@@ -205,7 +215,7 @@ def attn_ref(q, k, v, scale):
     return torch.einsum("bhij,bhjd->bhid", s.softmax(-1), v)
 
 
-@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B,H,Nq,Nk", [(2, 8, 200, 200), (1, 8, 1024, 1024), (2, 8, 300, 32), (2, 8, 32, 135), (3, 4, 70, 16),
                                        (1, 2, 129, 65)])
 def test_attention(B, H, Nq, Nk, prec):
@@ -213,13 +223,14 @@ def test_attention(B, H, Nq, Nk, prec):
     q = rnd(B * Nq, a_dim, seed=20)
     k = rnd(B * Nk, a_dim, seed=21)
     v = rnd(B * Nk, a_dim, seed=22)
-    qp, kp = ops.split(q), ops.split(k)
+    qp, kp = asplit(q, prec), asplit(k, prec)
     vt_ld = ops.round_up(Nk, 32)
     # V^T planes [B, a, vt_ld]; poison the padding to prove the kernel masks it
     vt_f = torch.full((B, a_dim, vt_ld), float("nan"), device=DEV)
     vt_f[:, :, :Nk] = v.reshape(B, Nk, a_dim).transpose(1, 2)
-    vt = ops.split(vt_f.reshape(B * a_dim, vt_ld), ldo=vt_ld)
+    vt = asplit(vt_f.reshape(B * a_dim, vt_ld), prec, ldo=vt_ld)
     o = ops.attention(qp, kp, vt, B, H, Nq, Nk, precision=prec)
+    assert o.fmt == {3: "bf16", 1: "bf16", 2: "f16", 4: "h8"}[prec]
 
     def heads(p, n):
         return exact(p).reshape(B, n, H, 64).permute(0, 2, 1, 3)
@@ -228,7 +239,8 @@ def test_attention(B, H, Nq, Nk, prec):
     got = ops.join(o)
     assert torch.isfinite(got).all()
     e = rel(got, ref)
-    assert e < (3e-5 if prec == 3 else 2e-2), f"rel err {e}"
+    # precisions 2 and 4: one IEEE-half product for S and PV (P is rounded to half), output half / h8
+    assert e < {3: 3e-5, 1: 2e-2, 2: 8e-4, 4: 5e-4}[prec], f"rel err {e}"
 
 
 def test_attention_key_padding_mask():

@@ -1,0 +1,472 @@
+"""Round-2 parity hardening (VERDICT r1 "next" #1, #3, #4, #5, #6, #8): the benched precision modes under sweeps (weight
+seeds x diffusion times at the headline architecture), conditioned + classifier-free guidance, a 50-step DDIM trajectory,
+a large-activation stress, the mixed-mode plane format, repack after `.data` writes, the reference's sampling loop as the
+caller of the HIP model, the non-default schedules / objectives, concurrent models on separate streams (and devices when
+there are two), the sampler over an RCCL process group, RVQ at BASELINE config-4 size with every mismatch adjudicated,
+and the codec boundary class with HF EnCodec's SEANet injected.
+
+Measured numbers are also written to gpurun_out/parity_r2.json (copied to profiles/ by the builder)."""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+from naturalspeech2_pytorch_amd import EncodecWrapperHIP, HipRVQ, Model, NaturalSpeech2, ops  # noqa: E402
+from naturalspeech2_pytorch_amd import distributed as D  # noqa: E402
+from oracle import ns2_oracle as O  # noqa: E402
+from oracle import rvq_oracle as R  # noqa: E402
+from tests.golden.gen import make_input, make_weights  # noqa: E402
+
+DEV = torch.device("cuda:0")
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+GOLD = os.path.join(ROOT, "tests", "golden")
+TOL = 1e-3                                  # BASELINE.json north_star: <= 1e-3 relative to the fp32 reference
+# asserted ceilings per mode: "half" only has to meet the tolerance; "mixed" (the benched mode) must keep a >= 4x margin
+CEIL = {"exact": 1e-4, "mixed": 2.5e-4, "half": TOL}
+REPORT = {}
+
+
+def record(key, value):
+    REPORT[key] = value
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "parity_r2.json")
+    old = {}
+    if os.path.exists(path):
+        try:
+            old = json.load(open(path))
+        except Exception:
+            old = {}
+    old.update(REPORT)
+    json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def rel_rows(a, b):
+    a, b = a.double().cpu().flatten(1), b.double().cpu().flatten(1)
+    return ((a - b).norm(dim=1) / b.norm(dim=1)).tolist()
+
+
+def build(kw, seed=1, precision="exact", scale_weights=1.0):
+    m = Model(**kw, precision=precision)
+    own = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = make_weights(own, seed=seed)
+    if scale_weights != 1.0:
+        sd = {k: (v * scale_weights if k.endswith("weight") and v.ndim >= 2 else v) for k, v in sd.items()}
+    m.load_state_dict(sd)
+    return m.to(DEV).eval(), sd
+
+
+# ------------------------------------------------------------------------------------------ mixed mode vs the reference
+import glob  # noqa: E402
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "model_*.pt"))), ids=os.path.basename)
+def test_mixed_mode_matches_reference_golden(path):
+    """precision="mixed" (IEEE-half product + both first-order correction terms on the fp8 MFMA) against the reference's own
+    outputs, every golden configuration and guidance scale."""
+    fix = torch.load(path, weights_only=False)
+    kw, b, n = fix["kwargs"], fix["batch"], fix["n"]
+    m = Model(**kw, precision="mixed")
+    m.load_state_dict(make_weights(fix["shapes"], seed=fix["weight_seed"]))
+    m = m.to(DEV).eval()
+    x = make_input("x", (b, n, kw["dim"]), seed=fix["input_seed"]).to(DEV)
+    t = make_input("times", (b,), seed=fix["input_seed"], uniform=True).to(DEV)
+    kws = {}
+    if kw.get("condition_on_prompt"):
+        kws = dict(prompt=make_input("prompt", (b, fix["n_prompt"], kw["dim_prompt"]), seed=fix["input_seed"]).to(DEV),
+                   cond=make_input("cond", (b, kw["dim_prompt"], fix["n_cond"]), seed=fix["input_seed"]).to(DEV))
+    worst = 0.0
+    with torch.no_grad():
+        for name, ref in fix["outputs"].items():
+            y = m.forward_with_cond_scale(x, t, cond_scale=float(name.split("_")[-1]), **kws)
+            assert torch.isfinite(y).all()
+            worst = max(worst, rel(y, ref))
+    record(f"mixed_golden/{os.path.basename(path)}", worst)
+    assert 1e-7 < worst < CEIL["mixed"], f"mixed-mode rel {worst}"
+
+
+@pytest.mark.parametrize("precision", ["mixed", "half"])
+def test_precision_sweep_headline_architecture(precision):
+    """d512/L12 x 1024 frames: 8 weight seeds x diffusion times {0.002, 0.5, 0.999} (one utterance each), per-utterance error
+    against the fp32 oracle; the MAX over the sweep is what is asserted and what bench.py quotes."""
+    kw = dict(dim=512, depth=12)
+    times = torch.tensor([0.002, 0.5, 0.999])
+    errs = []
+    for seed in range(8):
+        m, sd = build(kw, seed=100 + seed, precision=precision)
+        x = make_input("x", (3, 1024, 512), seed=200 + seed)
+        with torch.no_grad():
+            y = m(x.to(DEV), times.to(DEV))
+            ref = O.model_forward(sd, x, times)
+        assert torch.isfinite(y).all()
+        errs.append(rel_rows(y, ref))
+        del m
+        torch.cuda.empty_cache()
+    flat = [e for row in errs for e in row]
+    record(f"sweep_d512_L12/{precision}", dict(max=max(flat), mean=sum(flat) / len(flat), per_seed_per_time=errs,
+                                               times=times.tolist(), seeds=8))
+    print(f"{precision}: max {max(flat):.2e} mean {sum(flat) / len(flat):.2e} over 8 seeds x 3 times")
+    assert max(flat) < CEIL[precision], f"{precision}: max rel err over the sweep {max(flat)}"
+
+
+@pytest.mark.parametrize("precision", ["mixed", "half"])
+def test_conditioned_cfg_d512(precision):
+    """BASELINE config 3 architecture with classifier-free guidance (two forwards mixed at cond_scale 1.3, NS2:914-927)."""
+    kw = dict(dim=512, depth=12, dim_prompt=512, condition_on_prompt=True)
+    m, sd = build(kw, seed=9, precision=precision)
+    b, n = 2, 512
+    x = make_input("x", (b, n, 512), seed=10)
+    t = make_input("times", (b,), seed=10, uniform=True)
+    prompt = make_input("prompt", (b, 103, 512), seed=10)
+    cond = make_input("cond", (b, 512, n), seed=10)
+    with torch.no_grad():
+        y = m.forward_with_cond_scale(x.to(DEV), t.to(DEV), prompt=prompt.to(DEV), cond=cond.to(DEV), cond_scale=1.3)
+        ref = O.model_forward_with_cond_scale(sd, x, t, prompt, cond, 1.3)
+    e = rel(y, ref)
+    record(f"conditioned_cfg_d512/{precision}", e)
+    assert torch.isfinite(y).all() and e < CEIL[precision], f"{precision}: rel {e}"
+
+
+def test_ddim_trajectory_50_steps():
+    """error compounding along a sampling trajectory: 50 DDIM steps at d128/L6 (timesteps=50), all precisions, against the
+    oracle's loop on the same injected noise"""
+    kw = dict(dim=128, depth=6)
+    noise = make_input("noise", (2, 256, 128), seed=31)
+    out = {}
+    ref = None
+    for precision in ("exact", "mixed", "half"):
+        m, sd = build(kw, seed=30, precision=precision)
+        d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=50)
+        y = d.sample(length=256, batch_size=2, noise=noise)
+        if ref is None:
+            with torch.no_grad():
+                ref = O.ddim_sample(sd, noise, 50)
+        assert torch.isfinite(y).all()
+        out[precision] = rel(y, ref)
+    record("ddim_50_steps_d128_L6", out)
+    print("50-step DDIM trajectory rel err:", {k: f"{v:.2e}" for k, v in out.items()})
+    assert out["exact"] < 1e-4 and out["mixed"] < 5e-4 and out["half"] < 5e-3, out
+
+
+def test_large_activation_stress():
+    """weights x8 (trained checkpoints have larger activations than N(0, 1/fan_in) init): outputs stay finite in every mode
+    (IEEE-half conversions saturate at +-65504 / +-57344 instead of producing inf) and the error is reported"""
+    kw = dict(dim=128, depth=6)
+    x = make_input("x", (2, 256, 128), seed=41) * 4.0
+    t = torch.tensor([0.3, 0.9])
+    out = {}
+    for scale in (2.0, 8.0):
+        for precision in ("exact", "mixed", "half"):
+            m, sd = build(kw, seed=40, precision=precision, scale_weights=scale)
+            with torch.no_grad():
+                y = m(x.to(DEV), t.to(DEV))
+                ref = O.model_forward(sd, x, t)
+            assert torch.isfinite(y).all(), f"{precision} x{scale}: non-finite output"
+            out[f"x{scale:g}/{precision}"] = rel(y, ref)
+    record("large_activation_stress_d128_L6", out)
+    print("stress rel err:", {k: f"{v:.2e}" for k, v in out.items()})
+    assert out["x2/exact"] < 1e-4 and out["x2/mixed"] < CEIL["mixed"] and out["x2/half"] < 2e-3, out
+    assert out["x8/exact"] < 1e-3, out
+
+
+def test_half_conversion_saturates():
+    x = torch.tensor([[1e6, -1e6, 65504.0, 7e4] + [0.0] * 28], device=DEV)
+    h = ops.join(ops.split(x, precision=2))[0, :4].tolist()
+    assert h == [65504.0, -65504.0, 65504.0, 65504.0]
+    m = ops.join(ops.split(x, precision=4))[0, :4]
+    assert torch.isfinite(m).all() and m[0].item() == 57344.0 and m[1].item() == -57344.0
+
+
+# ------------------------------------------------------------------------------------------ mixed-mode plane format
+def test_h8_plane_format_contract():
+    """include/ns2hip.h: precision-4 operands are 128-byte lines [half x 32 | e5m2(x) x 32 | e5m2((x - half(x)) * 2^12) x 32]"""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(70, 100, generator=g) * torch.logspace(-3, 3, 100)[None]).to(DEV)
+    p = ops.split(x, precision=4)
+    assert (p.fmt, p.rows, p.ld) == ("h8", 70, 128) and p.buf.shape == (70, 256) and p.buf.dtype == torch.float16
+    xc = x.cpu()
+    hi = xc.to(torch.float16)
+    assert torch.equal(p.hi_plane()[:, :100].cpu(), hi)
+    h8, l8 = p.byte_planes()
+    e_h8 = xc.to(torch.float8_e5m2).view(torch.uint8)
+    e_l8 = ((xc - hi.float()) * 4096.0).to(torch.float8_e5m2).view(torch.uint8)
+    assert torch.equal(h8[:, :100].cpu(), e_h8)                     # hardware v_cvt_pk_bf8_f32 == IEEE RNE e5m2
+    assert torch.equal(l8[:, :100].cpu(), e_l8)
+    assert p.buf.reshape(70, 4, 2, 32)[:, 3, 0, 4:].abs().sum().item() == 0            # zero padding (columns 100..127)
+    y = ops.join(p, 100)
+    assert rel(y, x) < 2 ** -13                                     # half + l8 * 2^-12 restores ~14 significand bits
+
+
+# ------------------------------------------------------------------------------------------ cache invalidation
+def test_param_data_mutation_triggers_repack():
+    """ema_pytorch writes the shadow model through `.data` (no version bump): `refresh_weights()` (called by sample()) must
+    notice by content and re-pack."""
+    m, sd = build(dict(dim=64, depth=1), seed=13)
+    x = make_input("x", (1, 40, 64), seed=14).to(DEV)
+    t = torch.tensor([0.3], device=DEV)
+    with torch.no_grad():
+        y0 = m(x, t)
+        w = getattr(m.transformer.layers[0], "1").to_q.weight
+        v0 = w._version
+        w.data.mul_(1.5)                                            # in-place through .data: version counter unchanged
+        assert w._version == v0
+        assert torch.equal(m(x, t), y0)                             # cheap signature cannot see it (documented)
+        assert m.refresh_weights() is True                          # content fingerprint does
+        y1 = m(x, t)
+        assert m.refresh_weights() is False
+    sd2 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    assert not torch.equal(y1, y0) and rel(y1, O.model_forward(sd2, x.cpu(), t.cpu())) < 1e-4
+    d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=2)
+    n = make_input("noise", (1, 40, 64), seed=15)
+    a = d.sample(length=40, noise=n)
+    getattr(m.transformer.layers[0], "1").to_q.weight.data.mul_(0.5)
+    b = d.sample(length=40, noise=n)                                # sample() refreshes by itself
+    assert not torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------ the reference's loop as caller
+def test_reference_caller_loop_drives_hip_model():
+    """NS2:1379-1431 restated as a caller (oracle.reference_caller_ddim_sample: per step `model.forward_with_cond_scale(audio,
+    times, prompt=, cond_scale=, cond=)` + the reference's unfused update chain in torch) around the HIP Model, against the
+    golden trajectory produced by the unmodified reference; and the fused sampler of this package against the same."""
+    fix = torch.load(os.path.join(GOLD, "ddim_uncond_d64.pt"), weights_only=False)
+    m = Model(**fix["kwargs"])
+    m.load_state_dict(make_weights(fix["shapes"], seed=fix["weight_seed"]))
+    m = m.to(DEV).eval()
+    noise = make_input("noise", (fix["batch"], fix["n"], fix["kwargs"]["dim"]), seed=fix["input_seed"])
+    out = O.reference_caller_ddim_sample(m, noise.to(DEV), fix["timesteps"])
+    assert rel(out, fix["output"]) < 5e-4
+    d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=fix["timesteps"])
+    assert rel(d.sample(length=fix["n"], batch_size=fix["batch"], noise=noise), out) < 1e-5
+
+
+@pytest.mark.parametrize("schedule", ["sigmoid", "cosine", "linear"])
+@pytest.mark.parametrize("objective", ["v", "eps", "x0"])
+def test_sampler_schedules_and_objectives(schedule, objective):
+    """NS2:1133-1148 schedules x NS2:1414-1422 objectives through the fused HIP update (cosine is unrunnable upstream:
+    restated intent, parity unpinned)"""
+    m, sd = build(dict(dim=64, depth=1), seed=50)
+    d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=4, noise_schedule=schedule, objective=objective)
+    noise = make_input("noise", (2, 48, 64), seed=51)
+    y = d.sample(length=48, batch_size=2, noise=noise)
+    with torch.no_grad():
+        ref = O.ddim_sample(sd, noise, 4, objective=objective, schedule=schedule)
+    assert rel(y, ref) < 5e-4, (schedule, objective, rel(y, ref))
+    # non-default schedule parameters go through the host-side schedule functions (same model steps)
+    d2 = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=4, noise_schedule="sigmoid", objective=objective,
+                        schedule_kwargs=dict(start=-3, end=3, tau=1))
+    if schedule == "sigmoid":
+        assert rel(d2.sample(length=48, batch_size=2, noise=noise), ref) < 5e-4
+
+
+# ------------------------------------------------------------------------------------------ no shared mutable state
+def test_two_models_on_two_streams_do_not_interfere():
+    """the library keeps no mutable host state and no library-owned scratch: two models driven from two
+    streams, interleaved, give the results of running each alone.  d=512 takes the split-K conditioning path."""
+    kw = dict(dim=512, depth=1, wavenet_layers=2, wavenet_stacks=1)
+    ma, _ = build(kw, seed=60)
+    mb, _ = build(kw, seed=61, precision="mixed")
+    xa, xb = make_input("x", (32, 64, 512), seed=62).to(DEV), make_input("x", (32, 64, 512), seed=63).to(DEV)
+    ta, tb = torch.rand(32, device=DEV), torch.rand(32, device=DEV)
+    with torch.no_grad():
+        ya, yb = ma(xa, ta), mb(xb, tb)
+        torch.cuda.synchronize()
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        outs_a, outs_b = [], []
+        for _ in range(6):
+            with torch.cuda.stream(sa):
+                outs_a.append(ma(xa, ta))
+            with torch.cuda.stream(sb):
+                outs_b.append(mb(xb, tb))
+        torch.cuda.synchronize()
+    assert all(torch.equal(o, ya) for o in outs_a) and all(torch.equal(o, yb) for o in outs_b)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two devices")
+def test_two_models_on_two_devices_one_process():
+    kw = dict(dim=64, depth=2)
+    outs = []
+    for i in range(2):
+        dev = torch.device("cuda", i)
+        m = Model(**kw)
+        sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=70)
+        m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        x = make_input("x", (2, 96, 64), seed=71)
+        t = make_input("times", (2,), seed=71, uniform=True)
+        with torch.cuda.device(dev), torch.no_grad():
+            outs.append(m(x.to(dev), t.to(dev)).cpu())
+    ref = O.model_forward(sd, x, t)
+    assert rel(outs[0], ref) < 1e-4 and torch.equal(outs[0], outs[1])
+
+
+def test_sharded_sample_over_rccl_world1():
+    """the data-parallel sampler with the real Model over an RCCL ("nccl") process group; world 1 on a one-GPU box, so the
+    collective degenerates but the whole code path (init, shard, all_gather, destroy) is the one the 8-GPU run takes"""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29700 + os.getpid() % 200)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        m, _ = build(dict(dim=64, depth=1), seed=18)
+        d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=3)
+        fn = lambda noise: d.ddim_sample(tuple(noise.shape), noise=noise)   # noqa: E731
+        out = D.sharded_sample(fn, total=5, length=32, dim=64, seed=9, device=DEV)
+        bufs = [torch.empty_like(out)]
+        dist.all_gather(bufs, out)                                   # RCCL really runs
+        direct = fn(D.utterance_noise(0, 5, 32, 64, seed=9, device=DEV))
+        assert torch.equal(bufs[0], direct) and out.shape == (5, 32, 64)
+    finally:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------ RVQ: test what is claimed
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_rvq_config4_size_every_mismatch_adjudicated(seed):
+    """BASELINE config 4 size (32 x 1024 frames x 8 codebooks x 1024 codes).  The claim is: indices equal to the reference
+    formula wherever that formula is well-defined.  `dist = -(|x|^2 - 2 x E^T + |E|^2)` evaluated in fp32 depends on the
+    BLAS summation order, so the oracle is run twice, in fp32 and in fp64: every row must equal the fp32 oracle, or -- at
+    its FIRST differing stage -- the fp64 oracle (i.e. the fp32 oracle itself is not the nearest code there)."""
+    cb = make_input("codebooks", (8, 1024, 128), seed=300 + seed)
+    x = make_input("latents", (32 * 1024, 128), seed=400 + seed)
+    codes, emb, ties = ops.rvq_encode(x.to(DEV), cb.to(DEV), count_ties=True)
+    codes = codes.cpu()
+    c32, e32, _ = R.rvq_encode(x, cb)
+    mism = (codes != c32).any(dim=-1).nonzero().flatten()
+    n_unexplained = 0
+    if len(mism):
+        c64, _, _ = R.rvq_encode(x[mism].double(), cb.double())
+        for i, r in enumerate(mism.tolist()):
+            q = int((codes[r] != c32[r]).float().argmax())
+            if not torch.equal(codes[r, : q + 1], c64[i, : q + 1]):
+                n_unexplained += 1
+    record(f"rvq_config4/seed{seed}", dict(rows=x.shape[0], rows_differing_from_fp32_oracle=len(mism),
+                                           unexplained=n_unexplained, near_tie_redecisions=int(ties.item())))
+    assert n_unexplained == 0, f"{n_unexplained} rows differ from BOTH the fp32 and the fp64 oracle"
+    same = torch.ones(x.shape[0], dtype=torch.bool)
+    same[mism] = False
+    assert torch.equal(emb.cpu()[same], e32[same])                  # summed embeddings bit-equal where the indices agree
+
+
+def _hf_encodec():
+    tf = pytest.importorskip("transformers")
+    torch.manual_seed(0)
+    model = tf.EncodecModel(tf.EncodecConfig()).eval()
+    g = torch.Generator().manual_seed(1)
+    for layer in model.quantizer.layers:                            # HF zero-initialises the codebooks (HFENC:355)
+        layer.codebook.embed.copy_(torch.randn(layer.codebook.embed.shape, generator=g))
+    return model.to(DEV)
+
+
+def test_encodec_wrapper_with_hf_seanet():
+    """the boundary class `codec(x, return_encoded=True)` on raw audio (BASELINE configs 1 / 4 input shape randn(4, 327680)):
+    HF EnCodec's SEANet encoder injected, RVQ in HIP, against HF's own quantizer on the same encoder output"""
+    hf = _hf_encodec()
+    codec = EncodecWrapperHIP.from_hf(hf).to(DEV).eval()
+    wav = make_input("wav", (4, 327680), seed=90).to(DEV)
+    with torch.no_grad():
+        emb, codes, _ = codec(wav, return_encoded=True)
+        lat = hf.encoder(wav[:, None])                               # [4, 128, 1024]
+        ref_codes = hf.quantizer.encode(lat, bandwidth=6.0)          # [8, 4, 1024]   (HFENC:424-438)
+        ref_emb = hf.quantizer.decode(ref_codes)                     # [4, 128, 1024] (HFENC:440-447)
+    assert emb.shape == (4, 1024, 128) and codes.shape == (4, 1024, 8) and codes.dtype == torch.int64
+    ref_codes = ref_codes.permute(1, 2, 0)
+    bad = (codes != ref_codes).any(dim=-1)
+    frac = bad.float().mean().item()
+    record("encodec_wrapper_hf", dict(frames=int(bad.numel()), frames_differing=int(bad.sum())))
+    if bad.any():                                                   # adjudicate against exact arithmetic like above
+        rows = bad.flatten().nonzero().flatten()
+        xr = lat.transpose(1, 2).reshape(-1, 128)[rows].double().cpu()
+        c64, _, _ = R.rvq_encode(xr, codec.rvq.codebooks.double().cpu())
+        mine, theirs = codes.reshape(-1, 8)[rows].cpu(), ref_codes.reshape(-1, 8)[rows].cpu()
+        for i in range(len(rows)):
+            q = int((mine[i] != theirs[i]).float().argmax())
+            assert torch.equal(mine[i, : q + 1], c64[i, : q + 1]), "index differs from HF's and from exact arithmetic"
+    assert frac < 1e-3
+    good = ~bad
+    assert torch.allclose(emb[good], ref_emb.transpose(1, 2)[good], atol=1e-5)
+    # curtail_from_left keeps the LAST whole frames (NS2:1445) and decode returns a waveform
+    emb2, _, _ = codec(wav[:, : 320 * 10 + 7], return_encoded=True, curtail_from_left=True)
+    assert emb2.shape == (4, 10, 128)
+    assert codec.decode(emb2).shape == (4, 1, 3200)
+
+
+def test_naturalspeech2_with_codec_composition():
+    """BASELINE config 1 as a composition (README:33-70): NaturalSpeech2(Model(dim=128, depth=6), codec): loss on raw audio
+    + backward, then sample() back to a waveform.  (timesteps reduced from 1000: the loop body is what test_ddim_* cover.)"""
+    hf = _hf_encodec()
+    codec = EncodecWrapperHIP.from_hf(hf).to(DEV)
+    model = Model(dim=128, depth=6).to(DEV)
+    d = NaturalSpeech2(model=model, codec=codec, timesteps=3)
+    raw = make_input("wav", (2, 32000), seed=91).to(DEV)
+    loss = d(raw)
+    loss.backward()
+    assert torch.isfinite(loss) and model.wavenet.init_conv.weight.grad is not None
+    d.eval()
+    audio = d.sample(length=64)
+    assert audio.shape == (1, 64 * 320) and torch.isfinite(audio).all()
+    # the RVQ cross-entropy term of NS2:1670-1684
+    d2 = NaturalSpeech2(model=model, codec=codec, timesteps=3, rvq_cross_entropy_loss_weight=0.1)
+    l2 = d2(raw)
+    assert torch.isfinite(l2) and l2.item() != loss.item()
+
+
+# ------------------------------------------------------------------------------------------ bench.py is driver-runnable
+def _run_bench(extra, env=None):
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--frames", "128",
+           "--dim", "64", "--depth", "1", "--no-secondary", "--no-side", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_single_gpu():
+    line = _run_bench(["--gpus", "1"])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["launches"] == 2 * 3
+    assert line["parity"]["live_rel_err_vs_fp32_oracle"]["mixed"] < 2.5e-4
+
+
+def test_bench_self_spawns_ranks_without_a_launcher():
+    """`python bench.py --gpus N` (no torchrun around it) must start N ranks itself.  On a one-GPU box
+    the two ranks share the device, so the process group is gloo here; on the 8-GPU node it is nccl = RCCL."""
+    line = _run_bench(["--gpus", "2"], env=dict(NS2_DIST_BACKEND="gloo"))
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["scaling"] == "weak"
+
+
+def test_conditional_sample_with_hip_prompt_encoder():
+    """NaturalSpeech2.sample on a conditional model with the reference keywords: `prompt` = codec latents [b, n_p, 128] goes
+    through the HIP SpeechPromptEncoder (NS2:1474-1475), the aligned conditioning comes in as `cond` (the duration / pitch
+    predictor is out of scope), classifier-free guidance at cond_scale 1.5; against the oracle's encoder + loop."""
+    kw = dict(dim=64, depth=1, dim_prompt=128, condition_on_prompt=True)
+    m, sd = build(kw, seed=80)
+    d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=3, dim_codebook=64).to(DEV).eval()
+    # a small prompt encoder (same class, reduced widths) so the CPU oracle stays cheap
+    from naturalspeech2_pytorch_amd import SpeechPromptEncoder
+    enc = SpeechPromptEncoder(64, dims=(96, 128), depth=1)
+    esd = make_weights({k: tuple(v.shape) for k, v in enc.state_dict().items()}, seed=81)
+    enc.load_state_dict(esd)
+    d.prompt_enc = enc.to(DEV).eval()
+    prompt = make_input("prompt", (2, 21, 64), seed=82)
+    cond = make_input("cond", (2, 128, 40), seed=82)
+    noise = make_input("noise", (2, 40, 64), seed=82)
+    text = torch.randint(0, 100, (2, 12))
+    y = d.sample(length=40, prompt=prompt.to(DEV), text=text.to(DEV), cond=cond.to(DEV), cond_scale=1.5, noise=noise)
+    with torch.no_grad():
+        p_enc = O.speech_prompt_encoder(prompt, esd, depth=1)
+        ref = O.ddim_sample(sd, noise, 3, prompt=p_enc, cond=cond, cond_scale=1.5)
+    assert y.shape == (2, 40, 64) and rel(y, ref) < 1e-3, rel(y, ref)

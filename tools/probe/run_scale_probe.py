@@ -1,0 +1,94 @@
+"""GPU-box probe of the block-scaled fp8 MFMA (tools/probe/mfma_scale_probe.hip): checks the operand model the "mixed"
+precision GEMM is built on,
+    D[i][j] = sum_{g in 0,1} sum_{t < 32} A[lane = i + 32 g][byte t] * B[lane = j + 32 g][byte t] * 2^(sa[i+32g]-127) * 2^(sb[j+32g]-127)
+with D in the standard 32x32 C layout, and measures the instruction rate.  Writes gpurun_out/scale_probe.json; on a mismatch
+also dumps structured one-hot experiments for offline analysis."""
+import ctypes, json, os, sys
+import torch
+
+here = os.path.dirname(os.path.abspath(__file__))
+outdir = os.path.join(here, "..", "..", "gpurun_out")
+os.makedirs(outdir, exist_ok=True)
+lib = ctypes.CDLL(os.path.join(here, "libscaleprobe.so"))
+P = ctypes.c_void_p
+lib.scale_probe_run.argtypes = [P, P, P, P, P, P]
+lib.scale_probe_rate.argtypes = [P, P, P, ctypes.c_int, ctypes.c_int, P]
+dev = torch.device("cuda:0")
+st = lambda: torch.cuda.current_stream().cuda_stream
+
+
+def run(A8, B8, sa, sb):
+    """A8, B8: uint8 [64, 32]; sa, sb: int32 [64] -> D [32, 32] (C layout decoded) and raw [64, 16]"""
+    a, b = A8.to(dev).contiguous(), B8.to(dev).contiguous()
+    sa, sb = sa.to(dev).int().contiguous(), sb.to(dev).int().contiguous()
+    d = torch.zeros(64, 16, device=dev)
+    rc = lib.scale_probe_run(a.data_ptr(), b.data_ptr(), sa.data_ptr(), sb.data_ptr(), d.data_ptr(), st())
+    torch.cuda.synchronize()
+    raw = d.cpu()
+    D = torch.zeros(32, 32)
+    for l in range(64):
+        for r in range(16):
+            D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31] = raw[l, r]
+    return rc, D, raw
+
+
+def f8(x):
+    return x.to(torch.float8_e5m2)
+
+
+def model(A8, B8, sa, sb):
+    Af = A8.view(torch.float8_e5m2).double() * torch.exp2(sa.double() - 127)[:, None]
+    Bf = B8.view(torch.float8_e5m2).double() * torch.exp2(sb.double() - 127)[:, None]
+    D = torch.zeros(32, 32, dtype=torch.float64)
+    for g in range(2):
+        D += Af[32 * g: 32 * g + 32] @ Bf[32 * g: 32 * g + 32].t()
+    return D
+
+
+out = {}
+g = torch.Generator().manual_seed(0)
+A = f8(torch.randn(64, 32, generator=g)).view(torch.uint8)
+B = f8(torch.randn(64, 32, generator=g)).view(torch.uint8)
+one = torch.full((64,), 127)
+rc, D, raw = run(A, B, one, one)
+ref = model(A, B, one, one)
+out["unit_scales_max_err"] = (D.double() - ref).abs().max().item()
+sa = torch.where(torch.arange(64) < 32, torch.tensor(127), torch.tensor(115))
+sb = torch.where(torch.arange(64) < 32, torch.tensor(120), torch.tensor(127))
+rc, D2, _ = run(A, B, sa, sb)
+ref2 = model(A, B, sa, sb)
+out["per_lane_scales_max_rel_err"] = ((D2.double() - ref2).abs().max() / ref2.abs().max()).item()
+rc, D3, _ = run(A, B, torch.full((64,), 115), one)
+out["uniform_A_scale_2^-12_max_rel_err"] = ((D3.double() - ref / 4096).abs().max() / (ref / 4096).abs().max()).item()
+ok = out["unit_scales_max_err"] < 1e-3 and out["per_lane_scales_max_rel_err"] < 1e-5 and out["uniform_A_scale_2^-12_max_rel_err"] < 1e-5
+out["operand_model_ok"] = bool(ok)
+if not ok:
+    # structured experiments: A one-hot (lane la, byte ta) = 1, B all ones except B[lane][t] = 2^t%8 -> which t pairs, which lanes
+    exps = {}
+    for la in (0, 3, 32, 35):
+        for ta in (0, 1, 5, 16, 31):
+            A1 = torch.zeros(64, 32, dtype=torch.uint8); A1[la, ta] = 0x3C          # 1.0 in e5m2
+            for tb in range(32):
+                B1 = torch.zeros(64, 32, dtype=torch.uint8); B1[:, tb] = 0x3C
+                _, Dx, _ = run(A1, B1, one, one)
+                nz = Dx.nonzero().tolist()
+                if nz:
+                    exps[f"A({la},{ta}) B(:,{tb})"] = dict(rows=sorted({r for r, _ in nz}), ncols=len({c for _, c in nz}), val=Dx.max().item())
+    out["one_hot"] = exps
+    torch.save(dict(A=A, B=B, D=D, raw=raw, ref=ref, D2=D2, ref2=ref2), os.path.join(outdir, "scale_probe_fail.pt"))
+
+# instruction rate: 256 CUs x 4 waves, 4 independent accumulators
+a = A.to(dev); b = B.to(dev); d = torch.zeros(4, device=dev)
+iters, blocks = 4096, 1024
+for _ in range(2):
+    lib.scale_probe_rate(a.data_ptr(), b.data_ptr(), d.data_ptr(), iters, blocks, st())
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); lib.scale_probe_rate(a.data_ptr(), b.data_ptr(), d.data_ptr(), iters, blocks, st()); e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+flops = 2.0 * 32 * 32 * 64 * 4 * iters * blocks * 4
+out["rate_tflops_e5m2_32x32x64"] = flops / (ms * 1e-3) / 1e12
+out["ms"] = ms
+print(json.dumps(out, indent=1))
+json.dump(out, open(os.path.join(outdir, "scale_probe.json"), "w"), indent=1)
