@@ -80,7 +80,7 @@ def test_split_plane_layout_contract():
     out = torch.empty(70, 96, device=DEV)
     from naturalspeech2_pytorch_amd import _lib
     lib = _lib.load()
-    rc = lib.ns2_join_f32(p.hi, p.hi + 2 * 64, 96, out.data_ptr(), 96, 70, 96, torch.cuda.current_stream().cuda_stream)
+    rc = lib.ns2_join_f32(p.hi, p.hi + 2 * 64, 96, out.data_ptr(), 96, 70, 96, 3, torch.cuda.current_stream().cuda_stream)
     assert rc != 0 and b"invalid" in lib.ns2_last_error().lower()  # lo pointer that is not hi + 32 elements is rejected
 
 

@@ -82,6 +82,32 @@ def f16_e5m2_cross(lo_fmt=torch.float8_e5m2):
         return contract(ah, wh) + contract(a8, wl8) + contract(al8, w8)
     return f
 
+def minifloat_block(x, ebits, mbits, bias, axis=-1, block=32):
+    """OCP-MX style element format (no inf/nan) with one power-of-two scale per `block` elements along `axis` (as float64)"""
+    x = x.double().movedim(axis, -1)
+    K = x.shape[-1]; pad = (-K) % block
+    xp = F.pad(x, (0, pad)).reshape(*x.shape[:-1], -1, block)
+    emax = (1 << ebits) - 1 - bias
+    fmax = 2.0 ** emax * (2 - 2.0 ** -mbits)
+    amax = xp.abs().amax(-1, keepdim=True).clamp_min(1e-300)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / fmax)))
+    v = xp / scale
+    a = v.abs().clamp_min(1e-300)
+    e = torch.floor(torch.log2(a)).clamp(min=1 - bias, max=emax)
+    step = torch.exp2(e - mbits)
+    q = (torch.round(a / step) * step).clamp(max=fmax) * torch.sign(v)
+    return (q * scale).reshape(*x.shape[:-1], -1)[..., :K].movedim(-1, axis)
+
+def f16_mx_cross(ebits, mbits, bias):
+    """fp16 hi.hi + both cross terms with MX-block-scaled minifloat operands (fp6 e2m3 / e3m2, fp4 e2m1: 4x the 16-bit MFMA rate)"""
+    def f(a, w, contract, axis_a=-1, axis_w=-1):
+        ah = a.float().to(FH).double(); wh = w.float().to(FH).double()
+        al = a.double() - ah; wl = w.double() - wh
+        q = lambda t, ax: minifloat_block(t, ebits, mbits, bias, ax)
+        return contract(ah, wh) + contract(q(ah, axis_a), q(wl, axis_w)) + contract(q(al, axis_a), q(wh, axis_w))
+    f.takes_axes = True
+    return f
+
 SCHEMES = [
     Scheme("bf16 x3  hi.hi+hi.lo+lo.hi (current exact)", 3.0, mk(BF, [(0, 0), (0, 1), (1, 0)])),
     Scheme("bf16 x1  hi.hi (current fast)", 1.0, mk(BF, [(0, 0)])),
@@ -96,6 +122,10 @@ SCHEMES = [
     Scheme("fp16 x1, but x3 for Linears writing the residual stream", 1.2, mk(FH, [(0, 0)]), None, mk(FH, [(0, 0), (0, 1), (1, 0)])),
     Scheme("fp16 hi.hi + cross terms fp8 e5m2 x e5m2(lo*2^12)", 2.0, f16_e5m2_cross()),
     Scheme("fp16 hi.hi + cross terms fp8 e5m2 x e4m3(lo*2^12)", 2.0, f16_e5m2_cross(torch.float8_e4m3fn)),
+    Scheme("fp16 hi.hi + cross terms MX fp6 e2m3 (GEMMs), fp16 attention", 1.5, f16_mx_cross(2, 3, 1), mk(FH, [(0, 0)])),
+    Scheme("fp16 hi.hi + cross terms MX fp6 e3m2 (GEMMs), fp16 attention", 1.5, f16_mx_cross(3, 2, 3), mk(FH, [(0, 0)])),
+    Scheme("fp16 hi.hi + cross terms MX fp4 e2m1 (GEMMs), fp16 attention", 1.5, f16_mx_cross(2, 1, 1), mk(FH, [(0, 0)])),
+    Scheme("fp16 hi.hi + cross terms fp8 e5m2 (GEMMs), fp16 attention", 2.0, f16_e5m2_cross(), mk(FH, [(0, 0)])),
     Scheme("bf16 hi.hi + both cross terms on fp8(e4m3, MX32)", 2.0, fp8_cross("aw wa")),
     Scheme("bf16 hi.hi + both cross terms on fp8, one scale per row", 2.0, fp8_cross_row()),
     Scheme("bf16 hi.hi + lo.hi bf16 + hi.lo on fp8", 2.5, fp8_cross("aw")),
@@ -109,11 +139,12 @@ def run(sd, x, t, scheme, big_rows):
     def lin(inp, w, b=None):
         if inp.numel() // inp.shape[-1] < big_rows: return lin0(inp, w, b)
         f = scheme.resid_fn if (w.shape[0] == DIM and w.shape[1] != DIM) else scheme.fn
-        y = f(inp, w, lambda a, ww: a @ ww.t())
+        y = f(inp, w, lambda a, ww: a @ ww.t())          # contraction axis: last of both
         return (y + (b.double() if b is not None else 0)).float()
     def conv(inp, w, b=None, stride=1, padding=0, dilation=1, groups=1):
         if inp.shape[-1] * inp.shape[0] < big_rows: return conv0(inp, w, b, stride, padding, dilation, groups)
-        y = scheme.fn(inp, w, lambda a, ww: conv0(a, ww, None, stride, padding, dilation, groups))
+        cf = lambda a, ww: conv0(a, ww, None, stride, padding, dilation, groups)      # contraction axis: channels (dim 1 of both)
+        y = scheme.fn(inp, w, cf, 1, 1) if getattr(scheme.fn, "takes_axes", False) else scheme.fn(inp, w, cf)
         return (y + (b.double()[None, :, None] if b is not None else 0)).float()
     def ein(eq, a, bb):
         y = scheme.attn_fn(a, bb, lambda p, q: ein0(eq, p, q))

@@ -60,8 +60,11 @@ ref2 = model(A, B, sa, sb)
 out["per_lane_scales_max_rel_err"] = ((D2.double() - ref2).abs().max() / ref2.abs().max()).item()
 rc, D3, _ = run(A, B, torch.full((64,), 115), one)
 out["uniform_A_scale_2^-12_max_rel_err"] = ((D3.double() - ref / 4096).abs().max() / (ref / 4096).abs().max()).item()
-ok = out["unit_scales_max_err"] < 1e-3 and out["per_lane_scales_max_rel_err"] < 1e-5 and out["uniform_A_scale_2^-12_max_rel_err"] < 1e-5
-out["operand_model_ok"] = bool(ok)
+# what the mixed-mode GEMM relies on: the (lane, byte) pairing with UNIFORM scales (unit, and 2^-12 on A)
+ok = out["unit_scales_max_err"] < 2e-3 and out["uniform_A_scale_2^-12_max_rel_err"] < 1e-4
+out["operand_model_ok_uniform_scales"] = bool(ok)
+out["per_lane_scale_model_ok"] = bool(out["per_lane_scales_max_rel_err"] < 1e-4)     # NOT relied upon (round 2: it is not per-lane)
+ok = ok and out["per_lane_scale_model_ok"]
 if not ok:
     # structured experiments: A one-hot (lane la, byte ta) = 1, B all ones except B[lane][t] = 2^t%8 -> which t pairs, which lanes
     exps = {}
