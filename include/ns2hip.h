@@ -129,6 +129,29 @@ int ns2_ddim_step(const float* audio, const float* model_out, float* out, const 
 /* classifier-free guidance mix (NS2:927) */
 int ns2_cfg_mix(const float* cond_out, const float* null_out, float* out, int64_t n, float cond_scale, void* stream);
 
+/* ------------------------------------------------------------------ EnCodec SEANet encoder / decoder pieces (HFENC:81-347)
+ * The convolutions themselves are ns2_linear_* calls on channel-last rows (strided / transposed convolutions as 2-tap
+ * convolutions over rows regrouped by the stride); these are the pieces around them.
+ * ns2_seanet_prep: fp32 x [B, in_prefix + T, C] (row stride ldx, the first in_prefix rows of every utterance skipped;
+ *   + optional add [B, T, C]) -> optional ELU (HFENC:285-347) -> operand
+ *   planes [B, prefix + T, ldo] whose `prefix` leading rows per utterance hold the mirrored samples (row -j = row j): EnCodec's
+ *   reflect padding of causal convolutions (HFENC:142-175).  im2col_k > 0 (C must be 1, prefix 0): output column j of row n is
+ *   x_reflect[n - (k - 1) + j], the k taps of the first convolution as a K = k Linear.
+ * ns2_seanet_unpad: dst[b][t][:] = src[b][prefix + t][:]  (drop the prefix rows of a convolution output)
+ * ns2_lstm_layer: one nn.LSTM layer (HFENC:253-266; gate order i, f, g, o).  xproj [B*T, 4H] = x W_ih^T + b_ih (a GEMM, row
+ *   b*T + t), w_hh [4H, H], b_hh [4H]; state = 3*B*H floats of caller scratch; out[b*T + t, :H] = h_t (+ resid row). */
+int ns2_seanet_prep(const float* x, int ldx, int in_prefix, const float* add, int ldadd, int B, int64_t T, int C, int elu, int prefix,
+                    int im2col_k, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream);
+int ns2_seanet_unpad(const float* src, int64_t ld_src, int prefix, float* dst, int64_t ld_dst, int B, int64_t T, int C, void* stream);
+int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_hh, const float* b_hh, float* state, const float* resid,
+                   int64_t ld_r, float* out, int64_t ld_o, int B, int64_t T, int H, void* stream);
+
+/* Range guard of precisions 2 and 4 (IEEE-half operands stop at 65504 / 57344; beyond, values are clamped: finite but
+ * wrong).  Counts, on the CURRENT device, the conversions that met an out-of-range (or NaN) value since the last reset.
+ * Synchronises the device: call it between sampling runs, not per step.  A non-zero count means the model needs
+ * precision 3 (bf16 planes: fp32 exponent range). */
+int ns2_saturation_count(int reset, int64_t* count);
+
 /* EnCodec RVQ (HFENC:364-369, 424-447; reference call sites NS2:1445, NS2:1611, NS2:1496).
  * cb_norm: [Q, C] scratch filled by ns2_rvq_prepare (once per codebook set). codes: [M, Q] int64; emb/residual [M, D] or null */
 int ns2_rvq_prepare(const float* codebooks, float* cb_norm, int Q, int C, int D, void* stream);

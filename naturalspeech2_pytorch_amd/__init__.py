@@ -6,5 +6,6 @@ from .diffusion import NaturalSpeech2                      # noqa: F401
 from .codec import EncodecWrapperHIP, HipRVQ               # noqa: F401
 from .transformer import Transformer                        # noqa: F401
 from .encoders import PhonemeEncoder, SpeechPromptEncoder   # noqa: F401
+from .seanet import SEANetDecoderHIP, SEANetEncoderHIP      # noqa: F401
 
-__all__ = ["Model", "NaturalSpeech2", "Transformer", "PhonemeEncoder", "SpeechPromptEncoder", "EncodecWrapperHIP", "HipRVQ", "Ns2Error", "load_library"]
+__all__ = ["Model", "NaturalSpeech2", "Transformer", "PhonemeEncoder", "SpeechPromptEncoder", "EncodecWrapperHIP", "HipRVQ", "SEANetEncoderHIP", "SEANetDecoderHIP", "Ns2Error", "load_library"]

@@ -7,8 +7,9 @@ Surface kept for `NaturalSpeech2` (reference call sites in brackets):
     codec.decode(emb [b,n,128]) -> waveform [b,1,T]                                                        [NS2:1496-1499]
     codec.rq(x_start, codes) -> (quantized, ce_loss)                                                       [NS2:1682]
 
-The SEANet conv/LSTM encoder and decoder of EnCodec are injected as callables (`encoder`, `decoder`); `from_hf` wires the
-ones of a HF `transformers.EncodecModel` (the in-container stand-in for the un-vendored `encodec` package) and
+The SEANet conv/LSTM encoder and decoder of EnCodec are callables (`encoder`, `decoder`): `from_hf` takes them from a HF
+`transformers.EncodecModel` (the in-container stand-in for the un-vendored `encodec` package), by default wrapped
+in `seanet.SEANetEncoderHIP / SEANetDecoderHIP` so that waveform <-> latents also runs on the HIP kernels, and
 copies its codebooks.  With `encoder=None` the wrapper accepts latents [b, n, 128] directly.
 """
 from typing import Callable, Optional
@@ -90,12 +91,17 @@ class EncodecWrapperHIP(nn.Module):
         self.encoder, self.decoder = encoder, decoder
 
     @classmethod
-    def from_hf(cls, hf_model, num_quantizers: int = 8):
+    def from_hf(cls, hf_model, num_quantizers: int = 8, hip_seanet: bool = True, precision: str = "exact"):
         """wire a `transformers.EncodecModel`'s SEANet encoder / decoder and its first `num_quantizers` codebooks (6 kbps at
-        24 kHz = 8, what audiolm's EncodecWrapper uses)"""
+        24 kHz = 8, what audiolm's EncodecWrapper uses).  hip_seanet=True (default): the SEANet stacks run on the HIP kernels
+        (seanet.py) with the model's own (weight-normalised) parameters; False: HF's PyTorch modules are called as they are."""
         layers = list(hf_model.quantizer.layers)[:num_quantizers]
         cbs = torch.stack([l.codebook.embed.detach().float() for l in layers])
-        return cls(cbs, encoder=hf_model.encoder, decoder=hf_model.decoder)
+        enc, dec = hf_model.encoder, hf_model.decoder
+        if hip_seanet:
+            from .seanet import SEANetDecoderHIP, SEANetEncoderHIP
+            enc, dec = SEANetEncoderHIP(enc, precision=precision), SEANetDecoderHIP(dec, precision=precision)
+        return cls(cbs, encoder=enc, decoder=dec)
 
     @property
     def num_quantizers(self):

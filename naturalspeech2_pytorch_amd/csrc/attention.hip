@@ -285,4 +285,6 @@ hipError_t launch_attention(const AttnArgs& a_in, int nsplit, hipStream_t s) {
   return launch_attn_t<1, false>(a, s);
 }
 
+NS2_DEFINE_SATURATION_READER(attention)
+
 }  // namespace ns2

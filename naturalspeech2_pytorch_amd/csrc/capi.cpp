@@ -217,6 +217,45 @@ extern "C" int ns2_cfg_mix(const float* cond_out, const float* null_out, float* 
   return NS2_OK;
 }
 
+extern "C" int ns2_seanet_prep(const float* x, int ldx, int in_prefix, const float* add, int ldadd, int B, int64_t T, int C, int elu,
+                               int prefix, int im2col_k, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream) {
+  ARGCHK(x && out_hi && prec_ok(precision), "ns2_seanet_prep: bad arguments");
+  HIPRET(launch_seanet_prep(x, ldx, in_prefix, add, ldadd, B, (long)T, C, elu, prefix, im2col_k, out_hi, out_lo, ldo,
+                            op_fmt(precision), (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_seanet_unpad(const float* src, int64_t ld_src, int prefix, float* dst, int64_t ld_dst, int B, int64_t T, int C,
+                                void* stream) {
+  ARGCHK(src && dst && B > 0 && T > 0 && C > 0 && prefix >= 0, "ns2_seanet_unpad: bad arguments");
+  HIPRET(launch_seanet_unpad(src, (long)ld_src, prefix, dst, (long)ld_dst, B, (long)T, C, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_hh, const float* b_hh, float* state, const float* resid,
+                              int64_t ld_r, float* out, int64_t ld_o, int B, int64_t T, int H, void* stream) {
+  ARGCHK(xproj && w_hh && b_hh && state && out, "ns2_lstm_layer: null pointer");
+  ARGCHK(B > 0 && T > 0 && H > 0 && H <= 512 && (H % 4) == 0, "ns2_lstm_layer: hidden size must be a multiple of 4, at most 512");
+  float* h_a = state;                                  // caller-owned scratch: 3 * B * H floats (h ping, h pong, c)
+  float* h_b = state + (size_t)B * H;
+  float* c = state + 2 * (size_t)B * H;
+  HIPRET(launch_lstm_layer(xproj, (long)ld_x, w_hh, b_hh, h_a, h_b, c, resid, (long)ld_r, out, (long)ld_o, B, (long)T, H,
+                           (hipStream_t)stream));
+  return NS2_OK;
+}
+
+extern "C" int ns2_saturation_count(int reset, int64_t* count) {
+  ARGCHK(count != nullptr, "ns2_saturation_count: null pointer");
+  HIPRET(hipDeviceSynchronize());                    // a diagnostic read between sampling runs, never on a launch path
+  const unsigned int parts[4] = {saturation_read_gemm(reset != 0), saturation_read_gemm2(reset != 0),
+                                 saturation_read_attention(reset != 0), saturation_read_elementwise(reset != 0)};
+  int64_t tot = 0;
+  for (unsigned int p : parts) {
+    ARGCHK(p != ~0u, "ns2_saturation_count: could not read the device counter");
+    tot += p;
+  }
+  *count = tot;
+  return NS2_OK;
+}
+
 extern "C" int ns2_rvq_prepare(const float* codebooks, float* cb_norm, int Q, int C, int D, void* stream) {
   ARGCHK(codebooks && cb_norm, "ns2_rvq_prepare: null pointer");
   HIPRET(launch_rvq_prepare(codebooks, cb_norm, Q, C, D, (hipStream_t)stream));

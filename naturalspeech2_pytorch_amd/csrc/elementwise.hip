@@ -158,20 +158,26 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* in, int
       s_in[b][k] = v;
     }
     __syncthreads();
-#pragma unroll 1
-    for (int k = 0; k < SK_KC; k += 8) {
-      float w[8][4];
+    // 8 weight rows (8 KiB per wave) are fetched one batch AHEAD of the 1024 FMAs that consume them, so loads are in flight
+    // all the time (the single-buffered loop measured 2 TB/s: every wave alternated between waiting and computing)
+    float w[8][4], wn[8][4];
+    auto load_rows = [&](float (&dst)[8][4], int k) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const long kr = k0 + k + e;
         if (kr < kend && jvec) {
           const float4 t = *reinterpret_cast<const float4*>(wt + kr * J + j);
-          w[e][0] = t.x; w[e][1] = t.y; w[e][2] = t.z; w[e][3] = t.w;
+          dst[e][0] = t.x; dst[e][1] = t.y; dst[e][2] = t.z; dst[e][3] = t.w;
         } else {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) w[e][c] = (kr < kend && j + c < J) ? wt[kr * J + j + c] : 0.f;
+          for (int c = 0; c < 4; ++c) dst[e][c] = (kr < kend && j + c < J) ? wt[kr * J + j + c] : 0.f;
         }
       }
+    };
+    load_rows(w, 0);
+#pragma unroll 1
+    for (int k = 0; k < SK_KC; k += 8) {
+      if (k + 8 < SK_KC) load_rows(wn, k + 8);
 #pragma unroll
       for (int b = 0; b < 32; ++b) {
         const float4 t = *reinterpret_cast<const float4*>(&s_in[b][k]);       // wave-uniform address: LDS broadcast
@@ -182,6 +188,10 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* in, int
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[b][c] = fmaf(x[e], w[e][c], acc[b][c]);
       }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[e][c] = wn[e][c];
     }
   }
   if (j >= J) return;
@@ -478,5 +488,145 @@ hipError_t launch_pack_weight(const float* src, int C, int T, int Cp, const int*
                      rows_p, dst_hi, dst_lo, ldk, k_off, fmt);
   return hipGetLastError();
 }
+
+// ================================================================ EnCodec SEANet helpers (HFENC:81-347)
+// The SEANet convolutions run on the GEMM family (channel-last rows, shifted-row taps).  What they need around the GEMM:
+//   * the activation in front of every convolution (ELU, HFENC:285-347 nn.ELU()) and the conversion to operand planes;
+//   * EnCodec pads with REFLECTION (pad_mode = "reflect", causal: everything on the left, HFENC:142-175) where the GEMM's
+//     conv loader zero-fills: every utterance gets `prefix` extra rows in front, filled with the mirrored first samples
+//     (row -j = row j), so the causal taps of the rows >= prefix never reach the zero fill; the GEMM's outputs for the prefix
+//     rows are garbage and are never read;
+//   * the first convolution has one input channel: its 7 taps are gathered into 7 columns here (im2col), so that it is a
+//     Linear with K = 7 instead of 7 taps of a 32-column-padded single channel.
+// x: fp32 [B, in_prefix + T, ldx] (channel-last; the first in_prefix rows of every utterance are skipped: x may be the output of
+// a convolution over prefixed rows), out planes [B, prefix + T, ldo]; add: optional fp32 [B, T, lda] added before the ELU.
+NS2_DEVINL float eluf(float x) { return x > 0.f ? x : expm1f(x); }
+
+__global__ __launch_bounds__(256) void seanet_prep_kernel(const float* x, int ldx, int in_prefix, const float* add, int ldadd, int B,
+                                                          long T, int C, int elu, int prefix, int im2col_k, bf16_t* out_hi,
+                                                          bf16_t* out_lo, int ldo, int fmt) {
+  const int chunks = ldo >> 2;
+  const long rows = (long)B * (prefix + T);
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * chunks) return;
+  const long orow = idx / chunks;
+  const int c = (int)(idx - orow * chunks) * 4;
+  const long b = orow / (prefix + T);
+  const long p = orow - b * (prefix + T);                 // position inside the padded utterance
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  const long xrow0 = b * (in_prefix + T) + in_prefix;      // the input may itself be a convolution output with garbage prefix rows
+  if (im2col_k > 0) {
+    // column j of output row n = x_reflect[n - (k - 1) + j]   (single input channel, causal left padding k - 1)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = c + e;
+      if (j < im2col_k) {
+        long t = p - (im2col_k - 1) + j;
+        if (t < 0) t = -t;                                // reflection: x[-t] = x[t]
+        float v = x[(xrow0 + t) * ldx];
+        o[e] = elu ? eluf(v) : v;
+      }
+    }
+  } else {
+    const long t = p >= prefix ? p - prefix : prefix - p;  // prefix row p mirrors row (prefix - p)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < C) {
+        float v = x[(xrow0 + t) * ldx + c + e];
+        if (add) v += add[(b * T + t) * ldadd + c + e];
+        o[e] = elu ? eluf(v) : v;
+      }
+  }
+  const bool il = out_lo != nullptr;
+  store_cols4(out_hi + orow * pld(ldo, il), c, o[0], o[1], o[2], o[3], fmt, il);
+}
+hipError_t launch_seanet_prep(const float* x, int ldx, int in_prefix, const float* add, int ldadd, int B, long T, int C, int elu,
+                              int prefix, int im2col_k, bf16_t* out_hi, bf16_t* out_lo, int ldo, int fmt, hipStream_t s) {
+  if (B <= 0 || T <= 0 || C <= 0 || (ldo & 3) || prefix < 0 || prefix >= T || in_prefix < 0) return hipErrorInvalidValue;
+  if (im2col_k > 0 ? (ldo < im2col_k || prefix != 0 || add) : ldo < C) return hipErrorInvalidValue;
+  if (!planes_ok(out_hi, out_lo) || (out_lo && (ldo & 31)) || (fmt == FMT_F16 && out_lo) || (fmt == FMT_H8 && !out_lo))
+    return hipErrorInvalidValue;
+  const long total = (long)B * (prefix + T) * (ldo >> 2);
+  hipLaunchKernelGGL(seanet_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, in_prefix, add, ldadd, B, T, C,
+                     elu, prefix, im2col_k, out_hi, out_lo, ldo, fmt);
+  return hipGetLastError();
+}
+
+// dst[b][t][c] = src[b][prefix + t][c]  (drop the prefix rows of a GEMM output), optionally + add
+__global__ void seanet_unpad_kernel(const float* src, long ld_src, int prefix, float* dst, long ld_dst, int B, long T, int C) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * T * C) return;
+  const int c = (int)(i % C);
+  const long r = i / C;
+  const long b = r / T, t = r - b * T;
+  dst[r * ld_dst + c] = src[(b * (prefix + T) + prefix + t) * ld_src + c];
+}
+hipError_t launch_seanet_unpad(const float* src, long ld_src, int prefix, float* dst, long ld_dst, int B, long T, int C, hipStream_t s) {
+  const long n = (long)B * T * C;
+  hipLaunchKernelGGL(seanet_unpad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld_src, prefix, dst, ld_dst, B, T, C);
+  return hipGetLastError();
+}
+
+// ---- LSTM (HFENC:253-266: nn.LSTM(dim, dim, num_layers), PyTorch gate order i, f, g, o).  The input projections of all time
+// steps are one GEMM; this kernel is ONE recurrent step of one layer:  gates = xproj[b, t] + h_prev[b] . W_hh^T + b_hh ;
+// c = sigma(f) c + sigma(i) tanh(g) ; h = sigma(o) tanh(c).  A workgroup owns 16 hidden units x 16 batch rows;
+// W_hh rows and h_prev come from L2 (the step is latency-bound: 2 x T dependent launches per utterance batch).
+constexpr int LSTM_UNITS = 16;                    // hidden units per workgroup
+constexpr int LSTM_ROWS = 16;                     // batch rows per workgroup
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float* xproj, long ld_x, long row_stride_t, long t, const float* w_hh,
+                                                        const float* b_hh, const float* h_prev, float* h_next, float* c_state,
+                                                        const float* resid, long ld_r, float* out, long ld_o, int B, int H) {
+  __shared__ __attribute__((aligned(16))) float s_h[LSTM_ROWS][512 + 4];       // +16 B per row: conflict-free 16-B reads down a column
+  const int b0 = blockIdx.y * LSTM_ROWS;
+  const int nb = min(LSTM_ROWS, B - b0);
+  for (int i = threadIdx.x; i < LSTM_ROWS * H; i += 256) {
+    const int b = i / H, k = i - b * H;
+    s_h[b][k] = b < nb ? h_prev[(long)(b0 + b) * H + k] : 0.f;
+  }
+  __syncthreads();
+  // thread -> (batch row b = tid & 15, unit u = tid >> 4): 4 gate dot products of length H, accumulated as 4 independent chains
+  const int b = threadIdx.x & 15, u = threadIdx.x >> 4;
+  const int j = blockIdx.x * LSTM_UNITS + u;
+  if (j >= H || b >= nb) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < H; k += 4) {
+    const float4 hv = *reinterpret_cast<const float4*>(&s_h[b][k]);
+#pragma unroll
+    for (int gate = 0; gate < 4; ++gate) {
+      const float4 wv = *reinterpret_cast<const float4*>(w_hh + ((long)gate * H + j) * H + k);   // shared by the 16 rows of a unit
+      acc[gate] = fmaf(wv.x, hv.x, acc[gate]); acc[gate] = fmaf(wv.y, hv.y, acc[gate]);
+      acc[gate] = fmaf(wv.z, hv.z, acc[gate]); acc[gate] = fmaf(wv.w, hv.w, acc[gate]);
+    }
+  }
+  const long row = (long)(b0 + b) * row_stride_t + t;
+  float g4[4];
+#pragma unroll
+  for (int gate = 0; gate < 4; ++gate) g4[gate] = acc[gate] + xproj[row * ld_x + (long)gate * H + j] + b_hh[gate * H + j];
+  const long sidx = (long)(b0 + b) * H + j;
+  const float ig = sigmoidf_acc(g4[0]), fg = sigmoidf_acc(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_acc(g4[3]);
+  const float c = fg * c_state[sidx] + ig * gg;
+  const float h = og * tanhf(c);
+  c_state[sidx] = c;
+  h_next[sidx] = h;
+  out[row * ld_o + j] = h + (resid ? resid[row * ld_r + j] : 0.f);
+}
+hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, const float* b_hh, float* h_a, float* h_b,
+                             float* c_state, const float* resid, long ld_r, float* out, long ld_o, int B, long T, int H,
+                             hipStream_t s) {
+  if (B <= 0 || T <= 0 || H <= 0 || H > 512 || (H & 3)) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(h_a, 0, (size_t)B * H * sizeof(float), s);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(c_state, 0, (size_t)B * H * sizeof(float), s);
+  if (e != hipSuccess) return e;
+  const dim3 grid((H + LSTM_UNITS - 1) / LSTM_UNITS, (B + LSTM_ROWS - 1) / LSTM_ROWS);
+  for (long t = 0; t < T; ++t) {
+    float* hp = (t & 1) ? h_b : h_a;
+    float* hn = (t & 1) ? h_a : h_b;
+    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, s, xproj, ld_x, T, t, w_hh, b_hh, hp, hn, c_state, resid, ld_r, out, ld_o, B, H);
+  }
+  return hipGetLastError();
+}
+
+NS2_DEFINE_SATURATION_READER(elementwise)
 
 }  // namespace ns2

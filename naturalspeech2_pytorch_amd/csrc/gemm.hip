@@ -243,4 +243,6 @@ hipError_t launch_gemm1(const GemmArgs& g, int precision, hipStream_t s) {      
   }
 }
 
+NS2_DEFINE_SATURATION_READER(gemm)
+
 }  // namespace ns2

@@ -376,4 +376,6 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
   }
 }
 
+NS2_DEFINE_SATURATION_READER(gemm2)
+
 }  // namespace ns2

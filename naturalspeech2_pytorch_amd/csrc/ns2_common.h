@@ -64,12 +64,30 @@ NS2_DEVINL void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
   lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));
 }
 
+// ---- Range guard of the IEEE-half based precisions.  Half (and e5m2) stop at 65504 (57344): a value beyond is clamped, which
+// keeps everything finite but is WRONG, silently (measured: weights x8 on a random-init d128/L6 model -> relative error 1.0
+// at precisions 2 and 4, 1e-5 at precision 3 whose bf16 planes have the fp32 exponent range).  Every conversion that clamps
+// (or meets a NaN) bumps a per-device counter; the host reads it after a sampling run (ns2_saturation_count) and fails
+// loudly.  One static counter per translation unit (no relocatable device code); capi.cpp sums them.
+static __device__ unsigned int ns2_sat_counter;
+NS2_DEVINL void note_out_of_range(float a, float b, float limit) {
+  if (!(fabsf(a) <= limit) || !(fabsf(b) <= limit)) atomicAdd(&ns2_sat_counter, 1u);
+}
+#define NS2_DEFINE_SATURATION_READER(tu)                                                              \
+  unsigned int saturation_read_##tu(bool reset) {                                                     \
+    unsigned int v = 0;                                                                               \
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(ns2_sat_counter), sizeof v) != hipSuccess) return ~0u;     \
+    if (reset && v) { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(ns2_sat_counter), &z, sizeof z); } \
+    return v;                                                                                         \
+  }
+
 // ---- IEEE half operands ("half" precision: ONE fp16 product per contraction, fp32 accumulate).  fp16 carries 11
 // significand bits against bf16's 8, so a single product lands at ~5e-4 end to end where bf16 needs the 3-product split
 // (tools/precision_study.py); the price is range: values are clamped to +-65504 on conversion instead of becoming inf.
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 NS2_DEVINL uint32_t cvt2h(float a, float b) {         // {half(a) | half(b) << 16}, round to nearest even, saturating
+  note_out_of_range(a, b, 65504.f);
   f32x2_t v = {fminf(fmaxf(a, -65504.f), 65504.f), fminf(fmaxf(b, -65504.f), 65504.f)};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
 }
@@ -96,6 +114,7 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 // (a, b) -> packed halves, packed e5m2(a, b) and packed e5m2 of the scaled remainders (each in the low 16 bits)
 NS2_DEVINL void cvt2_h8(float a, float b, uint32_t& h16, uint32_t& h8, uint32_t& l8) {
+  note_out_of_range(a, b, H8_MAX);
   a = fminf(fmaxf(a, -H8_MAX), H8_MAX);
   b = fminf(fmaxf(b, -H8_MAX), H8_MAX);
   f32x2_t v = {a, b};

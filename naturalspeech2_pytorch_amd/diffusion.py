@@ -137,6 +137,22 @@ class NaturalSpeech2(nn.Module):
             self.model.refresh_weights()        # parameters rewritten through `.data` since the last pack (EMA) -> re-pack
         if hasattr(self.model, "clear_cond_cache"):
             self.model.clear_cond_cache()
+        guard = getattr(self.model, "precision", "exact") in ("half", "mixed") and audio.is_cuda
+        if guard:
+            ops.saturation_count(reset=True, device=device)
+        audio = self._ddim_loop(audio, prompt, cond, cond_scale, use_graph)
+        if guard:
+            n = ops.saturation_count(reset=True, device=device)
+            if n:
+                from ._lib import Ns2Error
+                raise Ns2Error(
+                    f"{n} activation values left the IEEE-half range (|x| > 65504) during sampling at precision="
+                    f"'{self.model.precision}': the result is clamped and wrong.  Use precision='exact' (bf16 planes keep the "
+                    f"fp32 exponent range) for this checkpoint.")
+        return audio
+
+    def _ddim_loop(self, audio, prompt, cond, cond_scale, use_graph):
+        batch, device = audio.shape[0], audio.device
         pairs = self.get_sampling_timesteps(batch, device=device)
         # `time_difference` only shifts times_next AFTER gamma_next was taken (NS2:1396-1406): it has no effect upstream either
         if not self._fused_ddim_ok():

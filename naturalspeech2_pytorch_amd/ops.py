@@ -278,6 +278,16 @@ def time_embed(times: torch.Tensor, freqs: torch.Tensor, wt: torch.Tensor, bias:
     return out
 
 
+def saturation_count(reset: bool = True, device=None) -> int:
+    """conversions to IEEE half (precisions "half" / "mixed") that met a value outside the half range since the last reset, on
+    `device` (default: the current one).  Synchronises; see include/ns2hip.h."""
+    import ctypes
+    n = ctypes.c_int64(0)
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        check(_lib.load().ns2_saturation_count(int(reset), ctypes.byref(n)), "ns2_saturation_count")
+    return n.value
+
+
 OBJECTIVES = {"v": 0, "eps": 1, "x0": 2}
 SCHEDULES = {"sigmoid": 0, "cosine": 1, "linear": 2}
 

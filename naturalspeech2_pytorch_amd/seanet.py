@@ -1,0 +1,239 @@
+"""EnCodec's SEANet encoder / decoder on the HIP kernels (HFENC:81-347 = transformers `modeling_encodec.py`, the
+in-container restatement of the un-vendored `encodec` package that audiolm_pytorch's `EncodecWrapper` runs at NS2:1445,
+NS2:1496 and NS2:1611).
+
+MI355X-first layout: channel-last rows [B * T, C] throughout (the reference is channel-first), so that every convolution is
+a call of the denoiser's own MFMA GEMM family:
+  * stride-1 causal convolutions (HFENC:81-181) = shifted-row GEMMs; EnCodec's REFLECT padding is a per-utterance prefix of
+    mirrored rows written by `ns2_seanet_prep` (which also applies the ELU in front of the convolution and converts to operand
+    planes), so the GEMM's zero fill is never reached;
+  * the down-sampling convolutions (kernel 2r, stride r) = 2-tap convolutions over rows REGROUPED r at a time (a free view of
+    the same buffer: [T, C] -> [T / r, r C]);
+  * the up-sampling transposed convolutions (HFENC:184-244) = 2-tap convolutions producing r output frames per input row
+    ([T, r C_out] -> [T r, C_out], again a free view); their causal trimming drops exactly the rows that are never computed;
+  * the 2-layer LSTM (HFENC:253-266): input projections of all frames = one GEMM, the recurrence = one small kernel per step;
+  * ResnetBlock (HFENC:269-301): three GEMMs, the residual sum is the last one's `resid` operand.
+
+The module wraps an existing SEANet (`transformers.EncodecModel().encoder / .decoder`, or any module with the same layer
+structure) and reads its EFFECTIVE weights (weight-norm applied: `conv.weight`); it re-packs when their content changes.
+Inference only (like the codec in the reference: `codec.eval()` + `torch.no_grad()`, NS2:1443-1445, 1608-1611).
+"""
+import torch
+from torch import nn
+
+from . import _lib, ops
+from ._cache import PackedCache
+from ._lib import check
+from .model import _PRECISIONS
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _prep(x, B, T, C, *, in_prefix=0, elu=False, prefix=0, im2col_k=0, add=None, precision=3, ldo=None):
+    """fp32 rows [B, in_prefix + T, C] -> operand planes [B * (prefix + T), ldo] (ELU, reflect prefix, im2col of 1 channel)"""
+    ldo = ldo or ops.round_up(max(C, im2col_k), 32)
+    out = ops._out_planes(B * (prefix + T), ldo, x.device, precision)
+    check(_lib.load().ns2_seanet_prep(x.data_ptr(), x.shape[-1], in_prefix, ops._p(add), add.shape[-1] if add is not None else 0, B, T,
+                                      C, int(elu), prefix, im2col_k, out.hi, out.lo, ldo, precision, _stream()), "ns2_seanet_prep")
+    return out
+
+
+def _unpad(x, B, T, C, prefix):
+    out = torch.empty(B * T, C, dtype=torch.float32, device=x.device)
+    check(_lib.load().ns2_seanet_unpad(x.data_ptr(), x.shape[-1], prefix, out.data_ptr(), C, B, T, C, _stream()), "ns2_seanet_unpad")
+    return out
+
+
+class _Act:
+    """fp32 activation rows [B * (prefix + T), C]: the first `prefix` rows of every utterance are not data"""
+    __slots__ = ("x", "B", "T", "C", "prefix")
+
+    def __init__(self, x, B, T, C, prefix=0):
+        self.x, self.B, self.T, self.C, self.prefix = x, B, T, C, prefix
+
+    def clean(self):
+        if self.prefix == 0:
+            return self
+        return _Act(_unpad(self.x, self.B, self.T, self.C, self.prefix), self.B, self.T, self.C, 0)
+
+
+class _SEANetHIP(nn.Module):
+    def __init__(self, net: nn.Module, precision="exact"):
+        super().__init__()
+        assert precision in _PRECISIONS
+        self.net = net                       # owns the parameters (weight-norm parametrised convs, LSTM)
+        self.precision = precision
+        self._cache = PackedCache()
+
+    # ---- weights
+    @staticmethod
+    def _w(conv_module):
+        c = conv_module.conv
+        return c.weight.detach().float().contiguous(), (c.bias.detach().float().contiguous() if c.bias is not None else None)
+
+    def _packed(self):
+        return self._cache.get(self.net.parameters(), self._build, extra=(self.precision,))
+
+    def _pack_conv(self, m):
+        """EncodecConv1d (HFENC:81-181) -> (PackedWeight, bias, taps, dilation, stride, row prefix)"""
+        prec = _PRECISIONS[self.precision]
+        w, b = self._w(m)
+        co, ci, k = w.shape
+        stride, dil = m.conv.stride[0], m.conv.dilation[0]
+        assert getattr(m, "causal", True) and getattr(m, "pad_mode", "reflect") == "reflect" and m.norm_type == "weight_norm", \
+            "the HIP SEANet implements EnCodec's 24 kHz configuration: causal convolutions, reflect padding, weight norm"
+        if stride == 1:
+            if ci == 1:                                         # first encoder conv: k taps of one channel as a K = k Linear
+                return dict(w=ops.PackedWeight(w.reshape(co, k).contiguous(), precision=prec), b=b, kind="im2col", k=k, co=co)
+            return dict(w=ops.PackedWeight(w, precision=prec), b=b, kind="conv", k=k, dil=dil, co=co, ci=ci, prefix=(k - 1) * dil)
+        assert k == 2 * stride and dil == 1
+        # rows regrouped `stride` at a time: W'[co][a][i * ci + c] = W[co][c][a * stride + i]
+        w2 = w.reshape(co, ci, 2, stride).permute(0, 2, 3, 1).reshape(co, 2, stride * ci).permute(0, 2, 1).contiguous()
+        return dict(w=ops.PackedWeight(w2, precision=prec), b=b, kind="down", r=stride, co=co, ci=ci)
+
+    def _pack_convtr(self, m):
+        """EncodecConvTranspose1d (HFENC:184-244), kernel 2r, stride r, causal trim: Out'[n][i * co + c] =
+        sum_ci x[n][ci] W[ci][c][i] + x[n - 1][ci] W[ci][c][i + r]  ->  a 2-tap causal convolution with r * co outputs"""
+        prec = _PRECISIONS[self.precision]
+        c = m.conv
+        w = c.weight.detach().float()                           # [ci, co, k]
+        ci, co, k = w.shape
+        r = c.stride[0]
+        assert k == 2 * r and m.causal and m.trim_right_ratio == 1.0
+        w = w.reshape(ci, co, 2, r)                             # [ci][co][a][i], tap index j = a * r + i
+        cur = w[:, :, 0, :].permute(2, 1, 0).reshape(r * co, ci)    # row i * co + c: current frame n
+        prev = w[:, :, 1, :].permute(2, 1, 0).reshape(r * co, ci)   # previous frame n - 1
+        w2 = torch.stack((prev, cur), dim=-1).contiguous()      # taps: 0 = shifted by one row, 1 = unshifted
+        b = c.bias.detach().float().repeat(r).contiguous() if c.bias is not None else None
+        return dict(w=ops.PackedWeight(w2, precision=prec), b=b, kind="up", r=r, co=co, ci=ci)
+
+    def _pack_resblock(self, m):
+        convs = [l for l in m.block if not isinstance(l, nn.ELU)]
+        assert len(convs) == 2 and not isinstance(m.shortcut, nn.Identity), "EnCodec 24 kHz: two convolutions + conv shortcut"
+        return dict(kind="res", c1=self._pack_conv(convs[0]), c2=self._pack_conv(convs[1]), sc=self._pack_conv(m.shortcut))
+
+    def _pack_lstm(self, m):
+        prec = _PRECISIONS[self.precision]
+        lstm = m.lstm
+        layers = []
+        for l in range(lstm.num_layers):
+            g = lambda n: getattr(lstm, f"{n}_l{l}").detach().float().contiguous()     # noqa: E731
+            layers.append(dict(w_ih=ops.PackedWeight(g("weight_ih"), precision=prec), b_ih=g("bias_ih"), w_hh=g("weight_hh"),
+                               b_hh=g("bias_hh")))
+        return dict(kind="lstm", layers=layers, H=lstm.hidden_size)
+
+    def _build(self):
+        seq = []
+        pending_elu = False
+        for layer in self.net.layers:
+            name = type(layer).__name__
+            if isinstance(layer, nn.ELU):
+                pending_elu = True
+                continue
+            if name.endswith("ResnetBlock"):
+                item = self._pack_resblock(layer)
+            elif name.endswith("LSTM"):
+                item = self._pack_lstm(layer)
+            elif name.endswith("ConvTranspose1d"):
+                item = self._pack_convtr(layer)
+            elif name.endswith("Conv1d"):
+                item = self._pack_conv(layer)
+            else:
+                raise NotImplementedError(f"SEANet layer {name}")
+            item["elu"] = pending_elu                            # the activation in front of this layer
+            pending_elu = False
+            seq.append(item)
+        return seq
+
+    # ---- layers
+    def _conv(self, a: _Act, p, elu, resid=None):
+        prec = _PRECISIONS[self.precision]
+        B, T = a.B, a.T
+        if p["kind"] == "im2col":
+            pl = _prep(a.x, B, T, 1, in_prefix=a.prefix, elu=elu, im2col_k=p["k"], precision=prec)
+            y = ops.linear_f32(p["w"], pl, bias=p["b"], precision=prec)
+            return _Act(y, B, T, p["co"], 0)
+        if p["kind"] == "conv":
+            P = p["prefix"]
+            pl = _prep(a.x, B, T, a.C, in_prefix=a.prefix, elu=elu, prefix=P, precision=prec)
+            if p["k"] == 1:
+                y = ops.linear_f32(p["w"], pl, bias=p["b"], resid=resid, precision=prec)
+            else:
+                assert resid is None
+                y = ops.linear_f32(p["w"], pl, bias=p["b"], conv_taps=p["k"], dilation=p["dil"], seq_len=P + T, precision=prec)
+            return _Act(y, B, T, p["co"], P)
+        if p["kind"] == "down":
+            r = p["r"]
+            assert T % r == 0, "the frame count must be a multiple of every stride (codec(x) truncates to multiples of 320)"
+            pl = _prep(a.x, B, T, a.C, in_prefix=a.prefix, elu=elu, prefix=r, precision=prec)         # one regrouped row of reflection
+            rows = B * (r + T) // r
+            pl2 = ops.Planes(pl.buf.reshape(rows, -1), rows, r * a.C, pl.has_lo, pl.fmt)            # [T, C] -> [T / r, r C]: a view
+            y = ops.linear_f32(p["w"], pl2, bias=p["b"], conv_taps=2, dilation=1, seq_len=1 + T // r, precision=prec)
+            return _Act(y, B, T // r, p["co"], 1)
+        if p["kind"] == "up":
+            r = p["r"]
+            pl = _prep(a.x, B, T, a.C, in_prefix=a.prefix, elu=elu, precision=prec)
+            y = ops.linear_f32(p["w"], pl, bias=p["b"], conv_taps=2, dilation=1, seq_len=T, precision=prec)   # [B T, r co]
+            return _Act(y.reshape(B * T * r, p["co"]), B, T * r, p["co"], 0)                                # -> [B T r, co]: a view
+        raise NotImplementedError(p["kind"])
+
+    def _resblock(self, a: _Act, p):
+        a = a.clean() if a.prefix else a
+        h = self._conv(a, p["c1"], elu=True)
+        sc = self._conv(a, p["sc"], elu=False)
+        return self._conv(h, p["c2"], elu=True, resid=sc.x)
+
+    def _lstm(self, a: _Act, p):
+        prec = _PRECISIONS[self.precision]
+        a = a.clean()
+        B, T, H = a.B, a.T, p["H"]
+        lib = _lib.load()
+        x = a.x
+        state = torch.empty(3 * B * H, dtype=torch.float32, device=x.device)
+        for i, l in enumerate(p["layers"]):
+            pl = _prep(x, B, T, H, precision=prec)
+            xproj = ops.linear_f32(l["w_ih"], pl, bias=l["b_ih"], precision=prec)                       # [B T, 4H]
+            out = torch.empty(B * T, H, dtype=torch.float32, device=x.device)
+            last = i + 1 == len(p["layers"])
+            resid = a.x if last else None                                                                 # HFENC:264: lstm(x) + x
+            check(lib.ns2_lstm_layer(xproj.data_ptr(), 4 * H, l["w_hh"].data_ptr(), l["b_hh"].data_ptr(), state.data_ptr(),
+                                     ops._p(resid), H, out.data_ptr(), H, B, T, H, _stream()), "ns2_lstm_layer")
+            x = out
+        return _Act(x, B, T, H, 0)
+
+    @torch.no_grad()
+    def _run(self, x_rows, B, T, C):
+        a = _Act(x_rows, B, T, C, 0)
+        for p in self._packed():
+            if p["kind"] == "res":
+                assert not p["elu"]
+                a = self._resblock(a, p)
+            elif p["kind"] == "lstm":
+                assert not p["elu"]
+                a = self._lstm(a, p)
+            else:
+                a = self._conv(a, p, elu=p["elu"])
+        return a.clean()
+
+
+class SEANetEncoderHIP(_SEANetHIP):
+    """`encoder(wav [b, 1, t]) -> latents [b, 128, n]` (the call `EncodecWrapperHIP.forward` makes), HFENC:304-327"""
+
+    @torch.no_grad()
+    def forward(self, wav):
+        assert wav.ndim == 3 and wav.shape[1] == 1, "mono audio [b, 1, t]"
+        B, _, T = wav.shape
+        a = self._run(wav.reshape(B * T, 1).float().contiguous(), B, T, 1)
+        return a.x.reshape(B, a.T, a.C).transpose(1, 2)
+
+
+class SEANetDecoderHIP(_SEANetHIP):
+    """`decoder(latents [b, 128, n]) -> wav [b, 1, t]`, HFENC:330-358"""
+
+    @torch.no_grad()
+    def forward(self, latents):
+        B, C, N = latents.shape
+        a = self._run(latents.transpose(1, 2).reshape(B * N, C).float().contiguous(), B, N, C)
+        return a.x.reshape(B, a.T, a.C).transpose(1, 2)

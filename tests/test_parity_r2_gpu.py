@@ -178,6 +178,21 @@ def test_large_activation_stress():
     print("stress rel err:", {k: f"{v:.2e}" for k, v in out.items()})
     assert out["x2/exact"] < 1e-4 and out["x2/mixed"] < CEIL["mixed"] and out["x2/half"] < 2e-3, out
     assert out["x8/exact"] < 1e-3, out
+    # weights x8 push activations past the IEEE-half range: precisions "half" / "mixed" clamp (finite, wrong by O(1), see the
+    # numbers above) -- the range guard must say so loudly instead of returning the clamped result
+    from naturalspeech2_pytorch_amd import Ns2Error
+    noise = make_input("noise", (2, 256, 128), seed=42) * 4.0
+    for precision in ("mixed", "half"):
+        ops.saturation_count(reset=True)
+        ok_model, _ = build(kw, seed=40, precision=precision, scale_weights=2.0)
+        d = NaturalSpeech2(ok_model, codec=None, target_sample_hz=24000, timesteps=2)
+        d.sample(length=256, batch_size=2, noise=noise)                       # in range: no complaint
+        bad_model, _ = build(kw, seed=40, precision=precision, scale_weights=8.0)
+        d = NaturalSpeech2(bad_model, codec=None, target_sample_hz=24000, timesteps=2)
+        with pytest.raises(Ns2Error, match="IEEE-half range"):
+            d.sample(length=256, batch_size=2, noise=noise)
+    ex_model, _ = build(kw, seed=40, precision="exact", scale_weights=8.0)
+    NaturalSpeech2(ex_model, codec=None, target_sample_hz=24000, timesteps=2).sample(length=256, batch_size=2, noise=noise)
 
 
 def test_half_conversion_saturates():
@@ -369,11 +384,59 @@ def _hf_encodec():
     return model.to(DEV)
 
 
+@pytest.mark.parametrize("precision,tol", [("exact", 2e-4), ("mixed", 1e-3)])
+def test_seanet_encoder_decoder_match_hf(precision, tol):
+    """EnCodec's SEANet encoder (strided causal convs with reflect padding, ResnetBlocks, 2-layer LSTM) and
+    decoder (transposed convs) on the HIP kernels against HF's own modules (HFENC:285-347) on the same random-init weights"""
+    from naturalspeech2_pytorch_amd import SEANetDecoderHIP, SEANetEncoderHIP
+    hf = _hf_encodec()
+    wav = make_input("wav", (2, 1, 320 * 50), seed=92).to(DEV)
+    with torch.no_grad():
+        ref_lat = hf.encoder(wav)                                   # [2, 128, 50]
+        lat = SEANetEncoderHIP(hf.encoder, precision=precision)(wav)
+        assert lat.shape == ref_lat.shape == (2, 128, 50)
+        e_enc = rel(lat, ref_lat)
+        ref_wav = hf.decoder(ref_lat)                               # [2, 1, 16000]
+        out = SEANetDecoderHIP(hf.decoder, precision=precision)(ref_lat)
+        assert out.shape == ref_wav.shape == (2, 1, 320 * 50)
+        e_dec = rel(out, ref_wav)
+    record(f"seanet_vs_hf/{precision}", dict(encoder=e_enc, decoder=e_dec))
+    print(f"SEANet {precision}: encoder rel {e_enc:.2e}, decoder rel {e_dec:.2e}")
+    assert e_enc < tol and e_dec < tol, (e_enc, e_dec)
+
+
+def test_seanet_pieces():
+    """the pieces around the GEMMs: reflect prefix + ELU + im2col (ns2_seanet_prep), and one LSTM layer vs torch.nn.LSTM"""
+    from naturalspeech2_pytorch_amd import seanet as S
+    import torch.nn.functional as F
+    x = make_input("x", (2 * 40, 8), seed=93).to(DEV)
+    pl = S._prep(x, 2, 40, 8, elu=True, prefix=3, precision=3)
+    got = ops.join(pl, 8).reshape(2, 43, 8)
+    xe = F.elu(x.reshape(2, 40, 8))
+    assert rel(got[:, 3:], xe) < 1e-5 and rel(got[:, :3], xe[:, 1:4].flip(1)) < 1e-5          # row -j mirrors row j
+    x1 = make_input("x1", (2 * 40, 1), seed=94).to(DEV)
+    im = ops.join(S._prep(x1, 2, 40, 1, im2col_k=7, precision=3), 7).reshape(2, 40, 7)
+    xp = F.pad(x1.reshape(2, 1, 40), (6, 0), mode="reflect")[:, 0]
+    assert rel(im, xp.unfold(1, 7, 1)) < 1e-5
+    lstm = torch.nn.LSTM(64, 64, 1).to(DEV)
+    xin = make_input("xl", (3, 20, 64), seed=95).to(DEV)
+    with torch.no_grad():
+        ref = lstm(xin.transpose(0, 1))[0].transpose(0, 1) + xin
+        xproj = F.linear(xin.reshape(60, 64), lstm.weight_ih_l0, lstm.bias_ih_l0).contiguous()
+        state = torch.empty(3 * 3 * 64, device=DEV)
+        out = torch.empty(60, 64, device=DEV)
+        from naturalspeech2_pytorch_amd import _lib
+        _lib.check(_lib.load().ns2_lstm_layer(xproj.data_ptr(), 256, lstm.weight_hh_l0.data_ptr(), lstm.bias_hh_l0.data_ptr(),
+                                              state.data_ptr(), xin.reshape(60, 64).data_ptr(), 64, out.data_ptr(), 64, 3, 20, 64,
+                                              torch.cuda.current_stream().cuda_stream), "lstm")
+    assert rel(out.reshape(3, 20, 64), ref) < 1e-5
+
+
 def test_encodec_wrapper_with_hf_seanet():
     """the boundary class `codec(x, return_encoded=True)` on raw audio (BASELINE configs 1 / 4 input shape randn(4, 327680)):
     HF EnCodec's SEANet encoder injected, RVQ in HIP, against HF's own quantizer on the same encoder output"""
     hf = _hf_encodec()
-    codec = EncodecWrapperHIP.from_hf(hf).to(DEV).eval()
+    codec = EncodecWrapperHIP.from_hf(hf, hip_seanet=False).to(DEV).eval()     # HF's SEANet modules: isolates the RVQ comparison
     wav = make_input("wav", (4, 327680), seed=90).to(DEV)
     with torch.no_grad():
         emb, codes, _ = codec(wav, return_encoded=True)
@@ -400,6 +463,15 @@ def test_encodec_wrapper_with_hf_seanet():
     emb2, _, _ = codec(wav[:, : 320 * 10 + 7], return_encoded=True, curtail_from_left=True)
     assert emb2.shape == (4, 10, 128)
     assert codec.decode(emb2).shape == (4, 1, 3200)
+    # the whole codec on HIP (SEANet encoder + RVQ + SEANet decoder) at the BASELINE config 1 / 4 input shape
+    codec_hip = EncodecWrapperHIP.from_hf(hf).to(DEV).eval()
+    with torch.no_grad():
+        emb_h, codes_h, _ = codec_hip(wav, return_encoded=True)
+        wav_h = codec_hip.decode(emb_h)
+        wav_ref = hf.decoder(emb_h.transpose(1, 2))
+    same = (codes_h == codes).all(dim=-1).float().mean().item()
+    record("encodec_wrapper_hip_seanet", dict(frames_with_identical_codes=same, latent_rel=rel(emb_h, emb), decode_rel=rel(wav_h, wav_ref)))
+    assert same > 0.98 and wav_h.shape == (4, 1, 327680) and rel(wav_h, wav_ref) < 2e-4
 
 
 def test_naturalspeech2_with_codec_composition():
