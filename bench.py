@@ -236,11 +236,13 @@ def main():
         avg_ms = kern_ms_v / kern_n_v
         ach = (fl / nl) / (avg_ms * 1e-3) / 1e12
         traffic, tsrc = None, None
-        pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pj) and precision in ("half", "exact") and (dim, depth) == (512, 12):
+        pj = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(pj) and (dim, depth) == (512, 12):
             tj = json.load(open(pj))
-            traffic = tj.get("hbm_bytes_per_launch_by_precision", {}).get(precision, tj.get("hbm_bytes_per_launch"))
-            tsrc = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc passes of round 1, same kernel and shape; NOT measured in this run)"
+            traffic = tj.get("hbm_bytes_per_launch_by_precision", {}).get(precision)
+            if traffic is not None:
+                tsrc = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command "
+                        "(tools/pmc_bench.sh), read side doubled per MI355X_MICROARCH.md; a committed profile, NOT measured in this run")
         return dict(bound="mfma", kernel=f"ns2::{KERNEL_NAME[precision]} = EPI_SPLIT (FF causal conv k3 x{depth}, wavenet init conv, skip-sum GEMM)",
                     achieved=round(ach, 2), peak=PEAK_16BIT_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_16BIT_TFLOPS, 4),
                     traffic=traffic, traffic_source=tsrc, avg_launch_ms=round(avg_ms, 4), launches=kern_n_v,
