@@ -6,21 +6,23 @@ One step = Model.forward_with_cond_scale (cond_scale 1 -> one Model.forward, NS2
 replicas each denoising its own 32-utterance shard (weak scaling; no data-path collective inside the loop; the
 path's single RCCL all-gather of the generated latents runs once after the K steps and is inside the timed region).
 
-    python bench.py [--gpus N --steps K --warmup W] [--precision mixed|half|exact|fast] [--graph]
+    python bench.py [--gpus N --steps K --warmup W] [--precision hybrid|mixed|half|exact|fast] [--graph]
 
 `--gpus N` with N > 1 re-executes itself under `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU,
 backend "nccl" = RCCL) unless it already runs under one (RANK / WORLD_SIZE set by the driver's own launcher).
 
-Default precision is "mixed": one IEEE-half product per contraction plus BOTH first-order correction terms evaluated in
-one block-scaled fp8 MFMA per 32-deep k block -- 4e-5-class error against the fp32 reference (25x inside
-the 1e-3 tolerance of BASELINE.json; sweep in tests/test_parity_r2_gpu.py, quoted in `parity`).  The same JSON line
-reports, from short extra measurements on the same weights, `half_mode` (the half product alone: faster, error 8e-4 = a
-thin margin) and `exact_mode` (bf16 x3, 1e-5), and `side` = the other BASELINE configs (RVQ config 4, conditioned config
-3, d128 config 2), each with its own parity flag and roofline.
+Default precision is "hybrid", a per-site plan: every contraction is one IEEE-half product plus BOTH first-order
+correction terms evaluated in one block-scaled fp8 MFMA per 32-deep k block ("mixed"), except the
+feed-forward causal conv (43 % of the FLOPs), which runs as the half product alone -- 6e-5-class error against the fp32
+reference (>10x inside the 1e-3 tolerance of BASELINE.json; sweep in tests/test_parity_r2_gpu.py, quoted in `parity`).
+The same JSON line reports, from short extra measurements on the same weights, `mixed_mode` (correction terms
+everywhere), `half_mode` (the half product alone everywhere: faster, error 8e-4 = a thin margin) and `exact_mode`
+(bf16 x3, 1e-5), and `side` = the other BASELINE configs (RVQ config 4, conditioned config 3, d128 config 2), each with
+its own parity flag and roofline.
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events recorded by the executor on the launch stream
-around every launch of the dominant kernel symbol (gemm2_kernel<*, EPI_SPLIT, *>: the 12 FF causal convs + wavenet init
-conv + skip GEMM); `cpu_baseline` times the CPU oracle (a port of the reference path, SDPA attention like the reference's
+around every launch of the dominant kernel symbol (hybrid: gemm2_kernel<1, EPI_SPLIT, true> = the 12 FF causal convs;
+other modes: gemm2_kernel<*, EPI_SPLIT, *> = the 12 FF causal convs + wavenet init conv + skip GEMM); `cpu_baseline` times the CPU oracle (a port of the reference path, SDPA attention like the reference's
 default) on the full batch of 32 once.  See DESIGN.md §Measurement.
 """
 import argparse
@@ -38,22 +40,29 @@ sys.path.insert(0, ROOT)
 PEAK_16BIT_TFLOPS = 2500.0         # dense bf16 / f16 MFMA peak, MI355X_MICROARCH.md (spec; 2495 measured)
 PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (RVQ)
 UTT_GFLOP = {(512, 12, False): 316.37, (512, 12, True): 331.98, (128, 6, False): 26.74}   # per 1024-frame utterance, SURVEY §8d
-MFMA_UNITS = {"exact": 3, "mixed": 2, "half": 1, "fast": 1}        # MFMA-pipe time per algorithmic FLOP, in 16-bit-product units
+MFMA_UNITS = {"exact": 3, "mixed": 2, "half": 1, "fast": 1, "hybrid": 1}   # MFMA-pipe time per algorithmic FLOP of the dominant kernel, in 16-bit-product units
 KERNEL_NAME = {"exact": "gemm2_kernel<3, 1, false>", "mixed": "gemm2_kernel<2, 1, true>", "half": "gemm2_kernel<1, 1, true>",
-               "fast": "gemm2_kernel<1, 1, false>"}
+               "fast": "gemm2_kernel<1, 1, false>", "hybrid": "gemm2_kernel<1, 1, true>"}
 DTYPE = {"exact": "bf16x3 split operands on the bf16 MFMA, fp32 accumulate",
          "mixed": "fp16 operands on the f16 MFMA + both first-order correction terms as e5m2 on the block-scaled fp8 MFMA, fp32 accumulate",
+         "hybrid": "fp16 operands on the f16 MFMA + both first-order correction terms as e5m2 on the block-scaled fp8 MFMA "
+                   "(FF causal conv: the fp16 product alone), fp32 accumulate",
          "half": "fp16 operands on the f16 MFMA (one product), fp32 accumulate",
          "fast": "bf16 operands, fp32 accumulate"}
 
 
-def dominant_flops(B, N, dim, depth, ff_mult, wn_layers):
-    """algorithmic FLOPs (2*MAC) of the launches of gemm2_kernel<*, EPI_SPLIT, *> in one step, and their count."""
+def dominant_flops(B, N, dim, depth, ff_mult, wn_layers, conv_only=False, conditioned=False):
+    """algorithmic FLOPs (2*MAC) of the launches of gemm2_kernel<*, EPI_SPLIT, *> in one step, and their count
+    (conv_only: the FF causal convs alone, which in the hybrid plan are the only launches of their kernel symbol)."""
     M = B * N
     f = int(dim * ff_mult * 2 / 3)
     ffconv = 2.0 * M * f * (3 * f)                 # CausalConv1d(f, f, 3)  NS2:1016
     init = 2.0 * M * dim * (3 * dim)               # wavenet.init_conv      NS2:701
     skip = 2.0 * M * dim * (wn_layers * dim)       # 8 skip convs summed    NS2:639-640, 725
+    if conv_only:
+        return depth * ffconv, depth
+    if conditioned:                                # + the cross-attention query projections (same kernel symbol, NS2:1051)
+        return depth * (ffconv + 2.0 * M * dim * dim) + init + skip, 2 * depth + 2
     return depth * ffconv + init + skip, depth + 2
 
 
@@ -107,10 +116,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="mixed", choices=["mixed", "half", "exact", "fast"],
-                    help="mixed (default): half product + fp8 correction terms, ~4e-5 from the fp32 reference; half: one fp16 "
-                         "product, ~8e-4 (thin margin); exact: bf16x3 split, 1e-5; fast: bf16, ~1e-2 (outside the tolerance)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the short half/exact-mode measurements")
+    ap.add_argument("--precision", default="hybrid", choices=["hybrid", "mixed", "half", "exact", "fast"],
+                    help="hybrid (default): half product + fp8 correction terms, FF causal conv half only, ~6e-5 from the fp32 "
+                         "reference; mixed: correction terms everywhere, ~5e-5; half: one fp16 product, ~8e-4 (thin margin); "
+                         "exact: bf16x3 split, 1e-5; fast: bf16, ~1e-2 (outside the tolerance)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short mixed/half/exact-mode measurements")
     ap.add_argument("--no-side", action="store_true", help="skip the side workloads (RVQ config 4, conditioned config 3, d128 config 2)")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=1024)
@@ -187,7 +197,8 @@ def main():
                     step()
                 audio.copy_(keep)
             ns = model._ensure_native()
-            prof_mask = (1 << 1) if (profile and not graph) else 0      # gemm_kernel<*, EPI_SPLIT>
+            # the FF causal convs (bit 7); in the other modes init conv + skip GEMM share their kernel symbol (bit 1)
+            prof_mask = ((1 << 7) | (0 if precision == "hybrid" else (1 << 1))) if (profile and not graph) else 0
             barrier()
             if prof_mask:
                 lib.ns2_model_profile_begin(ns.handle, prof_mask)
@@ -229,10 +240,10 @@ def main():
             ref = O.model_forward(sd_cpu, x, t, **okw)
         return float(((y - ref).double().norm() / ref.double().norm()).item())
 
-    def roofline_obj(precision, dim, depth, kern_ms_v, kern_n_v):
+    def roofline_obj(precision, dim, depth, kern_ms_v, kern_n_v, conditioned=False):
         if not kern_n_v:
             return None
-        fl, nl = dominant_flops(B, N, dim, depth, 4, 8)
+        fl, nl = dominant_flops(B, N, dim, depth, 4, 8, conv_only=(precision == "hybrid"), conditioned=conditioned)
         avg_ms = kern_ms_v / kern_n_v
         ach = (fl / nl) / (avg_ms * 1e-3) / 1e12
         traffic, tsrc = None, None
@@ -243,7 +254,9 @@ def main():
             if traffic is not None:
                 tsrc = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command "
                         "(tools/pmc_bench.sh), read side doubled per MI355X_MICROARCH.md; a committed profile, NOT measured in this run")
-        return dict(bound="mfma", kernel=f"ns2::{KERNEL_NAME[precision]} = EPI_SPLIT (FF causal conv k3 x{depth}, wavenet init conv, skip-sum GEMM)",
+        what = f"FF causal conv k3 x{depth}" + ("" if precision == "hybrid" else ", wavenet init conv, skip-sum GEMM") + \
+               (f", cross-attention q projection x{depth}" if conditioned and precision != "hybrid" else "")
+        return dict(bound="mfma", kernel=f"ns2::{KERNEL_NAME[precision]} = EPI_SPLIT ({what})",
                     achieved=round(ach, 2), peak=PEAK_16BIT_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_16BIT_TFLOPS, 4),
                     traffic=traffic, traffic_source=tsrc, avg_launch_ms=round(avg_ms, 4), launches=kern_n_v,
                     algorithmic_gflop_per_launch=round(fl / nl / 1e9, 2),
@@ -272,7 +285,7 @@ def main():
                 pass
         if not args.no_secondary and not args.conditioned:
             k2 = min(args.steps, 10)
-            for other in ("half", "exact"):
+            for other in ("mixed", "half", "exact"):
                 if other == args.precision:
                     continue
                 e2, km, kn = measure(model, other, k2, 2)
@@ -319,11 +332,55 @@ def main():
                                    roofline=dict(bound="mfma (fp32 v_mfma_f32_32x32x2_f32)", achieved=round(gflop / ms, 2), peak=PEAK_F32_MFMA_TFLOPS,
                                                  unit="TFLOP/s", frac=round(gflop / ms / PEAK_F32_MFMA_TFLOPS, 4)))
         del cbd, latd, codes, emb
+        # --- the codec front of config 4 end to end: raw 24 kHz audio -> SEANet encoder (HIP, seanet.py) -> RVQ codes / latents,
+        #     and latents -> SEANet decoder -> audio; checked against HF's own EncodecModel on the same weights
+        try:
+            import transformers as tf
+            from naturalspeech2_pytorch_amd import EncodecWrapperHIP
+            torch.manual_seed(0)
+            hf = tf.EncodecModel(tf.EncodecConfig()).eval()
+            gq = torch.Generator().manual_seed(1)
+            with torch.no_grad():
+                for layer in hf.quantizer.layers:                    # HF zero-initialises the codebooks
+                    layer.codebook.embed.copy_(torch.randn(layer.codebook.embed.shape, generator=gq))
+            hf = hf.to(dev)
+            codec = EncodecWrapperHIP.from_hf(hf, num_quantizers=8).to(dev)
+            nb, nf = 8, 1024
+            wav = torch.randn(nb, nf * 320, generator=g).to(dev)
+            with torch.no_grad():
+                emb_c, codes_c, _ = codec(wav)                       # warm-up: packs the weights
+                rec = codec.decode(emb_c)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                emb_c, codes_c, _ = codec(wav)
+                torch.cuda.synchronize()
+                t_enc = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                rec = codec.decode(emb_c)
+                torch.cuda.synchronize()
+                t_dec = time.perf_counter() - t0
+                lat_hf = hf.encoder(wav[:2, None])
+                codes_hf = hf.quantizer.encode(lat_hf, bandwidth=6.0).permute(1, 2, 0)            # [b, n, Q]
+                rec_hf = hf.decoder(emb_c[:2].transpose(1, 2))
+            ndiff = int((codes_c[:2] != codes_hf).any(dim=-1).sum())
+            dec_err = float(((rec[:2] - rec_hf).double().norm() / rec_hf.double().norm()).item())
+            secs = nb * nf * 320 / 24000.0
+            side["codec_seanet_rvq"] = dict(
+                metric=f"EnCodec 24 kHz front end to end on the HIP path: {nb} x {nf * 320} samples -> SEANet encoder -> 8-stage RVQ "
+                       f"(codes + latents); latents -> SEANet decoder -> audio; random-init HF EncodecModel weights",
+                encode_ms=round(1e3 * t_enc, 2), decode_ms=round(1e3 * t_dec, 2),
+                encode_x_realtime=round(secs / t_enc, 1), decode_x_realtime=round(secs / t_dec, 1),
+                parity=dict(frames_checked=2 * nf, frames_with_codes_differing_from_hf=ndiff, decode_rel_err_vs_hf=dec_err),
+                note="the 2-layer LSTM recurrence is one small kernel per frame (2 x 1024 dependent launches): latency-bound")
+            del hf, codec, wav, emb_c, codes_c, rec
+        except Exception as e:                                        # transformers missing / API drift: report, do not fail the line
+            side["codec_seanet_rvq"] = dict(skipped=f"{type(e).__name__}: {e}")
+        torch.cuda.empty_cache()
         # --- BASELINE config 3 shape: conditioned d512/L12, prompt 103 frames, frame-aligned cond
         m3 = make_model(512, 12, True)
         e3, km, kn = measure(m3, args.precision, 10, 2, conditioned=True)
         sd3 = {k: v.detach().cpu() for k, v in m3.state_dict().items()}
-        r3 = roofline_obj(args.precision, 512, 12, km, kn)
+        r3 = roofline_obj(args.precision, 512, 12, km, kn, conditioned=True)
         side["conditioned_config3"] = dict(metric="denoise steps/sec, Model(dim=512, depth=12, dim_prompt=512, condition_on_prompt), 32 x 1024 frames, prompt 103 frames, cond_scale 1",
                                            value=round(10 / e3, 3), ms_per_step=round(1e3 * e3 / 10, 3), precision=args.precision,
                                            parity=dict(live_rel_err_vs_fp32_oracle=live_parity(m3, sd3, args.precision, True)),
@@ -365,7 +422,7 @@ def main():
                        "precision": args.precision,
                        "global_batch": B * world, "parallelism": f"dp{world}", "graph_replay": bool(args.graph)},
             "whole_step_algorithmic_tflops_per_gpu": whole,
-            "roofline": roofline_obj(args.precision, dim, depth, kern_ms_v, kern_n_v),
+            "roofline": roofline_obj(args.precision, dim, depth, kern_ms_v, kern_n_v, conditioned=args.conditioned),
             "cpu_baseline": extra.pop("cpu_baseline", None),
             "parity": extra.pop("parity", None),
         }

@@ -165,7 +165,9 @@ typedef struct {
   int dim, depth, dim_head, heads, ff_mult, wavenet_layers, wavenet_stacks, dim_cond_mult;   /* NS2:814-823 */
   int condition_on_prompt, dim_prompt, num_latents_m, resampler_depth;                       /* NS2:826-831 */
   int precision;               /* 3 = bf16 x3 split "exact", 4 = fp16 + fp8 correction terms "mixed", 2 = fp16 single product
-                                  "half", 1 = bf16 single product "fast" */
+                                  "half", 1 = bf16 single product "fast"; 5 = "hybrid": the per-site plan of this model
+                                  only: precision 4 everywhere except the feed-forward causal conv (NS2:1016), which runs
+                                  as one fp16 product (dense fp16 planes from the GEGLU epilogue in, precision-4 lines out) */
 } ns2_model_config;
 
 int ns2_model_create(const ns2_model_config* cfg, ns2_model** out);

@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 103; }   // 103: precision 2 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 104; }   // 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 2, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
   force_gemm_kernel(kernel);

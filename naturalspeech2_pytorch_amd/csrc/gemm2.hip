@@ -353,7 +353,7 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
   if (precision < 1 || precision > 4) return hipErrorInvalidValue;
   const int op_fmt = precision == 2 ? FMT_F16 : (precision == 4 ? FMT_H8 : FMT_BF16);
   if (g.out_fmt < 0) g.out_fmt = op_fmt;
-  g.vt_fmt = (precision == 2 || precision == 4) ? FMT_F16 : FMT_BF16;
+  if (g.vt_fmt < 0) g.vt_fmt = (precision == 2 || precision == 4) ? FMT_F16 : FMT_BF16;
   // operand / output plane pointers must match the formats: IEEE-half planes are dense (no lo pointer), FMT_H8 and the
   // bf16 x3 operands are interleaved lines (lo == hi + 32)
   if (precision == 2 && (g.a_lo || g.w_lo)) return hipErrorInvalidValue;

@@ -40,7 +40,8 @@ namespace ns2 {
   } while (0)
 
 // kernel categories for ns2_model_profile_* (== kernel symbols in a rocprofv3 trace)
-enum { PC_GEMM_F32 = 0, PC_GEMM_SPLIT = 1, PC_GEMM_QKV = 2, PC_GEMM_GEGLU = 3, PC_GEMM_WAVENET = 4, PC_ATTENTION = 5, PC_NORM = 6 };
+enum { PC_GEMM_F32 = 0, PC_GEMM_SPLIT = 1, PC_GEMM_QKV = 2, PC_GEMM_GEGLU = 3, PC_GEMM_WAVENET = 4, PC_ATTENTION = 5, PC_NORM = 6,
+       PC_GEMM_FFCONV = 7 /* the feed-forward causal conv alone (same kernel family as PC_GEMM_SPLIT) */ };
 
 static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t rup64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -99,6 +100,13 @@ static int dev_alloc(std::vector<void*>* owned, void** p, size_t bytes) {
 // Packing context: who owns the allocations and the layout of the weights being packed (ns2_common.h): interleaved
 // [hi32|lo32] rows with a lo plane (exact models and ns2_weight_pack) or dense hi-only rows (precision-1 "fast" models).
 struct PackCtx { std::vector<void*>* owned; bool il; int fmt; };   // il: interleaved 128-B lines (bf16 hi/lo or FMT_H8); fmt: PlaneFmt
+// Model precision 5 ("hybrid") is a per-site plan on top of precision 4: every contraction keeps the fp8 correction terms
+// except the feed-forward causal conv (45 % of the FLOPs), which runs as ONE IEEE-half product: its input arrives as dense
+// half planes from the GEGLU epilogue and it writes FMT_H8 lines for FF-out.  (tools/precision_study.py: of all sites this
+// is the one whose rounding error reaches the output least.)
+static inline int op_precision(int model_precision) { return model_precision == 5 ? 4 : model_precision; }
+static inline bool ffconv_half(int model_precision) { return model_precision == 5; }
+
 static PackCtx pack_ctx_for(std::vector<void*>* owned, int precision) {
   // precision 3: interleaved bf16 hi/lo rows; 1: dense bf16 hi-only weights; 2: dense IEEE-half weights; 4: FMT_H8 lines
   return PackCtx{owned, precision == 3 || precision == 4, precision == 2 ? FMT_F16 : (precision == 4 ? FMT_H8 : FMT_BF16)};
@@ -198,7 +206,7 @@ static GemmArgs base_args(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_
   g.a_hi = a_hi; g.a_lo = a_lo; g.lda = lda;
   g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk;
   g.M = M; g.N = w.N; g.nkt = w.nkt; g.kt_per_tap = w.nkt; g.conv_taps = 0; g.dil = 1; g.mid_kt = -1;
-  g.nz = 1; g.pad_left = -1; g.act = 0; g.out_fmt = -1;
+  g.nz = 1; g.pad_left = -1; g.act = 0; g.out_fmt = -1; g.vt_fmt = -1;
   return g;
 }
 static void set_conv(GemmArgs& g, const PackedW& w, int taps, int dil, int seq_len) {
@@ -224,17 +232,19 @@ int gemm_split(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda
   return NS2_OK;
 }
 int gemm_geglu(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, const float* pbias, bf16_t* o_hi,
-               bf16_t* o_lo, int ldo, int prec, hipStream_t s) {
+               bf16_t* o_lo, int ldo, int prec, hipStream_t s, int out_fmt) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
+  g.out_fmt = out_fmt;
   g.epi = EPI_GEGLU; g.bias = pbias; g.out_hi = o_hi; g.out_lo = o_lo; g.ldo_s = ldo; g.out_ncols = ldo;
   HIPCHK(launch_gemm(g, prec, s));
   return NS2_OK;
 }
 int gemm_qkv(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int seq_len, int split_col,
-             bf16_t* o_hi, bf16_t* o_lo, int ldo, bf16_t* vt_hi, bf16_t* vt_lo, int vt_ld, int prec, hipStream_t s) {
+             bf16_t* o_hi, bf16_t* o_lo, int ldo, bf16_t* vt_hi, bf16_t* vt_lo, int vt_ld, int prec, hipStream_t s, int att_fmt) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
   g.epi = EPI_QKV; g.seq_len = seq_len; g.split_col = split_col;
   g.out_fmt = (prec == 2 || prec == 4) ? FMT_F16 : FMT_BF16;        // q / k are attention operands: IEEE half also at precision 4
+  if (att_fmt >= 0) { g.out_fmt = att_fmt; g.vt_fmt = att_fmt; }   // ... unless the caller's attention runs in another format
   g.out_hi = o_hi; g.out_lo = o_lo; g.ldo_s = ldo; g.out_ncols = split_col;
   g.vt_hi = vt_hi; g.vt_lo = vt_lo; g.vt_ld = vt_ld; g.vt_rows = w.N - split_col;
   HIPCHK(launch_gemm(g, prec, s));
@@ -270,7 +280,7 @@ extern "C" int ns2_model_create(const ns2_model_config* cfg, ns2_model** out) {
   if (!cfg || !out) { set_error("null argument"); return NS2_ERR_ARG; }
   if (cfg->dim_head != 64) { set_error("dim_head must be 64 (attention kernel head dim), got %d", cfg->dim_head); return NS2_ERR_ARG; }
   if (cfg->dim % 32) { set_error("dim must be a multiple of 32, got %d", cfg->dim); return NS2_ERR_ARG; }
-  if (cfg->precision < 1 || cfg->precision > 4) { set_error("precision must be 1 (bf16), 2 (fp16), 3 (bf16 x3) or 4 (fp16 + fp8 correction terms)"); return NS2_ERR_ARG; }
+  if (cfg->precision < 1 || cfg->precision > 5) { set_error("precision must be 1 (bf16), 2 (fp16), 3 (bf16 x3), 4 (fp16 + fp8 correction terms) or 5 (4, with the FF causal conv as one fp16 product)"); return NS2_ERR_ARG; }
   if (cfg->wavenet_layers < 1 || cfg->wavenet_layers > 16 || cfg->wavenet_stacks < 1) { set_error("bad wavenet shape"); return NS2_ERR_ARG; }
   ns2_model* m = new ns2_model();
   m->cfg = *cfg;
@@ -314,7 +324,8 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
   const int dim = m->dim, a = m->a, f = m->f, L = m->L, S = m->S;
   const bool cond = m->cfg.condition_on_prompt;
   char key[256];
-  const PackCtx pc = pack_ctx_for(&m->owned, m->cfg.precision);
+  const PackCtx pc = pack_ctx_for(&m->owned, op_precision(m->cfg.precision));
+  const PackCtx pc_conv = ffconv_half(m->cfg.precision) ? pack_ctx_for(&m->owned, 2) : pc;
   const bool il = pc.il;
 
   // ---- time conditioning (NS2:839-843)
@@ -410,7 +421,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
       if (w1->dims[0] != 2 * f) { set_error("FF inner dim mismatch: expected %d got %lld", 2 * f, (long long)w1->dims[0]); return NS2_ERR_STATE; }
       NSCHK(pack_geglu(pc, &ly.ffin, w1->p, f, dim, s));
       NSCHK(pack_geglu_bias(&m->owned, &ly.b_ffin, b1->p, f, ly.ffin.rows_p));
-      NSCHK(pack_linear(pc, &ly.conv, cw->p, f, f, 3, s)); ly.b_conv = cb->p;
+      NSCHK(pack_linear(pc_conv, &ly.conv, cw->p, f, f, 3, s)); ly.b_conv = cb->p;
       NSCHK(pack_linear(pc, &ly.ffout, w2->p, dim, f, 1, s)); ly.b_ffout = b2->p; }
   }
   { GETP(g, "transformer.to_pred.0.gamma"); GETP(w, "transformer.to_pred.1.weight");
@@ -468,14 +479,18 @@ struct Carver {
 struct Planes { bf16_t* hi; bf16_t* lo; int fmt; };
 // Activation formats of a precision: `op` = what the GEMMs multiply in (and write for each other), `att` = what the
 // attention kernel reads (q, k, V^T): 3 -> interleaved bf16 hi/lo for both; 1 -> dense bf16; 2 -> dense IEEE half;
-// 4 -> FMT_H8 lines for GEMM operands, dense IEEE half for the attention operands
-struct Fmts { bool op_il; int op; bool att_il; int att; };
+// 4 -> FMT_H8 lines for GEMM operands, dense IEEE half for the attention operands.
+// `xatt` = the operands of the CROSS attention to the 32 resampled prompt tokens (NS2:799-803).  At precision 4 they are
+// bf16 hi/lo planes and the product runs as bf16 x3: every frame attends to the same 32 keys, so their rounding is not
+// averaged out over the sequence like self-attention's (tools/precision_study.py on the conditioned model: 1.4e-4 with
+// half-product cross attention, 3.8e-5 with it exact); its cost is 6 % of the self-attention's.
+struct Fmts { bool op_il; int op; bool att_il; int att; bool xatt_il; int xatt; int xatt_prec; };
 static Fmts fmts_for(int precision) {
   switch (precision) {
-    case 3: return Fmts{true, FMT_BF16, true, FMT_BF16};
-    case 2: return Fmts{false, FMT_F16, false, FMT_F16};
-    case 4: return Fmts{true, FMT_H8, false, FMT_F16};
-    default: return Fmts{false, FMT_BF16, false, FMT_BF16};
+    case 3: return Fmts{true, FMT_BF16, true, FMT_BF16, true, FMT_BF16, 3};
+    case 2: return Fmts{false, FMT_F16, false, FMT_F16, false, FMT_F16, 2};
+    case 4: return Fmts{true, FMT_H8, false, FMT_F16, true, FMT_BF16, 3};
+    default: return Fmts{false, FMT_BF16, false, FMT_BF16, false, FMT_BF16, 1};
   }
 }
 // n logical elements; il: interleaved 128-B lines in one buffer (4 bytes per element), else one dense 16-bit plane
@@ -491,6 +506,8 @@ struct Work {
   float *tfeat, *t, *condall, *xres, *tmp_f;
   float* skinny_ws; size_t skinny_ws_bytes;     // split-K partial sums of the conditioning projections (caller-owned)
   Planes xs, h0, wA, wB, ssum, xn, qk, vt, o, ffh, ffc;
+  Planes xq;               // cross-attention queries [M, a] in the cross-attention operand format: a view of qk's memory
+  Planes ffh_conv;         // the FF conv's input: ffh itself, or (precision 5) a dense IEEE-half view of the same memory
   int Nkp;
   // prepare_cond scratch
   float *pmean, *ctxf, *latf, *condT, *projf;
@@ -502,7 +519,7 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
   const int64_t M = (int64_t)B * N;
   const int64_t Mq = (int64_t)B * std::max(N, m->cfg.condition_on_prompt ? m->Lm : 0);   // prepare_cond reuses qk / o / ffh
   const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, L = m->L;
-  const Fmts F = fmts_for(m->cfg.precision);
+  const Fmts F = fmts_for(op_precision(m->cfg.precision));
   const bool il = F.op_il;
   const int f16 = F.op;                               // (historical name) PlaneFmt of the GEMM operands
   const bool ail = F.att_il;
@@ -523,10 +540,14 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
   w->ssum = take_planes(c, M * dp, il, f16);
   w->xn = take_planes(c, M * dp, il, f16);
   w->qk = take_planes(c, Mq * 2 * a, ail, afmt);
+  w->xq = w->qk;                                      // M x a interleaved (4 B / element) fits M x 2a dense 16-bit
+  w->xq.fmt = F.xatt; w->xq.lo = F.xatt_il ? w->xq.hi + 32 : nullptr;
   w->Nkp = rup(N, kpad);
   w->vt = take_planes(c, (int64_t)B * a * w->Nkp, ail, afmt);
   w->o = take_planes(c, Mq * a, il, f16);
   w->ffh = take_planes(c, Mq * fp, il, f16);
+  w->ffh_conv = w->ffh;
+  if (ffconv_half(m->cfg.precision)) { w->ffh_conv.lo = nullptr; w->ffh_conv.fmt = FMT_F16; }
   w->ffc = take_planes(c, M * fp, il, f16);
   if (m->cfg.condition_on_prompt && n_prompt > 0) {
     const int Lm = m->Lm;
@@ -556,9 +577,9 @@ static int64_t carve_cond(const ns2_model* m, CondState* cs, void* base, int64_t
   c.take<int64_t>(4);                              // header: {magic, B, N, n_cond_valid}
   cs->prompt_cond = c.take<float>((int64_t)B * m->dt);
   cs->condadd = c.take<float>((int64_t)B * n_cond * m->dim);
-  const Fmts F = fmts_for(m->cfg.precision);
-  const bool il = F.att_il;                         // the cached cross-attention keys / values are attention operands
-  const int f16 = F.att;
+  const Fmts F = fmts_for(op_precision(m->cfg.precision));
+  const bool il = F.xatt_il;                        // the cached cross-attention keys / values are attention operands
+  const int f16 = F.xatt;
   cs->Lmp = rup(m->Lm, il ? 32 : 8);
   cs->ck.resize(m->cfg.depth); cs->cvt.resize(m->cfg.depth);
   for (int l = 0; l < m->cfg.depth; ++l) {
@@ -637,7 +658,7 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
   if (carve_work(m, &w, workspace, workspace_bytes, B, N, n_prompt, n_cond) > workspace_bytes) { set_error("workspace too small"); return NS2_ERR_ARG; }
   CondState cs;
   carve_cond(m, &cs, cond_state, 0, B, N, n_cond);
-  const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, Lm = m->Lm, H = m->cfg.heads, prec = m->cfg.precision;
+  const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, Lm = m->Lm, H = m->cfg.heads, prec = op_precision(m->cfg.precision);
   const int dprompt = m->cfg.dim_prompt, dpp = m->dpp;
 
   float* ctok = w.latf;      // resampled prompt tokens c [B*Lm, dim] fp32 (final norm output or null tokens)
@@ -691,7 +712,7 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
   // per-layer cross-attention keys / values of the (step-invariant) context (NS2:1063 with context = c)
   for (int l = 0; l < m->cfg.depth; ++l)
     NSCHK(gemm_qkv(m->layers[l].ckv, w.cpl.hi, w.cpl.lo, dp, B * Lm, Lm, a, cs.ck[l].hi, cs.ck[l].lo, a, cs.cvt[l].hi, cs.cvt[l].lo,
-                   cs.Lmp, prec, s));
+                   cs.Lmp, prec, s, cs.ck[l].fmt));
   return NS2_OK;
 }
 
@@ -757,8 +778,10 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
   if (carve_work(m, &w, workspace, workspace_bytes, B, N, 0, 0) > workspace_bytes) { set_error("workspace too small"); return NS2_ERR_ARG; }
   CondState cs;
   if (cond) carve_cond(m, &cs, const_cast<void*>(cond_state), 0, B, N, n_cond);
-  const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, L = m->L, S = m->S, H = m->cfg.heads, prec = m->cfg.precision;
+  const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, L = m->L, S = m->S, H = m->cfg.heads, prec = op_precision(m->cfg.precision);
   const int M = B * N, Jtot = m->Jtot, Lm = m->Lm;
+  const int conv_prec = ffconv_half(m->cfg.precision) ? 2 : prec;
+  const int xprec = fmts_for(prec).xatt_prec;
   char name[64];
 
   // ---- t = to_time_cond(times) [, prompt_cond]  (NS2:944-960), then every conditioning projection of the step at once
@@ -806,14 +829,15 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
     NSCHK(tap_f32(m, name, w.xres, (int64_t)M * dim, s));
     if (cond) {   // cross attention to the resampled prompt tokens (NS2:799-803)
       PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + 2 * dim, Jtot, w.xn, dp, nullptr, 0, s));
-      PROF(PC_GEMM_SPLIT, gemm_split(ly.cq, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, w.qk.hi, w.qk.lo, a, prec, s, -1, 0, w.qk.fmt));
-      PROF(PC_ATTENTION, attention_call(w.qk.hi, w.qk.lo, a, 0, cs.ck[l].hi, cs.ck[l].lo, a, 0, cs.cvt[l], cs.Lmp, w.o, a, B, H, N, Lm, prec, s));
+      PROF(PC_GEMM_SPLIT, gemm_split(ly.cq, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, w.xq.hi, w.xq.lo, a, prec, s, -1, 0, w.xq.fmt));
+      PROF(PC_ATTENTION, attention_call(w.xq.hi, w.xq.lo, a, 0, cs.ck[l].hi, cs.ck[l].lo, a, 0, cs.cvt[l], cs.Lmp, w.o, a, B, H, N, Lm, xprec, s));
       PROF(PC_GEMM_F32, gemm_f32(ly.cout, w.o.hi, w.o.lo, a, M, 0, 1, 0, nullptr, w.xres, dim, w.xres, dim, prec, s));
     }
     // feedforward: Linear -> GEGLU -> causal conv k3 -> Linear (NS2:1009-1025)
     PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + (size_t)(m->nnorm - 1) * 2 * dim, Jtot, w.xn, dp, nullptr, 0, s));
-    PROF(PC_GEMM_GEGLU, gemm_geglu(ly.ffin, w.xn.hi, w.xn.lo, dp, M, ly.b_ffin, w.ffh.hi, w.ffh.lo, fp, prec, s));
-    PROF(PC_GEMM_SPLIT, gemm_split(ly.conv, w.ffh.hi, w.ffh.lo, fp, M, 3, 1, N, ly.b_conv, w.ffc.hi, w.ffc.lo, fp, prec, s));
+    PROF(PC_GEMM_GEGLU, gemm_geglu(ly.ffin, w.xn.hi, w.xn.lo, dp, M, ly.b_ffin, w.ffh_conv.hi, w.ffh_conv.lo, fp, prec, s, w.ffh_conv.fmt));
+    PROF(PC_GEMM_FFCONV, gemm_split(ly.conv, w.ffh_conv.hi, w.ffh_conv.lo, fp, M, 3, 1, N, ly.b_conv, w.ffc.hi, w.ffc.lo, fp,
+                                    conv_prec, s, -1, 0, w.ffc.fmt));
     PROF(PC_GEMM_F32, gemm_f32(ly.ffout, w.ffc.hi, w.ffc.lo, fp, M, 0, 1, 0, ly.b_ffout, w.xres, dim, w.xres, dim, prec, s));
     snprintf(name, sizeof name, "layer%d", l);
     NSCHK(tap_f32(m, name, w.xres, (int64_t)M * dim, s));

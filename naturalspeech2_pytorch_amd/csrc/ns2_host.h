@@ -24,9 +24,9 @@ int gemm_split(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda
                const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left = -1, int act = 0,
                int out_fmt = -1);
 int gemm_geglu(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, const float* pbias, bf16_t* o_hi,
-               bf16_t* o_lo, int ldo, int prec, hipStream_t s);
+               bf16_t* o_lo, int ldo, int prec, hipStream_t s, int out_fmt = -1);
 int gemm_qkv(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int seq_len, int split_col,
-             bf16_t* o_hi, bf16_t* o_lo, int ldo, bf16_t* vt_hi, bf16_t* vt_lo, int vt_ld, int prec, hipStream_t s);
+             bf16_t* o_hi, bf16_t* o_lo, int ldo, bf16_t* vt_hi, bf16_t* vt_lo, int vt_ld, int prec, hipStream_t s, int att_fmt = -1);
 int gemm_wavenet(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, long a_zs, int M, int seq_len, int dil,
                  int dil_z, int nz, const float* b_conv, const float* b_res, long bias_zs, const float* film, int film_ld,
                  long film_zs, bf16_t* o_hi, bf16_t* o_lo, int ldo, long out_zs, int out_ncols, int prec, hipStream_t s);

@@ -70,7 +70,7 @@ struct GemmArgs {
   int out_fmt;       // PlaneFmt of the split-plane output (ns2_common.h).  -1 = "the operand format of the precision":
                      // bf16 planes for 1 / 3, dense IEEE half for 2, FMT_H8 for 4.  Attention operands (q, k: EPI_QKV
                      // columns < split_col, the cross-attention q projection) are IEEE half also at precision 4.
-  int vt_fmt;        // PlaneFmt of the transposed value planes (FMT_BF16 or FMT_F16); set by launch_gemm
+  int vt_fmt;        // PlaneFmt of the transposed value planes (FMT_BF16 or FMT_F16); -1 = the attention format of the precision
 };
 
 // precision: 3 = bf16 x3 ("exact"), 1 = bf16 ("fast"), 2 = one IEEE-half product ("half"), 4 = half product + both

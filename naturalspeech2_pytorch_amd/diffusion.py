@@ -137,7 +137,7 @@ class NaturalSpeech2(nn.Module):
             self.model.refresh_weights()        # parameters rewritten through `.data` since the last pack (EMA) -> re-pack
         if hasattr(self.model, "clear_cond_cache"):
             self.model.clear_cond_cache()
-        guard = getattr(self.model, "precision", "exact") in ("half", "mixed") and audio.is_cuda
+        guard = getattr(self.model, "precision", "exact") in ("half", "mixed", "hybrid") and audio.is_cuda
         if guard:
             ops.saturation_count(reset=True, device=device)
         audio = self._ddim_loop(audio, prompt, cond, cond_scale, use_graph)

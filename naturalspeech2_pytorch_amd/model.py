@@ -126,7 +126,8 @@ class _NativeState:
 
 _CFG_KEYS = ("dim", "depth", "dim_head", "heads", "ff_mult", "wavenet_layers", "wavenet_stacks", "dim_cond_mult",
              "condition_on_prompt", "dim_prompt", "num_latents_m", "resampler_depth")
-_PRECISIONS = {"exact": 3, "mixed": 4, "half": 2, "fast": 1}
+_PRECISIONS = {"exact": 3, "mixed": 4, "half": 2, "fast": 1}          # op-level arithmetic modes (include/ns2hip.h)
+_MODEL_PRECISIONS = dict(_PRECISIONS, hybrid=5)                        # + the per-site plan of the denoiser ("mixed", FF conv "half")
 
 
 # ------------------------------------------------------------------------------------------ HIP execution mixin
@@ -137,7 +138,7 @@ class HipDenoiserMixin:
     `NaturalSpeech2`).  The host class provides `_forward_autograd` for the calls that need autograd."""
 
     def _hip_init(self, cfg: dict, precision: str):
-        assert precision in _PRECISIONS, f"precision must be one of {sorted(_PRECISIONS)}"
+        assert precision in _MODEL_PRECISIONS, f"precision must be one of {sorted(_MODEL_PRECISIONS)}"
         assert set(cfg) == set(_CFG_KEYS)
         self._hip_cfg = dict(cfg)
         self.precision = precision
@@ -191,7 +192,7 @@ class HipDenoiserMixin:
             dim=c["dim"], depth=c["depth"], dim_head=c["dim_head"], heads=c["heads"], ff_mult=c["ff_mult"],
             wavenet_layers=c["wavenet_layers"], wavenet_stacks=c["wavenet_stacks"], dim_cond_mult=c["dim_cond_mult"],
             condition_on_prompt=int(bool(c["condition_on_prompt"])), dim_prompt=int(c["dim_prompt"] or 0),
-            num_latents_m=c["num_latents_m"], resampler_depth=c["resampler_depth"], precision=_PRECISIONS[self.precision])
+            num_latents_m=c["num_latents_m"], resampler_depth=c["resampler_depth"], precision=_MODEL_PRECISIONS[self.precision])
         h = ctypes.c_void_p()
         check(lib.ns2_model_create(ctypes.byref(cfg), ctypes.byref(h)), "ns2_model_create")
         ns.handle = h

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the dominant kernel during bench.py (separate --pmc passes, MI355X_MICROARCH.md §HBM): writes
-# profiles-ready JSON to gpurun_out/pmc_traffic_<precision>.json.  usage (GPU box): tools/pmc_bench.sh <mixed|exact|half|fast> [bench args]
+# profiles-ready JSON to gpurun_out/pmc_traffic_<precision>.json.  usage (GPU box): tools/pmc_bench.sh <hybrid|mixed|exact|half|fast> [bench args]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 PREC=${1:-half}; shift
 OUT=$R/gpurun_out/pmc_bench_$PREC
@@ -20,7 +20,9 @@ for k, d in res.items():
     if "gemm2_kernel" not in k and "attn_kernel" not in k: continue
     fs = d.get("FETCH_SIZE", [0]); ws = d.get("WRITE_SIZE", [0])
     out[k] = dict(launches=len(fs), fetch_kb_per_launch=sum(fs)/max(1,len(fs)), write_kb_per_launch=sum(ws)/max(1,len(ws)))
-dom = [k for k in out if "gemm2_kernel<3, 1," in k or "gemm2_kernel<1, 1," in k or "gemm2_kernel<2, 1," in k]
+want = {"hybrid": "gemm2_kernel<1, 1, true>", "half": "gemm2_kernel<1, 1, true>", "mixed": "gemm2_kernel<2, 1, true>",
+        "exact": "gemm2_kernel<3, 1, false>", "fast": "gemm2_kernel<1, 1, false>"}["$PREC"]
+dom = [k for k in out if want in k]
 j = dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py; values are KB per launch as reported "
               "(gfx950: FETCH_SIZE under-reports wide coalesced streams by up to 2x, MI355X_MICROARCH.md HBM section; "
               "L2 misses served by the 256 MiB Infinity Cache are counted as fabric reads)", kernels=out)

@@ -44,6 +44,23 @@ class Scheme:
     def __init__(self, name, units, fn, attn_fn=None, resid_fn=None):
         self.name, self.units, self.fn, self.attn_fn = name, units, fn, attn_fn or fn   # attn_fn: the two attention products
         self.resid_fn = resid_fn or fn          # Linears whose output goes to the residual stream (out features == dim)
+        self.site_fn = None                     # optional: (kind, weight shape) -> contraction fn, overrides fn / resid_fn
+
+def per_site(name, units, default, **sites):
+    """sites: ffconv / ffin / ffout / qkv / attnout / wavenet -> fn (classified by the weight's shape)"""
+    sc = Scheme(name, units, default, mk(FH, [(0, 0)]))
+    def pick(kind, ws):
+        if kind == "conv":
+            site = "wavenet" if ws[0] in (DIM, 2 * DIM) or ws[1] == DIM else "ffconv"
+        elif ws[1] == DIM:
+            site = "ffin" if ws[0] > 3 * DIM else "qkv"
+        elif ws[0] == DIM:
+            site = "ffout" if ws[1] > DIM else "attnout"
+        else:
+            site = "other"
+        return sites.get(site, default)
+    sc.site_fn = pick
+    return sc
 
 def mk(fmt, terms):
     """terms: list of (a_piece_index, w_piece_index)"""
@@ -126,6 +143,15 @@ SCHEMES = [
     Scheme("fp16 hi.hi + cross terms MX fp6 e3m2 (GEMMs), fp16 attention", 1.5, f16_mx_cross(3, 2, 3), mk(FH, [(0, 0)])),
     Scheme("fp16 hi.hi + cross terms MX fp4 e2m1 (GEMMs), fp16 attention", 1.5, f16_mx_cross(2, 1, 1), mk(FH, [(0, 0)])),
     Scheme("fp16 hi.hi + cross terms fp8 e5m2 (GEMMs), fp16 attention", 2.0, f16_e5m2_cross(), mk(FH, [(0, 0)])),
+    per_site("mixed, FF conv fp16 x1", 1.55, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)])),
+    per_site("mixed, FF conv + FF-in fp16 x1", 1.45, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), ffin=mk(FH, [(0, 0)])),
+    per_site("mixed, whole FF fp16 x1", 1.4, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), ffin=mk(FH, [(0, 0)]), ffout=mk(FH, [(0, 0)])),
+    per_site("mixed, wavenet fp16 x1", 1.8, f16_e5m2_cross(), wavenet=mk(FH, [(0, 0)])),
+    per_site("mixed, FF conv + wavenet fp16 x1", 1.35, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), wavenet=mk(FH, [(0, 0)])),
+    per_site("fp16 x1, FF conv mixed", 1.45, mk(FH, [(0, 0)]), ffconv=f16_e5m2_cross()),
+    per_site("fp16 x1, wavenet mixed", 1.2, mk(FH, [(0, 0)]), wavenet=f16_e5m2_cross()),
+    per_site("fp16 x1, qkv+attnout mixed", 1.1, mk(FH, [(0, 0)]), qkv=f16_e5m2_cross(), attnout=f16_e5m2_cross()),
+    per_site("fp16 x1, ffin+ffout mixed", 1.15, mk(FH, [(0, 0)]), ffin=f16_e5m2_cross(), ffout=f16_e5m2_cross()),
     Scheme("bf16 hi.hi + both cross terms on fp8(e4m3, MX32)", 2.0, fp8_cross("aw wa")),
     Scheme("bf16 hi.hi + both cross terms on fp8, one scale per row", 2.0, fp8_cross_row()),
     Scheme("bf16 hi.hi + lo.hi bf16 + hi.lo on fp8", 2.5, fp8_cross("aw")),
@@ -139,12 +165,14 @@ def run(sd, x, t, scheme, big_rows):
     def lin(inp, w, b=None):
         if inp.numel() // inp.shape[-1] < big_rows: return lin0(inp, w, b)
         f = scheme.resid_fn if (w.shape[0] == DIM and w.shape[1] != DIM) else scheme.fn
+        if scheme.site_fn: f = scheme.site_fn("lin", tuple(w.shape))
         y = f(inp, w, lambda a, ww: a @ ww.t())          # contraction axis: last of both
         return (y + (b.double() if b is not None else 0)).float()
     def conv(inp, w, b=None, stride=1, padding=0, dilation=1, groups=1):
         if inp.shape[-1] * inp.shape[0] < big_rows: return conv0(inp, w, b, stride, padding, dilation, groups)
         cf = lambda a, ww: conv0(a, ww, None, stride, padding, dilation, groups)      # contraction axis: channels (dim 1 of both)
-        y = scheme.fn(inp, w, cf, 1, 1) if getattr(scheme.fn, "takes_axes", False) else scheme.fn(inp, w, cf)
+        fn = scheme.site_fn("conv", tuple(w.shape)) if scheme.site_fn else scheme.fn
+        y = fn(inp, w, cf, 1, 1) if getattr(fn, "takes_axes", False) else fn(inp, w, cf)
         return (y + (b.double()[None, :, None] if b is not None else 0)).float()
     def ein(eq, a, bb):
         y = scheme.attn_fn(a, bb, lambda p, q: ein0(eq, p, q))
