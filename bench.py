@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph (no live per-kernel events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the live parity forward (profile runs: keeps the kernel trace to the timed workload)")
     ap.add_argument("--conditioned", action="store_true",
                     help="BASELINE config 3 instead of the headline: dim_prompt=512, condition_on_prompt, prompt of 103 codec "
                          "frames, frame-aligned cond")
@@ -272,8 +273,8 @@ def main():
     extra = {}
     if rank == 0 and world == 1 and not args.graph:
         sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        parity = {"live_rel_err_vs_fp32_oracle": {args.precision: live_parity(model, sd_cpu, args.precision, args.conditioned)},
-                  "tolerance": 1e-3}
+        parity = {"live_rel_err_vs_fp32_oracle": {} if args.no_parity else
+                  {args.precision: live_parity(model, sd_cpu, args.precision, args.conditioned)}, "tolerance": 1e-3}
         pj = os.path.join(ROOT, "profiles", "r02_parity.json")
         if os.path.exists(pj):
             try:

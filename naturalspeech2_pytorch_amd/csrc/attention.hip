@@ -161,25 +161,27 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
       }
     }
 
-    // ---- online softmax for query l31; register r of sub-tile js is key key0 + 32js + 16(r>>3) + 8hi + (r&7)
-    const bool tail = key0 + 64 > a.Nk;
+    // ---- online softmax for query l31; register r of sub-tile js is key key0 + 32js + 16(r>>3) + 8hi + (r&7).
+    // st holds RAW scores; the scale (and log2 e) is folded into the exponent's fma.  Key masking is a wave-uniform
+    // slow path: only the last tile of a ragged key length, or a call with a key-padding mask, takes it.
     const unsigned char* km = a.kmask ? a.kmask + (long)b * a.Nk : nullptr;
+    if (key0 + 64 > a.Nk || km) {
+#pragma unroll
+      for (int js = 0; js < 2; ++js)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + 32 * js + 16 * (r >> 3) + 8 * hi + (r & 7);
+          if (key >= a.Nk) st[js][r] = -INFINITY;
+          else if (km && !km[key]) st[js][r] = -3.0e38f;   // ATT:136-138 masked_fill(~mask, -finfo.max): finite, like the reference
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int js = 0; js < 2; ++js)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = st[js][r] * sl2;
-        if (tail || km) {
-          const int key = key0 + 32 * js + 16 * (r >> 3) + 8 * hi + (r & 7);
-          if (key >= a.Nk) s = -INFINITY;
-          else if (km && !km[key]) s = -3.0e38f;      // ATT:136-138 masked_fill(~mask, -finfo.max): finite, like the reference
-        }
-        st[js][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, st[js][r]), st[js][r + 1]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run, mx * sl2);           // sl2 > 0: the scaled maximum is the maximum of the scaled scores
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
@@ -187,15 +189,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
     for (int js = 0; js < 2; ++js)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(st[js][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[js][r], sl2, -m_new));
         st[js][r] = p;
         psum += p;
       }
     l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {                           // the running maximum rarely moves after the first tiles
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+    }
 
     // ---- O^T += V^T P^T
 #pragma unroll
@@ -206,7 +210,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
         {
           uint32_t ph[4], pl[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) split2f(st[js][8 * g1 + 2 * e], st[js][8 * g1 + 2 * e + 1], ph[e], pl[e], F16);
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (F16) { ph[e] = cvt2h_inrange(st[js][8 * g1 + 2 * e], st[js][8 * g1 + 2 * e + 1]); pl[e] = 0u; }   // p in [0, 1]
+            else split2(st[js][8 * g1 + 2 * e], st[js][8 * g1 + 2 * e + 1], ph[e], pl[e]);
+          }
           const uint4 uh = make_uint4(ph[0], ph[1], ph[2], ph[3]);
           pf[0] = *reinterpret_cast<const bf16x8*>(&uh);
           if constexpr (NSPLIT == 3) {

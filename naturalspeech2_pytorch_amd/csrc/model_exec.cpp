@@ -106,6 +106,11 @@ struct PackCtx { std::vector<void*>* owned; bool il; int fmt; };   // il: interl
 // is the one whose rounding error reaches the output least.)
 static inline int op_precision(int model_precision) { return model_precision == 5 ? 4 : model_precision; }
 static inline bool ffconv_half(int model_precision) { return model_precision == 5; }
+// The step-invariant conditioning (ns2_model_prepare_cond: perceiver resampler, cond_to_model_dim, per-layer cross-attention
+// K / V) runs once per sampling run on a few rows, and every frame of every step consumes its 32 resampled tokens: their
+// rounding is a systematic error of the whole run (measured on the conditioned d512/L12 model: tokens 2.1e-4 -> output
+// 2.2e-4 at precision 4 against 4e-5 without conditioning).  So the IEEE-half modes compute it with the bf16 x3 products.
+static inline int cond_precision(int op_prec) { return (op_prec == 2 || op_prec == 4) ? 3 : op_prec; }
 
 static PackCtx pack_ctx_for(std::vector<void*>* owned, int precision) {
   // precision 3: interleaved bf16 hi/lo rows; 1: dense bf16 hi-only weights; 2: dense IEEE-half weights; 4: FMT_H8 lines
@@ -326,6 +331,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
   char key[256];
   const PackCtx pc = pack_ctx_for(&m->owned, op_precision(m->cfg.precision));
   const PackCtx pc_conv = ffconv_half(m->cfg.precision) ? pack_ctx_for(&m->owned, 2) : pc;
+  const PackCtx pc_cond = pack_ctx_for(&m->owned, cond_precision(op_precision(m->cfg.precision)));   // weights of prepare_cond
   const bool il = pc.il;
 
   // ---- time conditioning (NS2:839-843)
@@ -412,7 +418,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
     if (cond) {
       GETP(q, p + ".3.to_q.weight"); GETP(kv, p + ".3.to_kv.weight"); GETP(o, p + ".3.to_out.weight");
       NSCHK(pack_linear(pc, &ly.cq, q->p, a, dim, 1, s));
-      NSCHK(pack_linear(pc, &ly.ckv, kv->p, 2 * a, dim, 1, s));
+      NSCHK(pack_linear(pc_cond, &ly.ckv, kv->p, 2 * a, dim, 1, s));
       NSCHK(pack_linear(pc, &ly.cout, o->p, dim, a, 1, s));
     }
     { GETP(w1, p + ".5.0.weight"); GETP(b1, p + ".5.0.bias");
@@ -436,11 +442,11 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
     { GETP(p2, "null_prompt_tokens"); m->null_prompt_tokens = p2->p; }
     { GETP(p3, "null_cond"); m->null_cond = p3->p; }
     { GETP(w, "cond_to_model_dim.weight"); GETP(b, "cond_to_model_dim.bias");
-      NSCHK(pack_linear(pc, &m->w_cond2model, w->p, dim, dprompt, 1, s)); m->b_cond2model = b->p; }
+      NSCHK(pack_linear(pc_cond, &m->w_cond2model, w->p, dim, dprompt, 1, s)); m->b_cond2model = b->p; }
     m->has_proj = find_param(m, "perceiver_resampler.proj_context.weight") != nullptr;
     if (m->has_proj) {
       GETP(w, "perceiver_resampler.proj_context.weight"); GETP(b, "perceiver_resampler.proj_context.bias");
-      NSCHK(pack_linear(pc, &m->w_proj, w->p, dim, dprompt, 1, s)); m->b_proj = b->p;
+      NSCHK(pack_linear(pc_cond, &m->w_proj, w->p, dim, dprompt, 1, s)); m->b_proj = b->p;
     } else if (dprompt != dim) { set_error("dim_prompt != dim but proj_context is missing"); return NS2_ERR_STATE; }
     { GETP(lt, "perceiver_resampler.latents"); m->latents = lt->p; }
     { GETP(g, "perceiver_resampler.norm.gamma"); m->g_resampler = g->p; }
@@ -451,12 +457,12 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
       const std::string p(key);
       GETP(q, p + ".0.to_q.weight"); GETP(kv, p + ".0.to_kv.weight"); GETP(o, p + ".0.to_out.weight");
       GETP(w1, p + ".1.0.weight"); GETP(b1, p + ".1.0.bias"); GETP(w2, p + ".1.2.weight"); GETP(b2, p + ".1.2.bias");
-      NSCHK(pack_linear(pc, &r.q, q->p, a, dim, 1, s));
-      NSCHK(pack_linear(pc, &r.kv, kv->p, 2 * a, dim, 1, s));
-      NSCHK(pack_linear(pc, &r.out, o->p, dim, a, 1, s));
-      NSCHK(pack_geglu(pc, &r.ffin, w1->p, f, dim, s));
+      NSCHK(pack_linear(pc_cond, &r.q, q->p, a, dim, 1, s));
+      NSCHK(pack_linear(pc_cond, &r.kv, kv->p, 2 * a, dim, 1, s));
+      NSCHK(pack_linear(pc_cond, &r.out, o->p, dim, a, 1, s));
+      NSCHK(pack_geglu(pc_cond, &r.ffin, w1->p, f, dim, s));
       NSCHK(pack_geglu_bias(&m->owned, &r.b_ffin, b1->p, f, r.ffin.rows_p));
-      NSCHK(pack_linear(pc, &r.ffout, w2->p, dim, f, 1, s)); r.b_ffout = b2->p;
+      NSCHK(pack_linear(pc_cond, &r.ffout, w2->p, dim, f, 1, s)); r.b_ffout = b2->p;
     }
   }
   HIPCHK(hipStreamSynchronize(s));
@@ -517,7 +523,8 @@ struct Work {
 static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, int B, int N, int n_prompt, int n_cond) {
   Carver c(base, cap);
   const int64_t M = (int64_t)B * N;
-  const int64_t Mq = (int64_t)B * std::max(N, m->cfg.condition_on_prompt ? m->Lm : 0);   // prepare_cond reuses qk / o / ffh
+  // prepare_cond reuses qk / o / ffh for its B x Lm rows, possibly in a wider format (cond_precision): twice the rows cover it
+  const int64_t Mq = (int64_t)B * std::max(N, m->cfg.condition_on_prompt ? 2 * m->Lm : 0);
   const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, L = m->L;
   const Fmts F = fmts_for(op_precision(m->cfg.precision));
   const bool il = F.op_il;
@@ -551,7 +558,10 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
   w->ffc = take_planes(c, M * fp, il, f16);
   if (m->cfg.condition_on_prompt && n_prompt > 0) {
     const int Lm = m->Lm;
-    w->Nctx = Lm + n_prompt; w->Nctxp = rup(w->Nctx, kpad);
+    const Fmts CF = fmts_for(cond_precision(op_precision(m->cfg.precision)));     // formats of the prepare_cond pass
+    const bool il = CF.op_il, ail = CF.att_il;
+    const int f16 = CF.op, afmt = CF.att;
+    w->Nctx = Lm + n_prompt; w->Nctxp = rup(w->Nctx, ail ? 32 : 8);
     w->pmean = c.take<float>((int64_t)B * m->cfg.dim_prompt);
     w->ctxf = c.take<float>((int64_t)B * w->Nctx * dim);
     w->latf = c.take<float>((int64_t)B * Lm * dim);
@@ -658,8 +668,14 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
   if (carve_work(m, &w, workspace, workspace_bytes, B, N, n_prompt, n_cond) > workspace_bytes) { set_error("workspace too small"); return NS2_ERR_ARG; }
   CondState cs;
   carve_cond(m, &cs, cond_state, 0, B, N, n_cond);
-  const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, Lm = m->Lm, H = m->cfg.heads, prec = op_precision(m->cfg.precision);
+  const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, Lm = m->Lm, H = m->cfg.heads;
+  const int prec = cond_precision(op_precision(m->cfg.precision));     // the arithmetic of THIS pass (see cond_precision)
   const int dprompt = m->cfg.dim_prompt, dpp = m->dpp;
+  {   // the buffers shared with the forward pass (qk, o, ffh), viewed in this pass's formats
+    const Fmts CF = fmts_for(prec);
+    auto retype = [](Planes& p, bool il, int fmt) { p.fmt = fmt; p.lo = il ? p.hi + 32 : nullptr; };
+    retype(w.qk, CF.att_il, CF.att); retype(w.o, CF.op_il, CF.op); retype(w.ffh, CF.op_il, CF.op);
+  }
 
   float* ctok = w.latf;      // resampled prompt tokens c [B*Lm, dim] fp32 (final norm output or null tokens)
   if (drop) {

@@ -91,6 +91,11 @@ NS2_DEVINL uint32_t cvt2h(float a, float b) {         // {half(a) | half(b) << 1
   f32x2_t v = {fminf(fmaxf(a, -65504.f), 65504.f), fminf(fmaxf(b, -65504.f), 65504.f)};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
 }
+// the same for values known to lie inside the half range (softmax probabilities): no clamp, no range guard
+NS2_DEVINL uint32_t cvt2h_inrange(float a, float b) {
+  f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
 NS2_DEVINL float h2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 // element-format-aware pair conversion: f16 planes have no lo part
 NS2_DEVINL void split2f(float a, float b, uint32_t& hi, uint32_t& lo, int f16) {

@@ -19,29 +19,23 @@ constexpr int RV_D = 128;
 constexpr int RV_ROWF = RV_D + 4;                 // padded LDS row (floats): 528 B = 33 x 16 B
 constexpr int RV_TILE = 64;                       // codes per tile
 constexpr int RV_STAGE_F = RV_TILE * RV_ROWF + RV_TILE;   // tile + its 64 half-norms
-constexpr int RV_ROWS = 128;                      // latent rows per workgroup: 8 row groups of 16
-constexpr int RV_THREADS = 1024;                  // 16 waves: two per row group, each scanning half of every code tile
-constexpr int RV_XCHG_F = 2 * 8 * 16 * 4;         // floats: per (code half, row group, row) the wave's {best.v, best.i, second.v, second.i}
+constexpr int RV_ROWS = 128;                      // latent rows per workgroup: 8 waves x 16 rows
 
 struct Cand { float v; int i; };
 NS2_DEVINL bool better(const Cand& a, const Cand& b) { return a.v > b.v || (a.v == b.v && a.i < b.i); }
 
 // Round-2 structure: v_mfma_f32_16x16x4_f32 (32-cycle issue, 40-cycle dependent latency) on 16 latent rows per wave and
-// SIXTEEN waves per workgroup of 128 rows, i.e. four waves per SIMD at one workgroup per CU: while a wave runs its arg-max
-// VALU phase or waits for its LDS fragment reads the others keep the fp32 matrix pipe busy (the 32x32x2 version ran ONE wave
-// per SIMD and idled the pipe during every VALU phase: 51 % of the 157 TF peak; 8 waves: 61 %).  Waves w and w + 8 hold the
-// same 16 rows and scan the lower / upper 32 codes of every 64-code tile; their running (best, second) pairs meet in LDS
-// once per quantizer stage.  Product D[code][row] as before: a lane (l15 = lane & 15,
+// EIGHT waves per workgroup of 128 rows, i.e. two waves per SIMD at one workgroup per CU: while one wave of a SIMD runs its
+// arg-max VALU / LDS phase the other keeps the fp32 matrix pipe busy (the 32x32x2 version ran ONE wave per SIMD and idled the
+// pipe during every VALU phase: 51 % of the 157 TF peak).  Product D[code][row] as before: a lane (l15 = lane & 15,
 // g = lane >> 4) owns row l15 and, per 16-code group, the 4 codes 4 g .. 4 g + 3; two code groups are accumulated as
 // independent chains to cover the dependent latency.  K assignment: lane group g multiplies k = 32 g .. 32 g + 31 (any
 // assignment is a valid contraction order; this one makes both operands 16-B vector loads).
-__global__ __launch_bounds__(RV_THREADS, 1) void rvq_encode_kernel(const RvqArgs a) {
+__global__ __launch_bounds__(512, 2) void rvq_encode_kernel(const RvqArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int rgrp = wave & 7, chalf = wave >> 3;       // row group, code half
-  float* xchg = lds + 2 * RV_STAGE_F;
-  const long row = (long)blockIdx.x * RV_ROWS + rgrp * 16 + l15;
+  const long row = (long)blockIdx.x * RV_ROWS + wave * 16 + l15;
   const bool row_ok = row < a.M;
 
   // residual fragment: rf[s] = r[row][32 g + s]  (B operand: k slot (g, s))
@@ -54,13 +48,13 @@ __global__ __launch_bounds__(RV_THREADS, 1) void rvq_encode_kernel(const RvqArgs
   }
 
   const int ntile = a.C / RV_TILE;
-  // staging: 64 rows x 512 B = 2048 chunks of 16 B -> 2 per thread
-  struct TileRegs { f32x4 v[2]; float nrm; };
+  // staging: 64 rows x 512 B = 2048 chunks of 16 B -> 4 per thread
+  struct TileRegs { f32x4 v[4]; float nrm; };
   auto load_tile = [&](TileRegs& tr, int q, int ct) {
     const float* src = a.codebooks + ((long)q * a.C + (long)ct * RV_TILE) * RV_D;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + RV_THREADS * i;
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 512 * i;
       tr.v[i] = *reinterpret_cast<const f32x4*>(src + (long)(c >> 5) * RV_D + (c & 31) * 4);
     }
     tr.nrm = (tid < RV_TILE) ? a.cb_norm[(long)q * a.C + ct * RV_TILE + tid] : 0.f;
@@ -68,8 +62,8 @@ __global__ __launch_bounds__(RV_THREADS, 1) void rvq_encode_kernel(const RvqArgs
   auto store_tile = [&](const TileRegs& tr, int sidx) {
     float* base = lds + sidx * RV_STAGE_F;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + RV_THREADS * i;
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 512 * i;
       *reinterpret_cast<f32x4*>(base + (c >> 5) * RV_ROWF + (c & 31) * 4) = tr.v[i];
     }
     if (tid < RV_TILE) base[RV_TILE * RV_ROWF + tid] = tr.nrm;
@@ -86,8 +80,8 @@ __global__ __launch_bounds__(RV_THREADS, 1) void rvq_encode_kernel(const RvqArgs
       const bool more = (ct + 1) < ntile;
       if (more) load_tile(tr, q, ct + 1);
       const float* tb = lds + (ct & 1) * RV_STAGE_F;
-      {                                                                      // this wave's pair of 16-code groups
-        const int cp = chalf;
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {                                       // two pairs of 16-code groups per tile
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         const float* e0 = tb + ((2 * cp) * 16 + l15) * RV_ROWF + g * 32;     // A operand: E[code = l15][k slot (g, s)]
         const float* e1 = e0 + 16 * RV_ROWF;
@@ -135,20 +129,6 @@ __global__ __launch_bounds__(RV_THREADS, 1) void rvq_encode_kernel(const RvqArgs
       best = win;
       second = better(lose, s2) ? lose : s2;
     }
-    // ... and the two waves holding the other half of the codes
-    if (g == 0) *reinterpret_cast<float4*>(xchg + ((chalf * 8 + rgrp) * 16 + l15) * 4) =
-        make_float4(best.v, __int_as_float(best.i), second.v, __int_as_float(second.i));
-    __syncthreads();
-    {
-      const float4 o = *reinterpret_cast<const float4*>(xchg + (((chalf ^ 1) * 8 + rgrp) * 16 + l15) * 4);
-      const Cand pb = {o.x, __float_as_int(o.y)}, ps = {o.z, __float_as_int(o.w)};
-      const bool mine = better(best, pb);
-      const Cand win = mine ? best : pb;
-      const Cand lose = mine ? pb : best;
-      const Cand s2 = better(second, ps) ? second : ps;
-      best = win;
-      second = better(lose, s2) ? lose : s2;
-    }
     int idx = best.i;
 
     const float* cbq = a.codebooks + (long)q * a.C * RV_D;
@@ -166,9 +146,9 @@ __global__ __launch_bounds__(RV_THREADS, 1) void rvq_encode_kernel(const RvqArgs
       d0 += __shfl_xor(d0, 16, 64); d1 += __shfl_xor(d1, 16, 64);
       d0 += __shfl_xor(d0, 32, 64); d1 += __shfl_xor(d1, 32, 64);
       if (d1 < d0 || (d1 == d0 && second.i < best.i)) idx = second.i;
-      if (a.near_tie_count && g == 0 && chalf == 0 && row_ok) atomicAdd(a.near_tie_count, 1);
+      if (a.near_tie_count && g == 0 && row_ok) atomicAdd(a.near_tie_count, 1);
     }
-    if (row_ok && g == 0 && chalf == 0) a.codes[row * a.Q + q] = (int64_t)idx;
+    if (row_ok && g == 0) a.codes[row * a.Q + q] = (int64_t)idx;
 
     // residual -= E[idx]   (HFENC:433-434); the summed embedding is produced by rvq_decode_kernel from the codes
     const float* esel = cbq + (long)idx * RV_D + g * 32;
@@ -179,7 +159,7 @@ __global__ __launch_bounds__(RV_THREADS, 1) void rvq_encode_kernel(const RvqArgs
     }
   }
 
-  if (row_ok && a.residual && chalf == 0) {
+  if (row_ok && a.residual) {
 #pragma unroll
     for (int s4 = 0; s4 < 8; ++s4)
       *reinterpret_cast<float4*>(a.residual + row * RV_D + g * 32 + s4 * 4) =
@@ -189,13 +169,13 @@ __global__ __launch_bounds__(RV_THREADS, 1) void rvq_encode_kernel(const RvqArgs
 
 hipError_t launch_rvq_encode(const RvqArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.Q <= 0 || a.D != RV_D || a.C <= 0 || (a.C % RV_TILE)) return hipErrorInvalidValue;
-  const size_t lds = (2 * RV_STAGE_F + RV_XCHG_F) * sizeof(float);
+  const size_t lds = 2 * RV_STAGE_F * sizeof(float);
   static DynLdsAttr attr;
   {
     hipError_t e = attr.ensure(reinterpret_cast<const void*>(&rvq_encode_kernel), (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(rvq_encode_kernel, dim3((a.M + RV_ROWS - 1) / RV_ROWS), dim3(RV_THREADS), lds, s, a);
+  hipLaunchKernelGGL(rvq_encode_kernel, dim3((a.M + RV_ROWS - 1) / RV_ROWS), dim3(512), lds, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || !a.emb) return e;
   return launch_rvq_decode(a.codes, a.codebooks, a.emb, a.M, a.Q, a.C, a.D, s);

@@ -8,7 +8,7 @@ cd $R
 python bench.py --steps 20 --warmup 3 > $OUT/bench_default.json 2> $OUT/bench_default.err
 cd /tmp && export TMPDIR=/tmp
 for P in hybrid mixed half exact; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$P -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-side --precision $P > $OUT/prof_$P.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$P -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-side --no-parity --precision $P > $OUT/prof_$P.log 2>&1
   cp $(ls $OUT/prof_$P/*/*kernel_stats.csv | head -1) $OUT/bench_${P}_kernel_stats.csv
   rm -rf $OUT/prof_$P
 done

@@ -6,8 +6,8 @@ PREC=${1:-half}; shift
 OUT=$R/gpurun_out/pmc_bench_$PREC
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-side --precision $PREC "$@" > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-side --precision $PREC "$@" > $OUT/write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-side --no-parity --precision $PREC "$@" > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-side --no-parity --precision $PREC "$@" > $OUT/write.log 2>&1
 python - <<PY
 import csv, glob, json, collections
 res = collections.defaultdict(lambda: collections.defaultdict(list))
