@@ -139,12 +139,15 @@ int ns2_cfg_mix(const float* cond_out, const float* null_out, float* out, int64_
  *   x_reflect[n - (k - 1) + j], the k taps of the first convolution as a K = k Linear.
  * ns2_seanet_unpad: dst[b][t][:] = src[b][prefix + t][:]  (drop the prefix rows of a convolution output)
  * ns2_lstm_layer: one nn.LSTM layer (HFENC:253-266; gate order i, f, g, o).  xproj [B*T, 4H] = x W_ih^T + b_ih (a GEMM, row
- *   b*T + t), w_hh [4H, H], b_hh [4H]; state = 3*B*H floats of caller scratch; out[b*T + t, :H] = h_t (+ resid row). */
+ *   b*T + t), w_hh [4H, H], b_hh [4H]; state = ns2_lstm_state_floats(B, H) floats of caller scratch (at least 3*B*H: with less
+ *   than the full amount the recurrence runs as one launch per step instead of one persistent launch per layer);
+ *   out[b*T + t, :H] = h_t (+ resid row). */
 int ns2_seanet_prep(const float* x, int ldx, int in_prefix, const float* add, int ldadd, int B, int64_t T, int C, int elu, int prefix,
                     int im2col_k, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream);
 int ns2_seanet_unpad(const float* src, int64_t ld_src, int prefix, float* dst, int64_t ld_dst, int B, int64_t T, int C, void* stream);
-int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_hh, const float* b_hh, float* state, const float* resid,
-                   int64_t ld_r, float* out, int64_t ld_o, int B, int64_t T, int H, void* stream);
+int64_t ns2_lstm_state_floats(int B, int H);
+int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_hh, const float* b_hh, float* state, int64_t state_floats,
+                   const float* resid, int64_t ld_r, float* out, int64_t ld_o, int B, int64_t T, int H, void* stream);
 
 /* Range guard of precisions 2 and 4 (IEEE-half operands stop at 65504 / 57344; beyond, values are clamped: finite but
  * wrong).  Counts, on the CURRENT device, the conversions that met an out-of-range (or NaN) value since the last reset.

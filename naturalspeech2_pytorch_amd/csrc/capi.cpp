@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 104; }   // 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 105; }   // 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 2, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
   force_gemm_kernel(kernel);
@@ -230,15 +230,17 @@ extern "C" int ns2_seanet_unpad(const float* src, int64_t ld_src, int prefix, fl
   HIPRET(launch_seanet_unpad(src, (long)ld_src, prefix, dst, (long)ld_dst, B, (long)T, C, (hipStream_t)stream));
   return NS2_OK;
 }
-extern "C" int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_hh, const float* b_hh, float* state, const float* resid,
-                              int64_t ld_r, float* out, int64_t ld_o, int B, int64_t T, int H, void* stream) {
+extern "C" int64_t ns2_lstm_state_floats(int B, int H) { return (B > 0 && H > 0) ? (int64_t)lstm_state_floats(B, H) : 0; }
+extern "C" int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_hh, const float* b_hh, float* state, int64_t state_floats,
+                              const float* resid, int64_t ld_r, float* out, int64_t ld_o, int B, int64_t T, int H, void* stream) {
   ARGCHK(xproj && w_hh && b_hh && state && out, "ns2_lstm_layer: null pointer");
   ARGCHK(B > 0 && T > 0 && H > 0 && H <= 512 && (H % 4) == 0, "ns2_lstm_layer: hidden size must be a multiple of 4, at most 512");
-  float* h_a = state;                                  // caller-owned scratch: 3 * B * H floats (h ping, h pong, c)
+  ARGCHK(state_floats >= 3 * (int64_t)B * H, "ns2_lstm_layer: state scratch too small (ns2_lstm_state_floats)");
+  float* h_a = state;                                  // caller-owned scratch (h ping, h pong, c | h exchange + step barrier)
   float* h_b = state + (size_t)B * H;
   float* c = state + 2 * (size_t)B * H;
-  HIPRET(launch_lstm_layer(xproj, (long)ld_x, w_hh, b_hh, h_a, h_b, c, resid, (long)ld_r, out, (long)ld_o, B, (long)T, H,
-                           (hipStream_t)stream));
+  HIPRET(launch_lstm_layer(xproj, (long)ld_x, w_hh, b_hh, h_a, h_b, c, (long)state_floats, resid, (long)ld_r, out, (long)ld_o, B,
+                           (long)T, H, (hipStream_t)stream));
   return NS2_OK;
 }
 

@@ -570,7 +570,8 @@ hipError_t launch_seanet_unpad(const float* src, long ld_src, int prefix, float*
 // ---- LSTM (HFENC:253-266: nn.LSTM(dim, dim, num_layers), PyTorch gate order i, f, g, o).  The input projections of all time
 // steps are one GEMM; this kernel is ONE recurrent step of one layer:  gates = xproj[b, t] + h_prev[b] . W_hh^T + b_hh ;
 // c = sigma(f) c + sigma(i) tanh(g) ; h = sigma(o) tanh(c).  A workgroup owns 16 hidden units x 16 batch rows;
-// W_hh rows and h_prev come from L2 (the step is latency-bound: 2 x T dependent launches per utterance batch).
+// W_hh rows and h_prev come from L2 (the step is latency-bound: 2 x T dependent launches per utterance batch).  This is the
+// fallback (H != 512, B > 32, or a caller that passes only the minimal scratch); the persistent kernel below is the default.
 constexpr int LSTM_UNITS = 16;                    // hidden units per workgroup
 constexpr int LSTM_ROWS = 16;                     // batch rows per workgroup
 __global__ __launch_bounds__(256) void lstm_step_kernel(const float* xproj, long ld_x, long row_stride_t, long t, const float* w_hh,
@@ -610,10 +611,191 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* xproj, long
   h_next[sidx] = h;
   out[row * ld_o + j] = h + (resid ? resid[row * ld_r + j] : 0.f);
 }
+// ---- persistent recurrence: ONE launch per layer instead of T.  H = 512 only (EnCodec's LSTM width); 64 workgroups, each owning
+// 8 hidden units = 32 gate rows of W_hh, which live in REGISTERS for the whole sequence: thread (r = tid >> 3, kq = tid & 7)
+// holds row r's columns k = 4 kq + 32 i .. + 3 (i < 16).  Per step a workgroup stages h_{t-1} [B, 512] into LDS, every thread
+// forms its partial dot products for all batch rows, an 8-lane transpose-reduction leaves lane kq with the complete sums of
+// batch rows kq, kq + 8, .., the four gates of a unit meet through two lane exchanges, and the gate-0 lanes apply the cell
+// update (the cell state never leaves their registers).  Steps are separated by a device-wide barrier on a global counter.
+// The XCDs' L2s are not coherent with each other, so h travels through global memory with agent-scope (sc1) loads and stores
+// -- individually coherent accesses of the few KB that are shared -- instead of release / acquire fences, whose L2 write-back
+// and invalidate cost 10 us per step (measured: 16.6 us per step with fences).  The next step's input projections are
+// fetched before the barrier wait: they do not depend on the recurrence.
+constexpr int LP_UNITS = 8;
+constexpr int LP_LDH = 512 + 4;                   // LDS row stride of the staged h (floats)
+constexpr int LP_MAXB = 32;
+constexpr unsigned LP_SPIN_LIMIT = 1u << 26;      // ~ seconds: a lost workgroup turns into a trap, not a hang
+
+NS2_DEVINL float ld_agent(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+NS2_DEVINL float2 ld_agent2(const float* p) {       // 8-byte aligned
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+}
+NS2_DEVINL void st_agent(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int BG>                                 // batch rows in groups of 8: B <= 8 BG
+__global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* xproj, long ld_x, long T, const float* w_hh, const float* b_hh,
+                                                              float* hbuf, const float* resid, long ld_r, float* out, long ld_o, int B,
+                                                              unsigned* bar) {
+  constexpr int H = 512;
+  extern __shared__ __attribute__((aligned(16))) float s_h[];      // [8 BG][LP_LDH]
+  const int tid = threadIdx.x, kq = tid & 7, r = tid >> 3;
+  const int gate = r & 3, u = r >> 2;
+  const int j = blockIdx.x * LP_UNITS + u;                         // hidden unit
+  const unsigned nwg = gridDim.x;
+
+  float w[64];
+  {
+    const float* wr = w_hh + ((long)gate * H + j) * H + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(wr + 32 * i);
+      w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+  }
+  const float bias = b_hh[gate * H + j];
+  float c[BG], xp[BG];
+#pragma unroll
+  for (int g = 0; g < BG; ++g) {
+    c[g] = 0.f;
+    const int b = 8 * g + kq;
+    xp[g] = (b < B) ? xproj[((long)b * T) * ld_x + (long)gate * H + j] : 0.f;      // step 0's input projection
+  }
+
+  for (long t = 0; t < T; ++t) {
+    // ---- stage h_{t-1} (zeros at t = 0)
+    const float* hp = hbuf + (t & 1) * (long)LP_MAXB * H;
+#pragma unroll
+    for (int g = 0; g < BG; ++g) {                 // 8 rows x 512 floats = 2048 pairs: 8 per thread, all in flight together
+      float2 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = tid + 256 * q, b = 8 * g + (i >> 8), k = 2 * (i & 255);
+        v[q] = (t > 0 && b < B) ? ld_agent2(hp + (long)b * H + k) : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = tid + 256 * q, b = 8 * g + (i >> 8), k = 2 * (i & 255);
+        *reinterpret_cast<float2*>(s_h + b * LP_LDH + k) = v[q];
+      }
+    }
+    __syncthreads();
+    // ---- partial dot products over this thread's 64 columns, all batch rows
+    float acc[8 * BG];
+#pragma unroll
+    for (int b = 0; b < 8 * BG; ++b) {
+      float a0 = 0.f, a1 = 0.f;
+      if (b < B) {
+        const float* hb = s_h + b * LP_LDH + 4 * kq;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          const float4 h0 = *reinterpret_cast<const float4*>(hb + 32 * i);
+          const float4 h1 = *reinterpret_cast<const float4*>(hb + 32 * i + 32);
+          a0 = fmaf(w[4 * i], h0.x, a0); a0 = fmaf(w[4 * i + 1], h0.y, a0); a0 = fmaf(w[4 * i + 2], h0.z, a0); a0 = fmaf(w[4 * i + 3], h0.w, a0);
+          a1 = fmaf(w[4 * i + 4], h1.x, a1); a1 = fmaf(w[4 * i + 5], h1.y, a1); a1 = fmaf(w[4 * i + 6], h1.z, a1); a1 = fmaf(w[4 * i + 7], h1.w, a1);
+        }
+      }
+      acc[b] = a0 + a1;
+    }
+    __syncthreads();                               // s_h is free for the next step's staging
+    // ---- transpose-reduce over the 8 kq lanes: lane kq ends with the full sum of batch rows 8 g + kq
+    float pre[BG];
+#pragma unroll
+    for (int g = 0; g < BG; ++g) {
+      float v4[4], v2[2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float keep = (kq & 4) ? acc[8 * g + 4 + q] : acc[8 * g + q];
+        const float send = (kq & 4) ? acc[8 * g + q] : acc[8 * g + 4 + q];
+        v4[q] = keep + __shfl_xor(send, 4, 64);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float keep = (kq & 2) ? v4[2 + q] : v4[q];
+        const float send = (kq & 2) ? v4[q] : v4[2 + q];
+        v2[q] = keep + __shfl_xor(send, 2, 64);
+      }
+      const float keep = (kq & 1) ? v2[1] : v2[0];
+      const float send = (kq & 1) ? v2[0] : v2[1];
+      pre[g] = keep + __shfl_xor(send, 1, 64);
+    }
+    // ---- gates of unit u, batch row b = 8 g + kq: lanes tid ^ 8, ^ 16, ^ 24 hold the other three
+    float* hn = hbuf + ((t + 1) & 1) * (long)LP_MAXB * H;
+#pragma unroll
+    for (int g = 0; g < BG; ++g) {
+      const int b = 8 * g + kq;
+      const float x = pre[g] + bias + xp[g];
+      if (b < B && t + 1 < T) xp[g] = xproj[((long)b * T + t + 1) * ld_x + (long)gate * H + j];   // in flight across the barrier
+      const float x1 = __shfl_xor(x, 8, 64), x2 = __shfl_xor(x, 16, 64), x3 = __shfl_xor(x, 24, 64);
+      if (gate == 0 && b < B) {                    // x = i, x1 = f, x2 = g, x3 = o
+        const float ig = sigmoidf_acc(x), fg = sigmoidf_acc(x1), gg = tanhf(x2), og = sigmoidf_acc(x3);
+        c[g] = fg * c[g] + ig * gg;
+        const float h = og * tanhf(c[g]);
+        st_agent(hn + (long)b * H + j, h);
+        const long row = (long)b * T + t;
+        out[row * ld_o + j] = h + (resid ? resid[row * ld_r + j] : 0.f);
+      }
+    }
+    // ---- device-wide step barrier: every thread's h stores have completed (write-through) before its workgroup arrives
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = nwg * (unsigned)(t + 1);
+      unsigned spins = 0;
+      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > LP_SPIN_LIMIT) __builtin_trap();
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int BG>
+static hipError_t launch_lstm_persistent(const float* xproj, long ld_x, const float* w_hh, const float* b_hh, float* hbuf, unsigned* bar,
+                                         const float* resid, long ld_r, float* out, long ld_o, int B, long T, hipStream_t s) {
+  const size_t lds = (size_t)8 * BG * LP_LDH * sizeof(float);
+  static DynLdsAttr attr;
+  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&lstm_persistent_kernel<BG>), (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((lstm_persistent_kernel<BG>), dim3(512 / LP_UNITS), dim3(256), lds, s, xproj, ld_x, T, w_hh, b_hh, hbuf, resid, ld_r,
+                     out, ld_o, B, bar);
+  return hipGetLastError();
+}
+
+static bool lstm_persistent_enabled() {              // NS2_LSTM_PERSISTENT=0: the per-step kernel (A/B, tests of both paths)
+  static const bool on = [] { const char* e = getenv("NS2_LSTM_PERSISTENT"); return !(e && e[0] == '0'); }();
+  return on;
+}
+long lstm_state_floats(int B, int H) {
+  const long step = 3L * B * H, pers = 2L * LP_MAXB * 512 + 64;
+  return (H == 512 && B <= LP_MAXB) ? (step > pers ? step : pers) : step;
+}
 hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, const float* b_hh, float* h_a, float* h_b,
-                             float* c_state, const float* resid, long ld_r, float* out, long ld_o, int B, long T, int H,
-                             hipStream_t s) {
+                             float* c_state, long state_floats, const float* resid, long ld_r, float* out, long ld_o, int B,
+                             long T, int H, hipStream_t s) {
   if (B <= 0 || T <= 0 || H <= 0 || H > 512 || (H & 3)) return hipErrorInvalidValue;
+  if (H == 512 && B <= LP_MAXB && lstm_persistent_enabled()) {
+    // the persistent kernel needs 2 x 32 x 512 floats of h exchange + the barrier counter: the caller's scratch is
+    // 3 x B x H floats (h_a, h_b, c contiguous, include/ns2hip.h), enough only from B >= 22 on -- smaller batches take the step kernel
+    // unless the caller handed over the larger scratch (state_floats)
+    if (state_floats >= 2L * LP_MAXB * 512 + 64) {
+      float* hbuf = h_a;
+      unsigned* bar = reinterpret_cast<unsigned*>(h_a + 2L * LP_MAXB * 512);
+      hipError_t e = hipMemsetAsync(bar, 0, 64 * sizeof(float), s);
+      if (e != hipSuccess) return e;
+      switch ((B + 7) / 8) {
+        case 1: return launch_lstm_persistent<1>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s);
+        case 2: return launch_lstm_persistent<2>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s);
+        case 3: return launch_lstm_persistent<3>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s);
+        default: return launch_lstm_persistent<4>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s);
+      }
+    }
+  }
   hipError_t e = hipMemsetAsync(h_a, 0, (size_t)B * H * sizeof(float), s);
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(c_state, 0, (size_t)B * H * sizeof(float), s);

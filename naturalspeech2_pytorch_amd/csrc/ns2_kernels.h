@@ -167,9 +167,10 @@ struct RvqArgs {
 hipError_t launch_seanet_prep(const float* x, int ldx, int in_prefix, const float* add, int ldadd, int B, long T, int C, int elu,
                               int prefix, int im2col_k, bf16_t* out_hi, bf16_t* out_lo, int ldo, int fmt, hipStream_t s);
 hipError_t launch_seanet_unpad(const float* src, long ld_src, int prefix, float* dst, long ld_dst, int B, long T, int C, hipStream_t s);
+long lstm_state_floats(int B, int H);     // caller scratch of launch_lstm_layer (h exchange, cell state / barrier counter)
 hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, const float* b_hh, float* h_a, float* h_b,
-                             float* c_state, const float* resid, long ld_r, float* out, long ld_o, int B, long T, int H,
-                             hipStream_t s);
+                             float* c_state, long state_floats, const float* resid, long ld_r, float* out, long ld_o, int B,
+                             long T, int H, hipStream_t s);
 
 // values that left the IEEE-half range in this translation unit's kernels since the last reset (synchronising reads)
 unsigned int saturation_read_gemm(bool reset);

@@ -319,17 +319,18 @@ def rvq_prepare(codebooks: torch.Tensor) -> torch.Tensor:
 
 
 def rvq_encode(x: torch.Tensor, codebooks: torch.Tensor, cb_norm: Optional[torch.Tensor] = None, tie_eps: float = 1e-4,
-               want_residual=False, count_ties=False):
-    """x [M, 128] fp32, codebooks [Q, C, 128] -> codes [M, Q] int64, emb [M, 128] (, residual, n_near_ties)."""
+               want_residual=False, count_ties=False, want_emb=True):
+    """x [M, 128] fp32, codebooks [Q, C, 128] -> codes [M, Q] int64, emb [M, 128] (, residual, n_near_ties).
+    want_emb=False skips the decode launch that sums the selected code vectors (emb is returned as None)."""
     x, cb = _f32(x), _f32(codebooks)
     M, D = x.shape
     Q, C, _ = cb.shape
     cb_norm = rvq_prepare(cb) if cb_norm is None else cb_norm
     codes = torch.empty(M, Q, dtype=torch.int64, device=x.device)
-    emb = torch.empty(M, D, dtype=torch.float32, device=x.device)
+    emb = torch.empty(M, D, dtype=torch.float32, device=x.device) if want_emb else None
     resid = torch.empty(M, D, dtype=torch.float32, device=x.device) if want_residual else None
     ties = torch.zeros(1, dtype=torch.int32, device=x.device) if count_ties else None
-    check(_lib.load().ns2_rvq_encode(x.data_ptr(), cb.data_ptr(), cb_norm.data_ptr(), codes.data_ptr(), emb.data_ptr(), _p(resid),
+    check(_lib.load().ns2_rvq_encode(x.data_ptr(), cb.data_ptr(), cb_norm.data_ptr(), codes.data_ptr(), _p(emb), _p(resid),
                                      _p(ties), M, Q, C, D, float(tie_eps), _stream()), "ns2_rvq_encode")
     res = [codes, emb]
     if want_residual:

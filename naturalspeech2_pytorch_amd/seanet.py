@@ -191,14 +191,15 @@ class _SEANetHIP(nn.Module):
         B, T, H = a.B, a.T, p["H"]
         lib = _lib.load()
         x = a.x
-        state = torch.empty(3 * B * H, dtype=torch.float32, device=x.device)
+        nstate = int(lib.ns2_lstm_state_floats(B, H))
+        state = torch.empty(nstate, dtype=torch.float32, device=x.device)
         for i, l in enumerate(p["layers"]):
             pl = _prep(x, B, T, H, precision=prec)
             xproj = ops.linear_f32(l["w_ih"], pl, bias=l["b_ih"], precision=prec)                       # [B T, 4H]
             out = torch.empty(B * T, H, dtype=torch.float32, device=x.device)
             last = i + 1 == len(p["layers"])
             resid = a.x if last else None                                                                 # HFENC:264: lstm(x) + x
-            check(lib.ns2_lstm_layer(xproj.data_ptr(), 4 * H, l["w_hh"].data_ptr(), l["b_hh"].data_ptr(), state.data_ptr(),
+            check(lib.ns2_lstm_layer(xproj.data_ptr(), 4 * H, l["w_hh"].data_ptr(), l["b_hh"].data_ptr(), state.data_ptr(), nstate,
                                      ops._p(resid), H, out.data_ptr(), H, B, T, H, _stream()), "ns2_lstm_layer")
             x = out
         return _Act(x, B, T, H, 0)

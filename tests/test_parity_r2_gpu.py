@@ -32,6 +32,7 @@ TOL = 1e-3                                  # BASELINE.json north_star: <= 1e-3 
 CEIL = {"exact": 1e-4, "mixed": 2.5e-4, "hybrid": 2.5e-4, "half": TOL}
 _SWEEP_REF = {}                            # oracle outputs of the sweep, shared by the precision parametrisations
 REPORT = {}
+F_linear = torch.nn.functional.linear
 
 
 def record(key, value):
@@ -432,9 +433,36 @@ def test_seanet_pieces():
         out = torch.empty(60, 64, device=DEV)
         from naturalspeech2_pytorch_amd import _lib
         _lib.check(_lib.load().ns2_lstm_layer(xproj.data_ptr(), 256, lstm.weight_hh_l0.data_ptr(), lstm.bias_hh_l0.data_ptr(),
-                                              state.data_ptr(), xin.reshape(60, 64).data_ptr(), 64, out.data_ptr(), 64, 3, 20, 64,
+                                              state.data_ptr(), state.numel(), xin.reshape(60, 64).data_ptr(), 64, out.data_ptr(), 64, 3, 20, 64,
                                               torch.cuda.current_stream().cuda_stream), "lstm")
     assert rel(out.reshape(3, 20, 64), ref) < 1e-5
+
+
+@pytest.mark.parametrize("B", [1, 5, 8, 19, 32])
+def test_lstm_persistent_recurrence(B):
+    """EnCodec's LSTM width (H = 512): the one-launch persistent recurrence (device-wide step barrier) against torch.nn.LSTM and
+    against the per-step kernel (the same entry point with only the minimal scratch), ragged batch sizes across the 8-row groups"""
+    from naturalspeech2_pytorch_amd import _lib
+    lib = _lib.load()
+    H, T = 512, 37
+    torch.manual_seed(B)
+    lstm = torch.nn.LSTM(H, H, 1).to(DEV)
+    xin = make_input("xl", (B, T, H), seed=96 + B).to(DEV)
+    with torch.no_grad():
+        ref = lstm(xin.transpose(0, 1))[0].transpose(0, 1) + xin
+        xproj = F_linear(xin.reshape(B * T, H), lstm.weight_ih_l0, lstm.bias_ih_l0).contiguous()
+    outs = []
+    for nstate in (int(lib.ns2_lstm_state_floats(B, H)), 3 * B * H):
+        state = torch.empty(nstate, device=DEV)
+        out = torch.full((B * T, H), float("nan"), device=DEV)
+        _lib.check(lib.ns2_lstm_layer(xproj.data_ptr(), 4 * H, lstm.weight_hh_l0.data_ptr(), lstm.bias_hh_l0.data_ptr(), state.data_ptr(), nstate,
+                                      xin.reshape(B * T, H).data_ptr(), H, out.data_ptr(), H, B, T, H,
+                                      torch.cuda.current_stream().cuda_stream), "lstm")
+        torch.cuda.synchronize()
+        outs.append(out.reshape(B, T, H))
+        assert rel(outs[-1], ref) < 1e-5, f"scratch {nstate}: {rel(outs[-1], ref)}"
+    if int(lib.ns2_lstm_state_floats(B, H)) > 3 * B * H:            # the two calls really took different kernels
+        assert rel(outs[0], outs[1]) < 1e-5
 
 
 def test_encodec_wrapper_with_hf_seanet():
