@@ -91,7 +91,9 @@ int ns2_linear_qkv(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_
                    int split_col, uint16_t* out_hi, uint16_t* out_lo, int ldo, uint16_t* vt_hi, uint16_t* vt_lo,
                    int vt_ld, int precision, void* stream);
 /* WavenetResBlock (NS2:597-642) in one launch: out = tanh(g)*sigmoid(g) + res_conv(x), g = conv_dil(x)*gamma_t+beta_t.
- * w packed with taps=3 and extra1x1 = res_conv.weight; film[b] = [gamma(dim) | beta(dim)] = to_time_cond(t) */
+ * w packed with taps=3 and extra1x1 = res_conv.weight; film[b] = [gamma(dim) | beta(dim)] = to_time_cond(t).
+ * precision 5 (this entry point only): precision-4 operands and weight; the dilated conv multiplies their IEEE-half parts as
+ * one product, res_conv keeps the fp8 correction terms (what model precision 5 runs; outputs wider than 128 columns) */
 int ns2_wavenet_block(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int seq_len,
                       int dilation, const float* conv_bias, const float* res_bias, const float* film, int film_ld,
                       uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream);

@@ -139,11 +139,14 @@ extern "C" int ns2_linear_qkv(const ns2_weight* w, const uint16_t* a_hi, const u
 extern "C" int ns2_wavenet_block(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int seq_len,
                                  int dilation, const float* conv_bias, const float* res_bias, const float* film, int film_ld,
                                  uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream) {
+  // precision 5 (this entry point only) = precision 4 operands, the dilated conv as one half product, res_conv with the correction terms
+  const int p1_half = precision == 5;
+  if (p1_half) precision = 4;
   ARGCHK(w && a_hi && out_hi && conv_bias && res_bias && film && prec_ok(precision), "ns2_wavenet_block: bad arguments");
   WFMT(w, precision, "ns2_wavenet_block");
   ARGCHK(w->taps == 3 && w->has_extra && seq_len > 0, "ns2_wavenet_block: weight must be packed with taps=3 and extra1x1");
   return gemm_wavenet(w->w, a_hi, a_lo, lda, 0, M, seq_len, dilation, 0, 1, conv_bias, res_bias, 0, film, film_ld, 0, out_hi, out_lo,
-                      ldo, 0, ldo, precision, (hipStream_t)stream);
+                      ldo, 0, ldo, precision, (hipStream_t)stream, p1_half);
 }
 
 extern "C" int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi,

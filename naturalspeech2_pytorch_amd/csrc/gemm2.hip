@@ -43,21 +43,32 @@ __device__ unsigned long long g2_trace[8 * 64 * 10];
 // exists once per device and needs no host-side allocation or bookkeeping (the library keeps no mutable host state).
 __device__ __attribute__((aligned(256))) bf16_t g2_zero_page[128];
 
-template <int NSPLIT, int EPI, bool F16>
+// arithmetic of a K range.  NS: 3 = bf16 hi/lo planes, three products; 1 = one 16-bit product (bf16 or IEEE half); 2 = FMT_H8
+// "mixed": one half product + both correction terms in one fp8 MFMA per 32-deep k block (ns2_common.h)
+template <int NS>
+struct KMode {
+  static constexpr int ns = NS;
+  static constexpr int np = (NS == 3) ? 2 : 1;           // 16-bit planes per operand (both inside one 128-B LDS row in exact mode)
+  static constexpr bool line32 = NS != 1;                // a K tile is one interleaved 128-B line per row: 32 logical columns
+  static constexpr int bk = line32 ? 32 : 64;            // K-tile depth (logical elements)
+  static constexpr int kch = bk / 16;                    // 16-deep MFMA K chunks per tile (2 / 4)
+};
+
+// P1 != 0 (EPI_WAVENET only): the first K phase -- the dilated conv taps -- runs in arithmetic P1 instead of NSPLIT, reading
+// the SAME operands: P1 = 1 under NSPLIT = 2 multiplies the IEEE-half parts of the FMT_H8 lines as one product per
+// contraction (64-deep tiles gathered from two lines), the second phase (res_conv) keeps the correction terms.
+template <int NSPLIT, int EPI, bool F16, int P1 = 0>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const bf16_t* zero_page = g2_zero_page;
-  // NSPLIT: 3 = bf16 hi/lo planes, three products; 1 = one 16-bit product (bf16 or, F16, IEEE half); 2 = FMT_H8 "mixed":
-  // one half product + both correction terms in one fp8 MFMA per 32-deep k block (ns2_common.h)
   static_assert(NSPLIT != 2 || F16, "the mixed mode multiplies IEEE-half operands");
-  constexpr int NP = (NSPLIT == 3) ? 2 : 1;          // 16-bit planes per operand (both inside one 128-B LDS row in exact mode)
-  constexpr bool LINE32 = NSPLIT != 1;               // a K tile is one interleaved 128-B line per row: 32 logical columns
-  constexpr int BK = LINE32 ? 32 : 64;               // K-tile depth (logical elements)
+  static_assert(P1 == 0 || (EPI == EPI_WAVENET && P1 == 1 && NSPLIT == 2), "phase-1 override: half product under the mixed mode");
+  using ModeMain = KMode<NSPLIT>;
+  using ModeP1 = KMode<P1 ? P1 : NSPLIT>;
   constexpr int RB = 128;                            // LDS row bytes: [hi32|lo32] (exact), [half32|h8 32|l8 32] (mixed) or hi64
   constexpr int CPR = RB / 16;                       // 16-B chunks per row (8)
   constexpr int RPI = 64 / CPR;                      // tile rows moved by one DMA wave-instruction (8)
   constexpr int REGION = G2_BM * RB;                 // one operand of one K tile: 32 KiB
   constexpr int STAGE = 2 * REGION;                  // 64 KiB
-  constexpr int KCH = BK / 16;                       // 16-deep MFMA K chunks per tile (2 / 4)
   constexpr int IPO = G2_BM / RPI;                   // DMA instructions per operand (32)
   static_assert(2 * IPO == 64, "8 waves x 8 DMA instructions per K-tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -88,26 +99,24 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   // ---- DMA roles: instruction j = (wave&3)*8 + i of the operand; waves 0-3 stream A, waves 4-7 stream W
   const bool a_wave = wave < 4;
   const int lrow = lane / CPR, pchunk = lane % CPR;
-  const bf16_t* src[8];        // per-instruction source pointer at K offset 0 (A: unshifted row)
+  const bf16_t* src[8];        // per-instruction source ROW pointer at K offset 0 (A: unshifted row), without the chunk offset
   int nseq[8];                 // A only: position inside the utterance (for the causal zero fill); -1 = row >= M
   int ldst[8];                 // LDS byte offset inside a stage (wave-uniform)
-  bool lchunk_hi[8];           // fast mode: this lane fetches one of the upper 32 columns of a 64-deep tile
+  // logical 16-B chunk this lane fetches: pchunk ^ swizzle(row); row = 8 rg + lrow and rg = 8 (wave & 3) + i, so the
+  // swizzle (row >> 1) & 7 = 4 (i & 1) + (lrow >> 1) takes two values per lane, for even and odd i
+  const int lchunk_par[2] = {pchunk ^ (lrow >> 1), pchunk ^ (4 + (lrow >> 1))};
+  const bool opil = a_wave ? ail : wil;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int rg = (wave & 3) * 8 + i;               // row group inside the operand: [0, IPO)
     const int row = rg * RPI + lrow;                 // tile row
-    const int lchunk = pchunk ^ ((row >> 1) & 7);    // logical 16-B chunk this lane fetches
     ldst[i] = (a_wave ? 0 : REGION) + rg * 1024;
-    lchunk_hi[i] = lchunk >= 4;
     if (a_wave) {
       const long m = (long)tm * G2_BM + row;
-      // exact: chunk c of the line = 8 elements at c*8 (hi chunks 0-3, lo chunks 4-7); fast: logical column c*8
-      const int coff = LINE32 ? lchunk * 8 : pcol(lchunk * 8, ail);
-      src[i] = g.a_hi + pcol((int)(z * g.a_zs), ail) + m * a_rs + coff;
+      src[i] = g.a_hi + pcol((int)(z * g.a_zs), ail) + m * a_rs;
       nseq[i] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -1;
     } else {
-      const int coff = LINE32 ? lchunk * 8 : pcol(lchunk * 8, wil);
-      src[i] = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN + row) * w_rs + coff;
+      src[i] = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN + row) * w_rs;
       nseq[i] = 0;
     }
   }
@@ -115,14 +124,15 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   // K tiling in BK units: every tap spans tpt tiles; with BK = 64 an odd 32-multiple tap ends in a half tile whose
   // upper 32 columns are zero-filled (A and W lanes of those chunks read the zero page)
   const int tap_k = g.kt_per_tap * 32;                        // logical elements per tap
-  const int tpt = (tap_k + BK - 1) / BK;
-  const bool half_tail = !LINE32 && (g.kt_per_tap & 1);
   const int ntaps = g.nkt / g.kt_per_tap;
-  const int ntiles = ntaps * tpt;
-  const int mid_tile = (g.mid_kt > 0) ? (g.mid_kt / g.kt_per_tap) * tpt : 0;
-  const int nconv = g.conv_taps * tpt;                        // tiles of the row-shifted taps (come first)
+  auto tiles_per_tap = [&](auto mode) { return (tap_k + decltype(mode)::bk - 1) / decltype(mode)::bk; };
 
-  auto issue_tile = [&](int kt, int stage) {
+  auto issue_tile = [&](auto mode, int kt, int stage) {
+    using M = decltype(mode);
+    constexpr int BK = M::bk;
+    const int tpt = tiles_per_tap(mode);
+    const bool half_tail = !M::line32 && (g.kt_per_tap & 1);
+    const int nconv = g.conv_taps * tpt;                      // tiles of the row-shifted taps (come first)
     unsigned char* sbase = smem + stage * STAGE;
     // K order: the shifted conv taps are visited tap-minor (k chunk 0: taps 0..T-1, k chunk 1: ...).  Consecutive taps
     // read the same A lines shifted by `dil` rows, so every re-read comes straight after the first touch and hits L2;
@@ -131,6 +141,15 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     if (kt < nconv) { it = kt / g.conv_taps; tap = kt - it * g.conv_taps; }
     else { tap = kt / tpt; it = kt - tap * tpt; }
     const bool half = half_tail && (it == tpt - 1);
+    // chunk offset inside the tile (elements): a line32 tile is ONE 128-B line, chunk c = 8 elements at c * 8 (hi chunks
+    // 0-3, lo / fp8 chunks 4-7); a 64-deep tile of one plane takes logical columns c * 8 of either operand layout
+    int coff[2];
+    bool chi[2];                                              // (64-deep tiles) this lane fetches one of the upper 32 columns
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      coff[e] = M::line32 ? lchunk_par[e] * 8 : pcol(lchunk_par[e] * 8, opil);
+      chi[e] = lchunk_par[e] >= 4;
+    }
     if (a_wave) {
       const int pl = g.pad_left < 0 ? g.conv_taps - 1 : g.pad_left;      // causal: all padding on the left (NS2:583-595)
       const int shift = (tap < g.conv_taps) ? (pl - tap) * dil : 0;
@@ -138,15 +157,15 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       const long off = pcol(it * BK, ail) - (long)shift * a_rs;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const bool ok = ((unsigned)(nseq[i] - shift) < slim) && !(half && lchunk_hi[i]);   // nseq = -1 marks rows >= M
-        const bf16_t* p = ok ? (src[i] + off) : zero_page;
+        const bool ok = ((unsigned)(nseq[i] - shift) < slim) && !(half && chi[i & 1]);   // nseq = -1 marks rows >= M
+        const bf16_t* p = ok ? (src[i] + off + coff[i & 1]) : zero_page;
         glds16(p, sbase + ldst[i]);
       }
     } else {
       const long off = pcol(tap * tap_k + it * BK, wil);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const bf16_t* p = (half && lchunk_hi[i]) ? zero_page : (src[i] + off);
+        const bf16_t* p = (half && chi[i & 1]) ? zero_page : (src[i] + off + coff[i & 1]);
         glds16(p, sbase + ldst[i]);
       }
     }
@@ -172,8 +191,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const int a_row_off = (wm * 128 + l31) * RB;
   const int w_row_off = REGION + (wn * 64 + l31) * RB;
 
-  auto run_k = [&](const int kt0, const int kt1) {
-    issue_tile(kt0, kt0 & 1);
+  auto run_k = [&](auto mode, const int kt0, const int kt1) {
+    using M = decltype(mode);
+    constexpr int NS = M::ns, NP = M::np, KCH = M::kch;
+    issue_tile(mode, kt0, kt0 & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                  // tile kt0 landed for every wave
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -185,11 +206,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       // Anti-phase DMA issue: an LDS-DMA instruction blocks its wave for ~60-180 clocks at issue.  The A-streaming
       // waves 0-3 (one per SIMD) issue theirs now, while their SIMD partners 4-7 already run MFMAs; waves 4-7 issue
       // the W half after their first K step, when waves 0-3 are in their MFMA phase (measured +5 % on the FF conv).
-      if (kt + 1 < kt1 && a_wave) issue_tile(kt + 1, (kt + 1) & 1);
+      if (kt + 1 < kt1 && a_wave) issue_tile(mode, kt + 1, (kt + 1) & 1);
       STAMP(1);
       const unsigned char* sb = smem + (kt & 1) * STAGE;
       if (wave_active) {
-      if constexpr (NSPLIT == 2) {
+      if constexpr (NS == 2) {
         // mixed mode: per 32-deep tile 2 x (4x2) half MFMAs + (4x2) fp8 MFMAs of K = 64.  fp8 operands of lane (l31, hi):
         // A = 32 bytes [h8 | l8][hi] of row l31 (chunks 4+2hi, 5+2hi of the line), B = [l8 | h8][hi] (chunks 6-2hi, 7-2hi):
         // lanes 0-31 contribute a_h8 . w_l8, lanes 32-63 a_l8 . w_h8; every product carries exactly one 2^12-scaled factor,
@@ -227,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
             acc[mi][ni] = mma16<true>(af[0][mi], wf[0][ni], acc[mi][ni]);
             acc[mi][ni] = mma16<true>(af[1][mi], wf[1][ni], acc[mi][ni]);
           }
-        if (kt + 1 < kt1 && !a_wave) issue_tile(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < kt1 && !a_wave) issue_tile(mode, kt + 1, (kt + 1) & 1);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -255,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
-            if constexpr (NSPLIT == 3) {
+            if constexpr (NS == 3) {
               acc[mi][ni] = mma16<F16>(af[1][mi], wf[0][ni], acc[mi][ni]);
               acc[mi][ni] = mma16<F16>(af[0][mi], wf[1][ni], acc[mi][ni]);
             }
@@ -264,14 +285,14 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
 #ifdef G2_TRACE
         if (kc == 0) STAMP(3); else if (kc == 1) STAMP(6);
 #endif
-        if (kc == 0 && kt + 1 < kt1 && !a_wave) issue_tile(kt + 1, (kt + 1) & 1);
+        if (kc == 0 && kt + 1 < kt1 && !a_wave) issue_tile(mode, kt + 1, (kt + 1) & 1);
 #ifdef G2_TRACE
         if (kc == 0) STAMP(4);
 #endif
       }
       }
       } else if (kt + 1 < kt1 && !a_wave) {
-        issue_tile(kt + 1, (kt + 1) & 1);
+        issue_tile(mode, kt + 1, (kt + 1) & 1);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile has landed
       STAMP(7);
@@ -287,11 +308,13 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   };
 
   if constexpr (EPI == EPI_WAVENET) {
-    run_k(0, mid_tile);
+    // phase 1: the taps before mid_kt (dilated conv), phase 2: the rest (res_conv on the unshifted input)
+    const int mid_tap = (g.mid_kt > 0) ? g.mid_kt / g.kt_per_tap : 0;
+    run_k(ModeP1{}, 0, mid_tap * tiles_per_tap(ModeP1{}));
     wavenet_midgate<4, 2>(acc, g, z, row_base, col_base, l31, hi);
-    run_k(mid_tile, ntiles);
+    run_k(ModeMain{}, mid_tap * tiles_per_tap(ModeMain{}), ntaps * tiles_per_tap(ModeMain{}));
   } else {
-    run_k(0, ntiles);
+    run_k(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
   }
   if (!wave_active) return;
   // all waves are past the K loop's last barrier: the LDS ring is free, every wave takes a private 18 KiB region
@@ -310,15 +333,15 @@ extern "C" int ns2_debug_read_trace(unsigned long long* out) {
 }
 #endif
 
-template <int NSPLIT, int EPI, bool F16>
+template <int NSPLIT, int EPI, bool F16, int P1 = 0>
 static hipError_t launch2_one(const GemmArgs& g, hipStream_t s) {
   const int ntn = (g.N + G2_BN - 1) / G2_BN, ntm = (g.M + G2_BM - 1) / G2_BM;
   const int nz = g.nz > 0 ? g.nz : 1;
   const size_t lds = 8 * EPI_LDS_WAVE_BYTES;          // 144 KiB: 2 x 64 KiB K stages, reused as 8 x 18 KiB epilogue regions
   static DynLdsAttr attr;
-  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, F16>), (int)lds);
+  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, F16, P1>), (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, F16>), dim3(ntn * ntm * nz), dim3(512), lds, s, g);
+  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, F16, P1>), dim3(ntn * ntm * nz), dim3(512), lds, s, g);
   return hipGetLastError();
 }
 
@@ -329,7 +352,9 @@ static hipError_t launch2_epi(const GemmArgs& g, hipStream_t s) {
     case EPI_SPLIT: return launch2_one<NSPLIT, EPI_SPLIT, F16>(g, s);
     case EPI_QKV: return launch2_one<NSPLIT, EPI_QKV, F16>(g, s);
     case EPI_GEGLU: return launch2_one<NSPLIT, EPI_GEGLU, F16>(g, s);
-    case EPI_WAVENET: return launch2_one<NSPLIT, EPI_WAVENET, F16>(g, s);
+    case EPI_WAVENET:
+      if constexpr (NSPLIT == 2) { if (g.p1_half) return launch2_one<2, EPI_WAVENET, true, 1>(g, s); }
+      return launch2_one<NSPLIT, EPI_WAVENET, F16>(g, s);
   }
   return hipErrorInvalidValue;
 }

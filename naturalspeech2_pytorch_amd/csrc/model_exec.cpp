@@ -101,9 +101,11 @@ static int dev_alloc(std::vector<void*>* owned, void** p, size_t bytes) {
 // [hi32|lo32] rows with a lo plane (exact models and ns2_weight_pack) or dense hi-only rows (precision-1 "fast" models).
 struct PackCtx { std::vector<void*>* owned; bool il; int fmt; };   // il: interleaved 128-B lines (bf16 hi/lo or FMT_H8); fmt: PlaneFmt
 // Model precision 5 ("hybrid") is a per-site plan on top of precision 4: every contraction keeps the fp8 correction terms
-// except the feed-forward causal conv (45 % of the FLOPs), which runs as ONE IEEE-half product: its input arrives as dense
-// half planes from the GEGLU epilogue and it writes FMT_H8 lines for FF-out.  (tools/precision_study.py: of all sites this
-// is the one whose rounding error reaches the output least.)
+// except (a) the feed-forward causal conv (43 % of the FLOPs), which runs as ONE IEEE-half product: its input arrives as dense
+// half planes from the GEGLU epilogue and it writes FMT_H8 lines for FF-out; (b) the dilated k = 3 convs of the Wavenet
+// blocks (16 % of the FLOPs), which multiply the half parts of the same FMT_H8 operands as one product while the block's
+// res_conv keeps the correction terms (gemm2.hip, P1).  tools/precision_study.py: these are the two sites whose rounding
+// error reaches the output least (4.1e-5 -> 9.4e-5 for both at d128; every other site costs 1.6e-4 ... 3.5e-4).
 static inline int op_precision(int model_precision) { return model_precision == 5 ? 4 : model_precision; }
 static inline bool ffconv_half(int model_precision) { return model_precision == 5; }
 // The step-invariant conditioning (ns2_model_prepare_cond: perceiver resampler, cond_to_model_dim, per-layer cross-attention
@@ -257,9 +259,10 @@ int gemm_qkv(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, 
 }
 int gemm_wavenet(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, long a_zs, int M, int seq_len, int dil,
                  int dil_z, int nz, const float* b_conv, const float* b_res, long bias_zs, const float* film, int film_ld,
-                 long film_zs, bf16_t* o_hi, bf16_t* o_lo, int ldo, long out_zs, int out_ncols, int prec, hipStream_t s) {
+                 long film_zs, bf16_t* o_hi, bf16_t* o_lo, int ldo, long out_zs, int out_ncols, int prec, hipStream_t s, int p1_half) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
   set_conv(g, w, 3, dil, seq_len);
+  g.p1_half = (prec == 4) ? p1_half : 0;
   g.dil_z = dil_z; g.nz = nz; g.a_zs = a_zs; g.w_zs = (long)w.rows_p * w.ldk; g.bias_zs = bias_zs; g.film_zs = film_zs;
   g.out_zs = out_zs;
   g.mid_kt = 3 * w.kt_per_tap;
@@ -821,7 +824,8 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
     const int lda = (st == 0) ? dp : L * dp;
     const long a_zs = (st == 0) ? 0 : dp;
     PROF(PC_GEMM_WAVENET, gemm_wavenet(m->w_wn[st], a_hi, a_lo, lda, a_zs, M, N, /*dil=*/1, /*dil_z=*/1, /*nz=*/L, m->b_wn_conv[st], m->b_wn_res[st],
-                       dim, w.condall + (size_t)st * L * 2 * dim, Jtot, 2 * dim, cur.hi, cur.lo, L * dp, dp, dp, prec, s));
+                       dim, w.condall + (size_t)st * L * 2 * dim, Jtot, 2 * dim, cur.hi, cur.lo, L * dp, dp, dp, prec, s,
+                       /*p1_half=*/ffconv_half(m->cfg.precision) ? 1 : 0));
     snprintf(name, sizeof name, "wavenet.stack%d", st);
     NSCHK(tap_planes(m, name, cur, L * dp, M, L * dp, s));
     Planes tmp = prev; prev = cur; cur = tmp;

@@ -208,7 +208,7 @@ def wavenet_block(w: PackedWeight, a: Planes, seq_len: int, dilation: int, conv_
                   precision=3) -> Planes:
     M = a.rows
     ldo = round_up(w.rows, 32)
-    out = _out_planes(M, ldo, a.device, precision)
+    out = _out_planes(M, ldo, a.device, 4 if precision == 5 else precision)      # 5: precision-4 planes, dilated conv as one half product
     check(_lib.load().ns2_wavenet_block(w.handle, a.hi, a.lo, a.ld, M, seq_len, dilation, conv_bias.data_ptr(),
                                         res_bias.data_ptr(), _f32(film).data_ptr(), film.shape[1], out.hi,
                                         out.lo, ldo, precision, _stream()), "ns2_wavenet_block")

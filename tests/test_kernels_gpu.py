@@ -208,6 +208,12 @@ def test_wavenet_block(B, N, C, dil, prec, gemm_kernel):
     ref = (h + conv_ref(xe, wr, br, 1)).reshape(B * N, C)          # NS2:627-636
     e = rel(ops.join(out, C), ref)
     assert e < TOL[prec] + (5e-4 if prec == 2 else 1e-5), f"rel err {e}"
+    if prec == 4:      # the hybrid plan's block: same operands, dilated conv as ONE half product, res_conv with the correction terms
+        out5 = ops.wavenet_block(pw, a, N, dil, bc, br, film, precision=5)
+        e5 = rel(ops.join(out5, C), ref)
+        assert e5 < TOL[2] + 5e-4, f"rel err {e5}"
+        if gemm_kernel == 2:                   # the 256x256 kernel really took the half-product phase
+            assert e5 > 2 * e, (e5, e)
 
 
 def attn_ref(q, k, v, scale):

@@ -201,6 +201,32 @@ def test_large_activation_stress():
     NaturalSpeech2(ex_model, codec=None, target_sample_hz=24000, timesteps=2).sample(length=256, batch_size=2, noise=noise)
 
 
+def test_hybrid_plan_with_amplified_ff_branch():
+    """The hybrid plan drops the correction terms of the FF causal conv and of the Wavenet's dilated convs.  At random init the FF
+    branch is dominated by its biases and hides its own rounding, so the plan is also checked with every FF-in weight x6 (GEGLU
+    output x36: the branch's data term dominates, like a trained branch that carries signal): it must keep a >= 2x margin there
+    (tools/precision_study.py --scale-ffin 6 predicts 2.3e-4 for hybrid, 4.8e-5 for mixed, 7.2e-4 for half)."""
+    kw = dict(dim=128, depth=6)
+    x = make_input("x", (2, 256, 128), seed=51)
+    t = torch.tensor([0.2, 0.8])
+    out = {}
+    for precision in ("mixed", "hybrid", "half"):
+        m = Model(**kw, precision=precision)
+        sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=50)
+        for k, v in sd.items():
+            if v.ndim == 2 and v.shape[1] == 128 and v.shape[0] != 128 and v.shape[0] % 64 != 0:      # FF-in [2 * inner, dim]
+                sd[k] = v * 6.0
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        with torch.no_grad():
+            y = m(x.to(DEV), t.to(DEV))
+            ref = O.model_forward(sd, x, t)
+        out[precision] = rel(y, ref)
+    record("ff_branch_x6_d128_L6", out)
+    print("FF-in x6:", {k: f"{v:.2e}" for k, v in out.items()})
+    assert out["mixed"] < 2.5e-4 and out["hybrid"] < 5e-4 and out["half"] < 2e-3, out
+
+
 def test_half_conversion_saturates():
     x = torch.tensor([[1e6, -1e6, 65504.0, 7e4] + [0.0] * 28], device=DEV)
     h = ops.join(ops.split(x, precision=2))[0, :4].tolist()

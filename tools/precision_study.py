@@ -47,17 +47,24 @@ class Scheme:
         self.site_fn = None                     # optional: (kind, weight shape) -> contraction fn, overrides fn / resid_fn
 
 def per_site(name, units, default, **sites):
-    """sites: ffconv / ffin / ffout / qkv / attnout / wavenet -> fn (classified by the weight's shape)"""
+    """sites: ffconv / ffin / ffout / qkv / attnout / wavenet (all Wavenet convs) or wavenet3 (dilated k = 3 convs + init conv)
+    / wavenet1 (1x1 res / skip / final convs) -> fn (classified by the weight's shape)"""
     sc = Scheme(name, units, default, mk(FH, [(0, 0)]))
     def pick(kind, ws):
         if kind == "conv":
             site = "wavenet" if ws[0] in (DIM, 2 * DIM) or ws[1] == DIM else "ffconv"
-        elif ws[1] == DIM:
-            site = "ffin" if ws[0] > 3 * DIM else "qkv"
-        elif ws[0] == DIM:
-            site = "ffout" if ws[1] > DIM else "attnout"
+            if site == "wavenet" and "wavenet" not in sites:
+                site = "wavenet3" if ws[2] == 3 else "wavenet1"
+        elif ws[1] == DIM and ws[0] % 64 == 0 and ws[0] != DIM:
+            site = "qkv"                                   # to_q [512, dim] / to_kv [1024, dim] (8 heads x 64)
+        elif ws[1] == DIM and ws[0] != DIM:
+            site = "ffin"                                  # [2 * inner, dim], inner = int(dim * 4 * 2 / 3)
+        elif ws[0] == DIM and ws[1] % 64 == 0 and ws[1] != DIM:
+            site = "attnout"                               # to_out [dim, 512]
+        elif ws[0] == DIM and ws[1] != DIM:
+            site = "ffout"
         else:
-            site = "other"
+            site = "other"                                 # [dim, dim]: to_pred / final Linear
         return sites.get(site, default)
     sc.site_fn = pick
     return sc
@@ -144,6 +151,12 @@ SCHEMES = [
     Scheme("fp16 hi.hi + cross terms MX fp4 e2m1 (GEMMs), fp16 attention", 1.5, f16_mx_cross(2, 1, 1), mk(FH, [(0, 0)])),
     Scheme("fp16 hi.hi + cross terms fp8 e5m2 (GEMMs), fp16 attention", 2.0, f16_e5m2_cross(), mk(FH, [(0, 0)])),
     per_site("mixed, FF conv fp16 x1", 1.55, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)])),
+    per_site("mixed, FF conv + wavenet k3 convs fp16 x1 (= hybrid)", 1.4, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), wavenet3=mk(FH, [(0, 0)])),
+    per_site("mixed, FF conv + wavenet 1x1 convs fp16 x1", 1.45, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), wavenet1=mk(FH, [(0, 0)])),
+    per_site("mixed, FF-in fp16 x1", 1.9, f16_e5m2_cross(), ffin=mk(FH, [(0, 0)])),
+    per_site("mixed, FF-out fp16 x1", 1.95, f16_e5m2_cross(), ffout=mk(FH, [(0, 0)])),
+    per_site("mixed, qkv fp16 x1", 1.9, f16_e5m2_cross(), qkv=mk(FH, [(0, 0)])),
+    per_site("mixed, attention out-projection fp16 x1", 1.95, f16_e5m2_cross(), attnout=mk(FH, [(0, 0)])),
     per_site("mixed, FF conv + FF-in fp16 x1", 1.45, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), ffin=mk(FH, [(0, 0)])),
     per_site("mixed, whole FF fp16 x1", 1.4, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), ffin=mk(FH, [(0, 0)]), ffout=mk(FH, [(0, 0)])),
     per_site("mixed, wavenet fp16 x1", 1.8, f16_e5m2_cross(), wavenet=mk(FH, [(0, 0)])),
@@ -192,10 +205,13 @@ def main():
     ap.add_argument("--seeds", type=int, default=2)
     ap.add_argument("--times", type=float, default=None, help="fix the diffusion time of every utterance")
     ap.add_argument("--only", default="", help="comma-separated substrings of scheme names to run")
+    ap.add_argument("--scale-ffin", type=float, default=1.0,
+                    help="multiply every FF-in weight (GEGLU output grows with its square): at random init the FF branch is dominated "
+                         "by its biases and hides its own rounding; 6 makes its data term dominant, like a trained branch carrying signal")
     a = ap.parse_args()
     global DIM
     DIM = a.dim
-    print(f"Model(dim={a.dim}, depth={a.depth}), batch {a.batch} x {a.n} frames, random-init weights; rel = |y - y_fp32| / |y_fp32| (Frobenius)")
+    print(f"Model(dim={a.dim}, depth={a.depth}), batch {a.batch} x {a.n} frames, random-init weights" + (f", FF-in weights x{a.scale_ffin:g}" if a.scale_ffin != 1 else "") + f"; rel = |y - y_fp32| / |y_fp32| (Frobenius)")
     rows = []
     for sc in SCHEMES:
         if a.only and not any(k in sc.name for k in a.only.split(",")): continue
@@ -204,6 +220,10 @@ def main():
             torch.manual_seed(seed)
             m = Model(dim=a.dim, depth=a.depth)
             sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+            if a.scale_ffin != 1.0:
+                for k, v in sd.items():
+                    if v.ndim == 2 and v.shape[1] == a.dim and v.shape[0] != a.dim and v.shape[0] % 64 != 0:
+                        v.mul_(a.scale_ffin)
             x = torch.randn(a.batch, a.n, a.dim); t = torch.rand(a.batch)
             if a.times is not None: t = torch.full((a.batch,), a.times)
             with torch.no_grad(): ref = O.model_forward(sd, x, t).double()
