@@ -41,8 +41,8 @@ PEAK_16BIT_TFLOPS = 2500.0         # dense bf16 / f16 MFMA peak, MI355X_MICROARC
 PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (RVQ)
 UTT_GFLOP = {(512, 12, False): 316.37, (512, 12, True): 331.98, (128, 6, False): 26.74}   # per 1024-frame utterance, SURVEY §8d
 MFMA_UNITS = {"exact": 3, "mixed": 2, "half": 1, "fast": 1, "hybrid": 1}   # MFMA-pipe time per algorithmic FLOP of the dominant kernel, in 16-bit-product units
-KERNEL_NAME = {"exact": "gemm2_kernel<3, 1, false>", "mixed": "gemm2_kernel<2, 1, true>", "half": "gemm2_kernel<1, 1, true>",
-               "fast": "gemm2_kernel<1, 1, false>", "hybrid": "gemm2_kernel<1, 1, true>"}
+KERNEL_NAME = {"exact": "gemm2_kernel<3, 1, false, 0>", "mixed": "gemm2_kernel<2, 1, true, 0>", "half": "gemm2_kernel<1, 1, true, 0>",
+               "fast": "gemm2_kernel<1, 1, false, 0>", "hybrid": "gemm2_kernel<1, 1, true, 0>"}     # <NSPLIT, EPI_SPLIT = 1, F16, P1>
 DTYPE = {"exact": "bf16x3 split operands on the bf16 MFMA, fp32 accumulate",
          "mixed": "fp16 operands on the f16 MFMA + both first-order correction terms as e5m2 on the block-scaled fp8 MFMA, fp32 accumulate",
          "hybrid": "fp16 operands on the f16 MFMA + both first-order correction terms as e5m2 on the block-scaled fp8 MFMA "

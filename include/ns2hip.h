@@ -171,8 +171,10 @@ typedef struct {
   int condition_on_prompt, dim_prompt, num_latents_m, resampler_depth;                       /* NS2:826-831 */
   int precision;               /* 3 = bf16 x3 split "exact", 4 = fp16 + fp8 correction terms "mixed", 2 = fp16 single product
                                   "half", 1 = bf16 single product "fast"; 5 = "hybrid": the per-site plan of this model
-                                  only: precision 4 everywhere except the feed-forward causal conv (NS2:1016), which runs
-                                  as one fp16 product (dense fp16 planes from the GEGLU epilogue in, precision-4 lines out) */
+                                  only: precision 4 everywhere except the feed-forward causal conv (NS2:1016) and the dilated
+                                  convs of the Wavenet blocks (NS2:612), which run as one fp16 product on the same operands.
+                                  At precisions 2 / 4 / 5 the step-invariant pass (ns2_model_prepare_cond) computes in
+                                  precision 3: its few rows condition every frame of every step */
 } ns2_model_config;
 
 int ns2_model_create(const ns2_model_config* cfg, ns2_model** out);
