@@ -11,8 +11,8 @@ lib = _lib.load(); _lib.check(lib.ns2_debug_force_gemm(2))
 raw = ctypes.CDLL(os.environ["NS2_LIB"])
 g = torch.Generator().manual_seed(0)
 M, f, N = 32768, 1365, 1024
-x = ops.split((torch.randn(M, f, generator=g)).cuda(), ldo=ops.round_up(f, 32))
-w = ops.PackedWeight((torch.randn(f, f, 3, generator=g) * 0.02).cuda()); b = torch.randn(f, generator=g).cuda()
+x = ops.split((torch.randn(M, f, generator=g)).cuda(), ldo=ops.round_up(f, 32), precision=args.prec)
+w = ops.PackedWeight((torch.randn(f, f, 3, generator=g) * 0.02).cuda(), precision=args.prec); b = torch.randn(f, generator=g).cuda()
 for _ in range(5):
     ops.linear_split(w, x, bias=b, conv_taps=3, dilation=1, seq_len=N, precision=args.prec)
 torch.cuda.synchronize()
