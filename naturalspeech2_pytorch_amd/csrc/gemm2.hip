@@ -203,6 +203,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       const bool tr_on = (EPI == EPI_SPLIT) && blockIdx.x == 8 * 37 && kt >= 16 && kt < 80;
 #endif
       STAMP(0);
+#ifdef G2_TRACE
+      if (tr_on) ts[9] = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz: calibrates the shader clock
+#endif
       // Anti-phase DMA issue: an LDS-DMA instruction blocks its wave for ~60-180 clocks at issue.  The A-streaming
       // waves 0-3 (one per SIMD) issue theirs now, while their SIMD partners 4-7 already run MFMAs; waves 4-7 issue
       // the W half after their first K step, when waves 0-3 are in their MFMA phase (measured +5 % on the FF conv).
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       STAMP(8);
       if (tr_on && lane == 0) {
 #pragma unroll
-        for (int n = 0; n < 9; ++n) g2_trace[(wave * 64 + (kt - 16)) * 10 + n] = ts[n];
+        for (int n = 0; n < 10; ++n) g2_trace[(wave * 64 + (kt - 16)) * 10 + n] = ts[n];
       }
 #endif
     }
