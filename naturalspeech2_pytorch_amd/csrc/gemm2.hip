@@ -24,6 +24,9 @@
 namespace ns2 {
 
 constexpr int G2_BM = 256, G2_BN = 256;
+#ifndef G2_CONV3
+#define G2_CONV3 true          // -DG2_CONV3=false: without the tap-shared conv path (A/B builds, tools/ablate_gemm2.sh)
+#endif
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -125,9 +128,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   // upper 32 columns are zero-filled (A and W lanes of those chunks read the zero page)
   const int tap_k = g.kt_per_tap * 32;                        // logical elements per tap
   const int ntaps = g.nkt / g.kt_per_tap;
-  auto tiles_per_tap = [&](auto mode) { return (tap_k + decltype(mode)::bk - 1) / decltype(mode)::bk; };
+  auto tiles_per_tap = [&](auto mode) __attribute__((always_inline)) { return (tap_k + decltype(mode)::bk - 1) / decltype(mode)::bk; };
 
-  auto issue_tile = [&](auto mode, int kt, int stage) {
+  auto issue_tile = [&](auto mode, int kt, int stage) __attribute__((always_inline)) {
     using M = decltype(mode);
     constexpr int BK = M::bk;
     const int tpt = tiles_per_tap(mode);
@@ -191,86 +194,74 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const int a_row_off = (wm * 128 + l31) * RB;
   const int w_row_off = REGION + (wn * 64 + l31) * RB;
 
-  auto run_k = [&](auto mode, const int kt0, const int kt1) {
+#ifdef G2_TRACE
+  unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool tr_on = false;
+#endif
+
+  // ---- one K tile of MFMAs.  A fragments come from `sa` (row offset a_off, swizzle fz_a), W fragments from `sw`; the two
+  // differ only for the tap-shared conv path, where the A rows are shifted by the tap.  `after_first` runs after the first
+  // group of MFMAs (the late DMA issue of waves 4-7).
+  auto compute_tile = [&](auto mode, const unsigned char* sa, const int a_off, const int fz_a, const unsigned char* sw,
+                          const int w_off, const int fz_w, auto&& after_first) __attribute__((always_inline)) {
     using M = decltype(mode);
     constexpr int NS = M::ns, NP = M::np, KCH = M::kch;
-    issue_tile(mode, kt0, kt0 & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                  // tile kt0 landed for every wave
-    for (int kt = kt0; kt < kt1; ++kt) {
-#ifdef G2_TRACE
-      unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      const bool tr_on = (EPI == EPI_SPLIT) && blockIdx.x == 8 * 37 && kt >= 16 && kt < 80;
-#endif
-      STAMP(0);
-#ifdef G2_TRACE
-      if (tr_on) ts[9] = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz: calibrates the shader clock
-#endif
-      // Anti-phase DMA issue: an LDS-DMA instruction blocks its wave for ~60-180 clocks at issue.  The A-streaming
-      // waves 0-3 (one per SIMD) issue theirs now, while their SIMD partners 4-7 already run MFMAs; waves 4-7 issue
-      // the W half after their first K step, when waves 0-3 are in their MFMA phase (measured +5 % on the FF conv).
-      if (kt + 1 < kt1 && a_wave) issue_tile(mode, kt + 1, (kt + 1) & 1);
-      STAMP(1);
-      const unsigned char* sb = smem + (kt & 1) * STAGE;
-      if (wave_active) {
-      if constexpr (NS == 2) {
-        // mixed mode: per 32-deep tile 2 x (4x2) half MFMAs + (4x2) fp8 MFMAs of K = 64.  fp8 operands of lane (l31, hi):
-        // A = 32 bytes [h8 | l8][hi] of row l31 (chunks 4+2hi, 5+2hi of the line), B = [l8 | h8][hi] (chunks 6-2hi, 7-2hi):
-        // lanes 0-31 contribute a_h8 . w_l8, lanes 32-63 a_l8 . w_h8; every product carries exactly one 2^12-scaled factor,
-        // undone by the block scale 2^-12 on A.
-        bf16x8 af[2][4], wf[2][2];
-        i32x8 a8[4], w8[2];
+    if constexpr (NS == 2) {
+      // mixed mode: per 32-deep tile 2 x (4x2) half MFMAs + (4x2) fp8 MFMAs of K = 64.  fp8 operands of lane (l31, hi):
+      // A = 32 bytes [h8 | l8][hi] of row l31 (chunks 4+2hi, 5+2hi of the line), B = [l8 | h8][hi] (chunks 6-2hi, 7-2hi):
+      // lanes 0-31 contribute a_h8 . w_l8, lanes 32-63 a_l8 . w_h8; every product carries exactly one 2^12-scaled factor,
+      // undone by the block scale 2^-12 on A.
+      bf16x8 af[2][4], wf[2][2];
+      i32x8 a8[4], w8[2];
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-          const int coff = ((2 * kc + hi) ^ fswz) * 16;
+      for (int kc = 0; kc < 2; ++kc) {
+        const int ca = ((2 * kc + hi) ^ fz_a) * 16, cw = ((2 * kc + hi) ^ fz_w) * 16;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) af[kc][i] = *reinterpret_cast<const bf16x8*>(sb + a_row_off + i * 32 * RB + coff);
+        for (int i = 0; i < 4; ++i) af[kc][i] = *reinterpret_cast<const bf16x8*>(sa + a_off + i * 32 * RB + ca);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) wf[kc][i] = *reinterpret_cast<const bf16x8*>(sb + w_row_off + i * 32 * RB + coff);
-        }
-        {
-          const int ca0 = ((4 + 2 * hi) ^ fswz) * 16, ca1 = ((5 + 2 * hi) ^ fswz) * 16;
-          const int cw0 = ((6 - 2 * hi) ^ fswz) * 16, cw1 = ((7 - 2 * hi) ^ fswz) * 16;
+        for (int i = 0; i < 2; ++i) wf[kc][i] = *reinterpret_cast<const bf16x8*>(sw + w_off + i * 32 * RB + cw);
+      }
+      {
+        const int ca0 = ((4 + 2 * hi) ^ fz_a) * 16, ca1 = ((5 + 2 * hi) ^ fz_a) * 16;
+        const int cw0 = ((6 - 2 * hi) ^ fz_w) * 16, cw1 = ((7 - 2 * hi) ^ fz_w) * 16;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int4 lo4 = *reinterpret_cast<const int4*>(sb + a_row_off + i * 32 * RB + ca0);
-            const int4 hi4 = *reinterpret_cast<const int4*>(sb + a_row_off + i * 32 * RB + ca1);
-            a8[i] = i32x8{lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int4 lo4 = *reinterpret_cast<const int4*>(sb + w_row_off + i * 32 * RB + cw0);
-            const int4 hi4 = *reinterpret_cast<const int4*>(sb + w_row_off + i * 32 * RB + cw1);
-            w8[i] = i32x8{lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-          }
+        for (int i = 0; i < 4; ++i) {
+          const int4 lo4 = *reinterpret_cast<const int4*>(sa + a_off + i * 32 * RB + ca0);
+          const int4 hi4 = *reinterpret_cast<const int4*>(sa + a_off + i * 32 * RB + ca1);
+          a8[i] = i32x8{lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
         }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int i = 0; i < 2; ++i) {
+          const int4 lo4 = *reinterpret_cast<const int4*>(sw + w_off + i * 32 * RB + cw0);
+          const int4 hi4 = *reinterpret_cast<const int4*>(sw + w_off + i * 32 * RB + cw1);
+          w8[i] = i32x8{lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        }
+      }
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            acc[mi][ni] = mma16<true>(af[0][mi], wf[0][ni], acc[mi][ni]);
-            acc[mi][ni] = mma16<true>(af[1][mi], wf[1][ni], acc[mi][ni]);
-          }
-        if (kt + 1 < kt1 && !a_wave) issue_tile(mode, kt + 1, (kt + 1) & 1);
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[mi][ni] = mma16<true>(af[0][mi], wf[0][ni], acc[mi][ni]);
+          acc[mi][ni] = mma16<true>(af[1][mi], wf[1][ni], acc[mi][ni]);
+        }
+      after_first();
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[mi], w8[ni], acc[mi][ni], /*A e5m2*/ 1, /*B e5m2*/ 1,
-                                                                          0, H8_E8M0_LO, 0, H8_E8M0_ONE);
-      } else {
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[mi], w8[ni], acc[mi][ni], /*A e5m2*/ 1, /*B e5m2*/ 1,
+                                                                        0, H8_E8M0_LO, 0, H8_E8M0_ONE);
+    } else {
 #pragma unroll
       for (int kc = 0; kc < KCH; ++kc) {
         bf16x8 af[NP][4], wf[NP][2];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          const int coff = ((4 * p + 2 * kc + hi) ^ fswz) * 16;
+          const int ca = ((4 * p + 2 * kc + hi) ^ fz_a) * 16, cw = ((4 * p + 2 * kc + hi) ^ fz_w) * 16;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            af[p][i] = *reinterpret_cast<const bf16x8*>(sb + a_row_off + i * 32 * RB + coff);
+          for (int i = 0; i < 4; ++i) af[p][i] = *reinterpret_cast<const bf16x8*>(sa + a_off + i * 32 * RB + ca);
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-            wf[p][i] = *reinterpret_cast<const bf16x8*>(sb + w_row_off + i * 32 * RB + coff);
+          for (int i = 0; i < 2; ++i) wf[p][i] = *reinterpret_cast<const bf16x8*>(sw + w_off + i * 32 * RB + cw);
         }
 #ifdef G2_TRACE
         if (kc < 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (kc == 0) STAMP(2); else STAMP(5); }
@@ -288,15 +279,112 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
 #ifdef G2_TRACE
         if (kc == 0) STAMP(3); else if (kc == 1) STAMP(6);
 #endif
-        if (kc == 0 && kt + 1 < kt1 && !a_wave) issue_tile(mode, kt + 1, (kt + 1) & 1);
+        if (kc == 0) after_first();
 #ifdef G2_TRACE
         if (kc == 0) STAMP(4);
 #endif
       }
+    }
+  };
+
+  // ---- tap-shared causal conv (3 taps, dilation 1, utterances aligned to the row tile: the FF conv and the Wavenet init conv).
+  // The three taps of a K chunk read the SAME 258 input rows shifted by one: instead of streaming three 256-row A tiles per
+  // chunk, one 264-row tile A' (rows m0 - 2 ...) is loaded once per chunk and the fragment reads address rows r + tap; only
+  // the W tile changes per step.  LDS: two A' buffers (33 KiB each) + two W buffers (32 KiB each); DMA per three steps:
+  // 33 + 96 wave-instructions instead of 192.  Rows before the utterance start are zero-page lanes, as in the standard path.
+  auto run_k_conv3 = [&](auto mode) __attribute__((always_inline)) {
+    using M = decltype(mode);
+    constexpr int BK = M::bk;
+    constexpr int A_BUF = 264 * RB, W_BUF = REGION;
+    unsigned char* const sA = smem;
+    unsigned char* const sW = smem + 2 * A_BUF;
+    const int tpt = tiles_per_tap(mode);
+    const bool half_tail = !M::line32 && (g.kt_per_tap & 1);
+    const int m0 = tm * G2_BM;
+    const int n0 = m0 % g.seq_len;                       // position of the tile's first row inside its utterance
+    const bf16_t* a_base = g.a_hi + pcol((int)(z * g.a_zs), ail) + (long)(m0 - 2) * a_rs;
+    const bf16_t* w_base = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN) * w_rs;
+    const int lc0 = pchunk ^ (lrow >> 1), lc1 = pchunk ^ (4 + (lrow >> 1));     // logical chunk for even / odd row groups
+    const int cofA0 = M::line32 ? lc0 * 8 : pcol(lc0 * 8, ail), cofA1 = M::line32 ? lc1 * 8 : pcol(lc1 * 8, ail);
+    const int cofW0 = M::line32 ? lc0 * 8 : pcol(lc0 * 8, wil), cofW1 = M::line32 ? lc1 * 8 : pcol(lc1 * 8, wil);
+    const bool chi0 = lc0 >= 4, chi1 = lc1 >= 4;
+
+    auto issue_w = [&](int it, int tap, int buf) __attribute__((always_inline)) {       // this wave's 4 of the 32 instructions of W(it, tap)
+      const bool half = half_tail && (it == tpt - 1);
+      const long off = pcol(tap * tap_k + it * BK, wil);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = wave * 4 + i;
+        const bf16_t* p = (half && ((i & 1) ? chi1 : chi0)) ? zero_page
+                                                            : (w_base + (long)(8 * j + lrow) * w_rs + off + ((i & 1) ? cofW1 : cofW0));
+        glds16(p, sW + buf * W_BUF + j * 1024);
       }
-      } else if (kt + 1 < kt1 && !a_wave) {
-        issue_tile(mode, kt + 1, (kt + 1) & 1);
+    };
+    auto issue_a = [&](int it, int part, int buf) __attribute__((always_inline)) {      // this wave's 1-2 of the 11 instructions of part `part` of A'(it)
+      const bool half = half_tail && (it == tpt - 1);
+      const long off = pcol(it * BK, ail);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (e == 1 && wave >= 3) break;
+        const int j = 11 * part + 8 * e + wave;            // row group [0, 33)
+        const bool par = j & 1;
+        const int row = 8 * j + lrow;                      // A' row: input row m0 - 2 + row
+        const bool ok = (n0 + row - 2 >= 0) && ((long)m0 - 2 + row < g.M) && !(half && (par ? chi1 : chi0));
+        const bf16_t* p = ok ? (a_base + (long)row * a_rs + off + (par ? cofA1 : cofA0)) : zero_page;
+        glds16(p, sA + buf * A_BUF + j * 1024);
       }
+    };
+
+#pragma unroll
+    for (int part = 0; part < 3; ++part) issue_a(0, part, 0);
+    issue_w(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int w_off = (wn * 64 + l31) * RB;
+    for (int it = 0; it < tpt; ++it) {
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        const int st = 3 * it + tap;
+        const bool more_w = st + 1 < 3 * tpt, more_a = it + 1 < tpt;
+        auto issue_next = [&]() __attribute__((always_inline)) {
+          if (more_w) issue_w(tap == 2 ? it + 1 : it, tap == 2 ? 0 : tap + 1, (st + 1) & 1);
+          if (more_a) issue_a(it + 1, tap, (it + 1) & 1);
+        };
+        if (a_wave) issue_next();                          // anti-phase issue as in the standard loop
+        auto late = [&]() __attribute__((always_inline)) { if (!a_wave) issue_next(); };
+        const int a_off = (wm * 128 + l31 + tap) * RB;
+        const int fz_a = ((l31 + tap) >> 1) & 7;
+        if (wave_active) compute_tile(mode, sA + (it & 1) * A_BUF, a_off, fz_a, sW + (st & 1) * W_BUF, w_off, fswz, late);
+        else late();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+  };
+
+  auto run_k = [&](auto mode, const int kt0, const int kt1) __attribute__((always_inline)) {
+    issue_tile(mode, kt0, kt0 & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // tile kt0 landed for every wave
+    for (int kt = kt0; kt < kt1; ++kt) {
+#ifdef G2_TRACE
+#pragma unroll
+      for (int n = 0; n < 10; ++n) ts[n] = 0;
+      tr_on = (EPI == EPI_SPLIT) && blockIdx.x == 8 * 37 && kt >= 16 && kt < 80;
+#endif
+      STAMP(0);
+#ifdef G2_TRACE
+      if (tr_on) ts[9] = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz: calibrates the shader clock
+#endif
+      // Anti-phase DMA issue: an LDS-DMA instruction blocks its wave for ~60-180 clocks at issue.  The A-streaming
+      // waves 0-3 (one per SIMD) issue theirs now, while their SIMD partners 4-7 already run MFMAs; waves 4-7 issue
+      // the W half after their first K step, when waves 0-3 are in their MFMA phase (measured +5 % on the FF conv).
+      if (kt + 1 < kt1 && a_wave) issue_tile(mode, kt + 1, (kt + 1) & 1);
+      STAMP(1);
+      const unsigned char* sb = smem + (kt & 1) * STAGE;
+      auto late = [&]() __attribute__((always_inline)) { if (kt + 1 < kt1 && !a_wave) issue_tile(mode, kt + 1, (kt + 1) & 1); };
+      if (wave_active) compute_tile(mode, sb, a_row_off, fswz, sb, w_row_off, fswz, late);
+      else late();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile has landed
       STAMP(7);
       __syncthreads();                                // ... everybody's has, and this stage is free to overwrite
@@ -316,6 +404,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     run_k(ModeP1{}, 0, mid_tap * tiles_per_tap(ModeP1{}));
     wavenet_midgate<4, 2>(acc, g, z, row_base, col_base, l31, hi);
     run_k(ModeMain{}, mid_tap * tiles_per_tap(ModeMain{}), ntaps * tiles_per_tap(ModeMain{}));
+  } else if constexpr (EPI == EPI_SPLIT && G2_CONV3) {
+    const bool conv3 = g.conv_taps == 3 && ntaps == 3 && !g.dil_z && g.dil == 1 && g.pad_left < 0 && g.seq_len > 0 &&
+                       (g.seq_len % G2_BM) == 0;
+    if (conv3) run_k_conv3(ModeMain{});
+    else run_k(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
   } else {
     run_k(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
   }

@@ -110,7 +110,10 @@ def conv_ref(x_bnc, w, b, dil):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("B,N,Cin,Cout,dil", [(3, 200, 96, 80, 1), (2, 300, 100, 100, 4), (2, 1024, 64, 64, 128), (1, 50, 170, 170, 1)])
+@pytest.mark.parametrize("B,N,Cin,Cout,dil", [(3, 200, 96, 80, 1), (2, 300, 100, 100, 4), (2, 1024, 64, 64, 128), (1, 50, 170, 170, 1),
+                                              # utterances aligned to the 256-row tile, dilation 1: the tap-shared path of the 256x256
+                                              # kernel (split epilogue), incl. an odd number of 32-blocks per tap and several column tiles
+                                              (2, 512, 170, 200, 1), (3, 256, 96, 300, 1), (1, 768, 100, 100, 1)])
 def test_causal_conv(B, N, Cin, Cout, dil, prec, gemm_kernel):
     x = rnd(B * N, Cin, seed=6)
     w = rnd(Cout, Cin, 3, seed=7, scale=1 / math.sqrt(3 * Cin))
