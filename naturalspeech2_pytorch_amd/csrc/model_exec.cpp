@@ -107,7 +107,7 @@ struct PackCtx { std::vector<void*>* owned; bool il; int fmt; };   // il: interl
 // res_conv keeps the correction terms (gemm2.hip, P1).  tools/precision_study.py: these are the two sites whose rounding
 // error reaches the output least (4.1e-5 -> 9.4e-5 for both at d128; every other site costs 1.6e-4 ... 3.5e-4).
 static inline int op_precision(int model_precision) { return model_precision == 5 ? 4 : model_precision; }
-static inline bool ffconv_half(int model_precision) { return model_precision == 5; }
+static inline bool hybrid_plan(int model_precision) { return model_precision == 5; }
 // The step-invariant conditioning (ns2_model_prepare_cond: perceiver resampler, cond_to_model_dim, per-layer cross-attention
 // K / V) runs once per sampling run on a few rows, and every frame of every step consumes its 32 resampled tokens: their
 // rounding is a systematic error of the whole run (measured on the conditioned d512/L12 model: tokens 2.1e-4 -> output
@@ -333,7 +333,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
   const bool cond = m->cfg.condition_on_prompt;
   char key[256];
   const PackCtx pc = pack_ctx_for(&m->owned, op_precision(m->cfg.precision));
-  const PackCtx pc_conv = ffconv_half(m->cfg.precision) ? pack_ctx_for(&m->owned, 2) : pc;
+  const PackCtx pc_conv = hybrid_plan(m->cfg.precision) ? pack_ctx_for(&m->owned, 2) : pc;
   const PackCtx pc_cond = pack_ctx_for(&m->owned, cond_precision(op_precision(m->cfg.precision)));   // weights of prepare_cond
   const bool il = pc.il;
 
@@ -557,7 +557,7 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
   w->o = take_planes(c, Mq * a, il, f16);
   w->ffh = take_planes(c, Mq * fp, il, f16);
   w->ffh_conv = w->ffh;
-  if (ffconv_half(m->cfg.precision)) { w->ffh_conv.lo = nullptr; w->ffh_conv.fmt = FMT_F16; }
+  if (hybrid_plan(m->cfg.precision)) { w->ffh_conv.lo = nullptr; w->ffh_conv.fmt = FMT_F16; }
   w->ffc = take_planes(c, M * fp, il, f16);
   if (m->cfg.condition_on_prompt && n_prompt > 0) {
     const int Lm = m->Lm;
@@ -799,7 +799,7 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
   if (cond) carve_cond(m, &cs, const_cast<void*>(cond_state), 0, B, N, n_cond);
   const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, L = m->L, S = m->S, H = m->cfg.heads, prec = op_precision(m->cfg.precision);
   const int M = B * N, Jtot = m->Jtot, Lm = m->Lm;
-  const int conv_prec = ffconv_half(m->cfg.precision) ? 2 : prec;
+  const int conv_prec = hybrid_plan(m->cfg.precision) ? 2 : prec;
   const int xprec = fmts_for(prec).xatt_prec;
   char name[64];
 
@@ -825,7 +825,7 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
     const long a_zs = (st == 0) ? 0 : dp;
     PROF(PC_GEMM_WAVENET, gemm_wavenet(m->w_wn[st], a_hi, a_lo, lda, a_zs, M, N, /*dil=*/1, /*dil_z=*/1, /*nz=*/L, m->b_wn_conv[st], m->b_wn_res[st],
                        dim, w.condall + (size_t)st * L * 2 * dim, Jtot, 2 * dim, cur.hi, cur.lo, L * dp, dp, dp, prec, s,
-                       /*p1_half=*/ffconv_half(m->cfg.precision) ? 1 : 0));
+                       /*p1_half=*/hybrid_plan(m->cfg.precision) ? 1 : 0));
     snprintf(name, sizeof name, "wavenet.stack%d", st);
     NSCHK(tap_planes(m, name, cur, L * dp, M, L * dp, s));
     Planes tmp = prev; prev = cur; cur = tmp;
