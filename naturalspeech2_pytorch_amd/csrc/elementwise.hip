@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* xproj, long
 constexpr int LP_UNITS = 8;
 constexpr int LP_LDH = 512 + 4;                   // LDS row stride of the staged h (floats)
 constexpr int LP_MAXB = 32;
-constexpr unsigned LP_SPIN_LIMIT = 1u << 26;      // ~ seconds: a lost workgroup turns into a trap, not a hang
+constexpr unsigned LP_SPIN_LIMIT = 1u << 22;      // ~ seconds of polling: a lost workgroup turns into a trap, not a hang
 
 NS2_DEVINL float ld_agent(const float* p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
