@@ -126,22 +126,33 @@ def test_precision_sweep_headline_architecture(precision):
     assert max(flat) < CEIL[precision], f"{precision}: max rel err over the sweep {max(flat)}"
 
 
+_COND_REF = {}
+
+
 @pytest.mark.parametrize("precision", ["hybrid", "mixed", "half"])
 def test_conditioned_cfg_d512(precision):
-    """BASELINE config 3 architecture with classifier-free guidance (two forwards mixed at cond_scale 1.3, NS2:914-927)."""
+    """BASELINE config 3 architecture with classifier-free guidance (two forwards mixed at cond_scale 1.3, NS2:914-927),
+    three weight / input seeds; the maximum is recorded and asserted."""
     kw = dict(dim=512, depth=12, dim_prompt=512, condition_on_prompt=True)
-    m, sd = build(kw, seed=9, precision=precision)
     b, n = 2, 512
-    x = make_input("x", (b, n, 512), seed=10)
-    t = make_input("times", (b,), seed=10, uniform=True)
-    prompt = make_input("prompt", (b, 103, 512), seed=10)
-    cond = make_input("cond", (b, 512, n), seed=10)
-    with torch.no_grad():
-        y = m.forward_with_cond_scale(x.to(DEV), t.to(DEV), prompt=prompt.to(DEV), cond=cond.to(DEV), cond_scale=1.3)
-        ref = O.model_forward_with_cond_scale(sd, x, t, prompt, cond, 1.3)
-    e = rel(y, ref)
-    record(f"conditioned_cfg_d512/{precision}", e)
-    assert torch.isfinite(y).all() and e < CEIL[precision], f"{precision}: rel {e}"
+    errs = []
+    for seed in (9, 19, 29):
+        m, sd = build(kw, seed=seed, precision=precision)
+        x = make_input("x", (b, n, 512), seed=seed + 1)
+        t = make_input("times", (b,), seed=seed + 1, uniform=True)
+        prompt = make_input("prompt", (b, 103, 512), seed=seed + 1)
+        cond = make_input("cond", (b, 512, n), seed=seed + 1)
+        with torch.no_grad():
+            y = m.forward_with_cond_scale(x.to(DEV), t.to(DEV), prompt=prompt.to(DEV), cond=cond.to(DEV), cond_scale=1.3)
+            if seed not in _COND_REF:
+                _COND_REF[seed] = O.model_forward_with_cond_scale(sd, x, t, prompt, cond, 1.3)
+        assert torch.isfinite(y).all()
+        errs.append(rel(y, _COND_REF[seed]))
+        del m
+        torch.cuda.empty_cache()
+    record(f"conditioned_cfg_d512/{precision}", max(errs))
+    record(f"conditioned_cfg_d512_per_seed/{precision}", errs)
+    assert max(errs) < CEIL[precision], f"{precision}: rel {errs}"
 
 
 def test_ddim_trajectory_50_steps():
