@@ -176,6 +176,29 @@ def test_ddim_trajectory_50_steps():
     assert out["exact"] < 1e-4 and out["mixed"] < 5e-4 and out["hybrid"] < 5e-4 and out["half"] < 5e-3, out
 
 
+def test_conditioned_ddim_trajectory_with_cfg():
+    """a conditioned sampling run with classifier-free guidance: 30 DDIM steps at d128/L6 (dim_prompt 128, prompt of 60 encoded
+    frames, frame-aligned cond, cond_scale 1.3): two forwards per step, the step-invariant conditioning computed once -- against
+    the oracle's loop on the same injected noise, every benched precision"""
+    kw = dict(dim=128, depth=6, dim_prompt=128, condition_on_prompt=True)
+    noise = make_input("noise", (2, 256, 128), seed=36)
+    p_enc = make_input("prompt_enc", (2, 60, 128), seed=36)
+    cond = make_input("cond", (2, 128, 256), seed=36)
+    out, ref = {}, None
+    for precision in ("exact", "mixed", "hybrid", "half"):
+        m, sd = build(kw, seed=35, precision=precision)
+        d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=30).to(DEV).eval()
+        y = d.sample(length=256, prompt_enc=p_enc.to(DEV), cond=cond.to(DEV), cond_scale=1.3, noise=noise)
+        if ref is None:
+            with torch.no_grad():
+                ref = O.ddim_sample(sd, noise, 30, prompt=p_enc, cond=cond, cond_scale=1.3)
+        assert torch.isfinite(y).all()
+        out[precision] = rel(y, ref)
+    record("ddim_30_steps_conditioned_cfg_d128_L6", out)
+    print("conditioned 30-step DDIM trajectory rel err:", {k: f"{v:.2e}" for k, v in out.items()})
+    assert out["exact"] < 1e-4 and out["mixed"] < 5e-4 and out["hybrid"] < 5e-4 and out["half"] < 5e-3, out
+
+
 def test_large_activation_stress():
     """weights x8 (trained checkpoints have larger activations than N(0, 1/fan_in) init): outputs stay finite in every mode
     (IEEE-half conversions saturate at +-65504 / +-57344 instead of producing inf) and the error is reported"""
