@@ -176,6 +176,27 @@ def test_ddim_trajectory_50_steps():
     assert out["exact"] < 1e-4 and out["mixed"] < 5e-4 and out["hybrid"] < 5e-4 and out["half"] < 5e-3, out
 
 
+def test_ddim_trajectory_headline_architecture():
+    """10 DDIM steps at the headline architecture (d512/L12, one utterance of 512 frames) in the benched plan and its neighbours"""
+    kw = dict(dim=512, depth=12)
+    noise = make_input("noise", (1, 512, 512), seed=38)
+    out, ref = {}, None
+    for precision in ("hybrid", "mixed", "half"):
+        m, sd = build(kw, seed=37, precision=precision)
+        d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=10)
+        y = d.sample(length=512, batch_size=1, noise=noise)
+        if ref is None:
+            with torch.no_grad():
+                ref = O.ddim_sample(sd, noise, 10)
+        assert torch.isfinite(y).all()
+        out[precision] = rel(y, ref)
+        del m, d
+        torch.cuda.empty_cache()
+    record("ddim_10_steps_d512_L12", out)
+    print("10-step DDIM trajectory at d512/L12 rel err:", {k: f"{v:.2e}" for k, v in out.items()})
+    assert out["hybrid"] < CEIL["hybrid"] and out["mixed"] < CEIL["mixed"] and out["half"] < 2e-3, out
+
+
 def test_conditioned_ddim_trajectory_with_cfg():
     """a conditioned sampling run with classifier-free guidance: 30 DDIM steps at d128/L6 (dim_prompt 128, prompt of 60 encoded
     frames, frame-aligned cond, cond_scale 1.3): two forwards per step, the step-invariant conditioning computed once -- against
