@@ -37,6 +37,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PARITY_RECORD = "r03_parity.json"    # profiles/: the tracked key-wise parity record (tests/parity_record.py)
 PEAK_16BIT_TFLOPS = 2500.0         # dense bf16 / f16 MFMA peak, MI355X_MICROARCH.md (spec; 2495 measured)
 PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (RVQ)
 UTT_GFLOP = {(512, 12, False): 316.37, (512, 12, True): 331.98, (128, 6, False): 26.74}   # per 1024-frame utterance, SURVEY §8d
@@ -275,15 +276,16 @@ def main():
         sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         parity = {"live_rel_err_vs_fp32_oracle": {} if args.no_parity else
                   {args.precision: live_parity(model, sd_cpu, args.precision, args.conditioned)}, "tolerance": 1e-3}
-        pj = os.path.join(ROOT, "profiles", "r02_parity.json")
-        if os.path.exists(pj):
-            try:
-                sw = json.load(open(pj))
-                parity["sweep_d512_L12"] = {k.split("/")[-1]: dict(max=v["max"], mean=v["mean"]) for k, v in sw.items()
-                                            if k.startswith("sweep_d512_L12/")}
-                parity["sweep_source"] = "profiles/r02_parity.json (tests/test_parity_r2_gpu.py: 8 weight seeds x times {0.002, 0.5, 0.999})"
-            except Exception:
-                pass
+        # committed sweep maxima (tests/test_parity_r2_gpu.py via tests/parity_record.py).  A record without the sweep keys is a
+        # broken evidence trail: fail loudly instead of quoting an empty sweep.
+        pj = os.path.join(ROOT, "profiles", PARITY_RECORD)
+        sw = json.load(open(pj))
+        missing = [k for k in ("sweep_d512_L12/hybrid", "sweep_d512_L12/mixed", "sweep_d512_L12/half") if k not in sw]
+        if missing:
+            raise RuntimeError(f"{pj} lacks {missing}: regenerate it from a full `pytest -m gpu` run + tools/merge_parity.py")
+        parity["sweep_d512_L12"] = {k.split("/")[-1]: dict(max=v["max"], mean=v["mean"]) for k, v in sw.items()
+                                    if k.startswith("sweep_d512_L12/")}
+        parity["sweep_source"] = f"profiles/{PARITY_RECORD} (tests/test_parity_r2_gpu.py: 8 weight seeds x times {{0.002, 0.5, 0.999}})"
         if not args.no_secondary and not args.conditioned:
             k2 = min(args.steps, 10)
             for other in ("mixed", "half", "exact"):

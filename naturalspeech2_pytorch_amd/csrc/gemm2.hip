@@ -42,6 +42,15 @@ __device__ unsigned long long g2_trace[8 * 64 * 10];
 #define STAMP(n)
 #endif
 
+#ifdef G2_BLKTRACE   // block-level timeline (tools/trace_blocks.py): per block and wave, 100 MHz s_memrealtime stamps at entry / first
+                     // tile landed / K loop done / epilogue stores issued / stores drained, plus HW_ID and XCC_ID
+constexpr int G2_BLK_MAX = 4096;
+__device__ unsigned long long g2_blk[G2_BLK_MAX * 8 * 8];
+#define BSTAMP(n) do { bts[n] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BSTAMP(n)
+#endif
+
 // 256 B of zeros in device memory: the DMA source of every padded / out-of-sequence lane.  A module-scope __device__ array
 // exists once per device and needs no host-side allocation or bookkeeping (the library keeps no mutable host state).
 __device__ __attribute__((aligned(256))) bf16_t g2_zero_page[128];
@@ -79,6 +88,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef G2_BLKTRACE
+  unsigned long long bts[6] = {0, 0, 0, 0, 0, 0};
+  BSTAMP(0);
+  const unsigned long long cyc0 = __builtin_readcyclecounter();
+#endif
   // wave -> (row half, column quarter): waves w and w+4 share a SIMD (dispatch order 0,2,1,3,0,2,1,3), so column
   // quarters {0,1} and {2,3} are paired on every SIMD: when the last column tile is at most half valid (FF conv:
   // N = 1365 = 5.33 tiles) the idle quarters leave each SIMD's MFMA pipe to one active wave instead of idling two SIMDs.
@@ -340,6 +354,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     issue_w(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef G2_BLKTRACE
+    if (bts[1] == 0) BSTAMP(1);
+#endif
     const int w_off = (wn * 64 + l31) * RB;
     for (int it = 0; it < tpt; ++it) {
 #pragma unroll
@@ -366,6 +383,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     issue_tile(mode, kt0, kt0 & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                  // tile kt0 landed for every wave
+#ifdef G2_BLKTRACE
+    if (bts[1] == 0) BSTAMP(1);
+#endif
     for (int kt = kt0; kt < kt1; ++kt) {
 #ifdef G2_TRACE
 #pragma unroll
@@ -412,20 +432,40 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   } else {
     run_k(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
   }
-  if (!wave_active) return;
+  BSTAMP(2);
   // all waves are past the K loop's last barrier: the LDS ring is free, every wave takes a private 18 KiB region
-  if constexpr (EPI == EPI_F32) {
-    if (epi_lds_supported<EPI>(g, row_base)) {
-      gemm_epilogue_lds<EPI, 2, 0>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane, smem + wave * EPI_LDS_WAVE_BYTES);
-      return;
+  if (wave_active) {
+    bool done = false;
+    if constexpr (EPI == EPI_F32) {
+      if (epi_lds_supported<EPI>(g, row_base)) {
+        gemm_epilogue_lds<EPI, 2, 0>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane, smem + wave * EPI_LDS_WAVE_BYTES);
+        done = true;
+      }
     }
+    if (!done) gemm_epilogue<EPI, 4, 2>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane);
   }
-  gemm_epilogue<EPI, 4, 2>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane);
+#ifdef G2_BLKTRACE
+  BSTAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BSTAMP(4);
+  if (lane == 0 && blockIdx.x < G2_BLK_MAX) {
+    unsigned long long* o = g2_blk + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = bts[0]; o[1] = bts[1]; o[2] = bts[2]; o[3] = bts[3]; o[4] = bts[4];
+    o[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    o[6] = __builtin_readcyclecounter() - cyc0;
+    o[7] = (unsigned long long)wave_active;
+  }
+#endif
 }
 
 #ifdef G2_TRACE
 extern "C" int ns2_debug_read_trace(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2_trace), sizeof(unsigned long long) * 8 * 64 * 10);
+}
+#endif
+#ifdef G2_BLKTRACE
+extern "C" int ns2_debug_read_blocks(unsigned long long* out, int nblk) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2_blk), sizeof(unsigned long long) * 64 * (size_t)nblk);
 }
 #endif
 

@@ -243,3 +243,31 @@ def test_planes_layout_helper_cpu():
     assert not d.has_lo and d.lo is None and torch.equal(d.buf, hi)
     for c in (0, 31, 32, 63, 64, 95):                          # physical column of logical column c
         assert buf[2, ((c & ~31) << 1) | (c & 31)] == hi[2, c] and buf[2, (((c & ~31) << 1) | (c & 31)) + 32] == lo[2, c]
+
+
+def test_parity_record_is_complete():
+    """The tracked parity record must hold every key bench.py quotes (a partial GPU run once overwrote it with one key)."""
+    import json
+    import re
+    from tests import parity_record as PR
+    rec = json.load(open(PR.TRACKED))
+    for k in PR.REQUIRED_KEYS:
+        assert k in rec and {"max", "mean"} <= set(rec[k]), f"{PR.TRACKED} lacks {k}"
+    bench_src = open(os.path.join(ROOT, "bench.py")).read()
+    m = re.search(r'PARITY_RECORD = "([^"]+)"', bench_src)
+    assert m and os.path.join(ROOT, "profiles", m.group(1)) == PR.TRACKED, "bench.py and tests/parity_record.py must name the same file"
+
+
+def test_parity_record_merges_key_by_key(tmp_path, monkeypatch):
+    """record() carries every other key of the tracked record along: a partial run can never shrink the evidence."""
+    import json
+    from tests import parity_record as PR
+    tracked, scratch = tmp_path / "tracked.json", tmp_path / "out" / "scratch.json"
+    tracked.write_text(json.dumps({"a": 1, "b": {"max": 2}}))
+    monkeypatch.setattr(PR, "TRACKED", str(tracked))
+    monkeypatch.setattr(PR, "SCRATCH", str(scratch))
+    PR.record("c", 3)
+    PR.record("a", 10)
+    got = json.load(open(scratch))
+    assert got["a"] == 10 and got["b"] == {"max": 2} and got["c"] == 3
+    assert got["_meta"]["updated_keys_r03"] == ["a", "c"]

@@ -5,7 +5,7 @@ caller of the HIP model, the non-default schedules / objectives, concurrent mode
 there are two), the sampler over an RCCL process group, RVQ at BASELINE config-4 size with every mismatch adjudicated,
 and the codec boundary class with HF EnCodec's SEANet injected.
 
-Measured numbers are also written to gpurun_out/parity_r2.json (copied to profiles/ by the builder)."""
+Measured numbers are merged key by key into the parity record (tests/parity_record.py -> profiles/r03_parity.json)."""
 import json
 import math
 import os
@@ -31,23 +31,8 @@ TOL = 1e-3                                  # BASELINE.json north_star: <= 1e-3 
 # conv as one half product) and "mixed" must keep a >= 4x margin
 CEIL = {"exact": 1e-4, "mixed": 2.5e-4, "hybrid": 2.5e-4, "half": TOL}
 _SWEEP_REF = {}                            # oracle outputs of the sweep, shared by the precision parametrisations
-REPORT = {}
 F_linear = torch.nn.functional.linear
-
-
-def record(key, value):
-    REPORT[key] = value
-    out = os.path.join(ROOT, "gpurun_out")
-    os.makedirs(out, exist_ok=True)
-    path = os.path.join(out, "parity_r2.json")
-    old = {}
-    if os.path.exists(path):
-        try:
-            old = json.load(open(path))
-        except Exception:
-            old = {}
-    old.update(REPORT)
-    json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+from tests.parity_record import record  # noqa: E402  (key-wise merge into the tracked record; never a whole-file overwrite)
 
 
 def rel(a, b):
