@@ -18,8 +18,9 @@
 //   * causal-conv zero fill (rows before the utterance start) and M-edge rows are lanes whose source pointer is
 //     redirected to a 16-B zero page -- the DMA needs no predication.
 #include <cstdlib>
+#include <type_traits>
 
-#include "gemm_epi.h"
+#include "gemm_epi_fast.h"
 
 namespace ns2 {
 
@@ -69,7 +70,11 @@ struct KMode {
 // P1 != 0 (EPI_WAVENET only): the first K phase -- the dilated conv taps -- runs in arithmetic P1 instead of NSPLIT, reading
 // the SAME operands: P1 = 1 under NSPLIT = 2 multiplies the IEEE-half parts of the FMT_H8 lines as one product per
 // contraction (64-deep tiles gathered from two lines), the second phase (res_conv) keeps the correction terms.
-template <int NSPLIT, int EPI, bool F16, int P1 = 0>
+// UNI (EPI_WAVENET only, chosen by the launcher): every wave tile lies inside one utterance and is fully valid (seq_len % 128 ==
+// 0, M % 128 == 0, N % 64 == 0), so the FiLM gate between the K phases reads gamma / beta once per column.  A template
+// parameter rather than a run-time branch: two alternative bodies that both rewrite the accumulators cost ~130 VGPRs of
+// tuple copies at their merge point (measured: 87-197 spilled registers, reloaded inside the second K loop).
+template <int NSPLIT, int EPI, bool F16, int P1 = 0, bool UNI = false>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const bf16_t* zero_page = g2_zero_page;
   static_assert(NSPLIT != 2 || F16, "the mixed mode multiplies IEEE-half operands");
@@ -422,7 +427,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     // phase 1: the taps before mid_kt (dilated conv), phase 2: the rest (res_conv on the unshifted input)
     const int mid_tap = (g.mid_kt > 0) ? g.mid_kt / g.kt_per_tap : 0;
     run_k(ModeP1{}, 0, mid_tap * tiles_per_tap(ModeP1{}));
-    wavenet_midgate<4, 2>(acc, g, z, row_base, col_base, l31, hi);
+    if constexpr (UNI) wavenet_midgate_fast(acc, g, z, row_base, col_base, l31);
+    else wavenet_midgate<4, 2>(acc, g, z, row_base, col_base, l31, hi);
     run_k(ModeMain{}, mid_tap * tiles_per_tap(ModeMain{}), ntaps * tiles_per_tap(ModeMain{}));
   } else if constexpr (EPI == EPI_SPLIT && G2_CONV3) {
     const bool conv3 = g.conv_taps == 3 && ntaps == 3 && !g.dil_z && g.dil == 1 && g.pad_left < 0 && g.seq_len > 0 &&
@@ -436,13 +442,62 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   // all waves are past the K loop's last barrier: the LDS ring is free, every wave takes a private 18 KiB region
   if (wave_active) {
     bool done = false;
-    if constexpr (EPI == EPI_F32) {
-      if (epi_lds_supported<EPI>(g, row_base)) {
-        gemm_epilogue_lds<EPI, 2, 0>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane, smem + wave * EPI_LDS_WAVE_BYTES);
-        done = true;
+    unsigned char* const wbuf = smem + wave * EPI_LDS_WAVE_BYTES;
+    const int ocol_base = tn * 128 + wn * 32;
+#ifndef G2_SLOW_EPILOGUE
+    // Interior wave tiles (all 128 rows and 64 columns valid) take the streamlined epilogues of gemm_epi_fast.h; edge tiles
+    // and the formats a kernel of this arithmetic does not normally write keep the generic path.
+    if (row_base + 128 <= g.M) {
+      // plane format of the output: kernels on IEEE-half operands write F16 / H8, kernels on bf16 operands bf16 planes
+      auto planes = [&](auto&& fn) __attribute__((always_inline)) {
+        const bool al = ((reinterpret_cast<uintptr_t>(g.out_hi) & 15) == 0) && (g.ldo_s & 31) == 0;
+        if (!al) return false;
+        if constexpr (F16) {
+          if (g.out_fmt == FMT_F16 && !g.out_lo) { fn(std::integral_constant<int, PF_F16>{}); return true; }
+          if (g.out_fmt == FMT_H8) { fn(std::integral_constant<int, PF_H8>{}); return true; }
+        } else {
+          if (g.out_fmt == FMT_BF16 && g.out_lo) { fn(std::integral_constant<int, PF_BF16IL>{}); return true; }
+          if constexpr (NSPLIT == 1) { if (g.out_fmt == FMT_BF16 && !g.out_lo) { fn(std::integral_constant<int, PF_BF16>{}); return true; } }
+        }
+        return false;
+      };
+      if constexpr (EPI == EPI_F32) {
+        if (col_base + 64 <= g.N && g.act == 0 && (g.ldo_f & 3) == 0 && (reinterpret_cast<uintptr_t>(g.out_f) & 15) == 0 &&
+            (!g.resid || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.resid) & 15) == 0))) {
+          epi_f32_fast(acc, g, row_base, col_base, lane, wbuf);
+          done = true;
+        }
+      } else if constexpr (EPI == EPI_GEGLU) {
+        if (ocol_base + 32 <= g.out_ncols)
+          done = planes([&](auto pf) __attribute__((always_inline)) { epi_geglu_fast<decltype(pf)::value>(acc, g, row_base, col_base, ocol_base, lane, wbuf); });
+      } else if constexpr (EPI == EPI_SPLIT) {
+        if (col_base + 64 <= g.N && g.act == 0)
+          done = planes([&](auto pf) __attribute__((always_inline)) { epi_planes_fast<decltype(pf)::value, true>(acc, g, z, row_base, col_base, lane, wbuf); });
+      } else if constexpr (EPI == EPI_WAVENET) {
+        if (col_base + 64 <= g.N)
+          done = planes([&](auto pf) __attribute__((always_inline)) { epi_planes_fast<decltype(pf)::value, false>(acc, g, z, row_base, col_base, lane, wbuf); });
+      } else if constexpr (EPI == EPI_QKV) {
+        if (col_base + 64 <= g.N && !g.bias) {
+          if (col_base + 64 <= g.split_col) {
+            done = planes([&](auto pf) __attribute__((always_inline)) { epi_planes_fast<decltype(pf)::value, false>(acc, g, 0, row_base, col_base, lane, wbuf); });
+          } else if (col_base >= g.split_col && !g.vt_lo && g.vt_fmt == (F16 ? FMT_F16 : FMT_BF16) && g.seq_len > 0 &&
+                     (g.seq_len & 127) == 0 && (g.vt_ld & 7) == 0 && (reinterpret_cast<uintptr_t>(g.vt_hi) & 15) == 0) {
+            epi_vt_fast<F16>(acc, g, row_base, col_base, lane, wbuf);
+            done = true;
+          }
+        }
       }
     }
-    if (!done) gemm_epilogue<EPI, 4, 2>(acc, g, z, row_base, col_base, tn * 128 + wn * 32, lane);
+#endif
+    if (!done) {
+      if constexpr (EPI == EPI_F32) {
+        if (epi_lds_supported<EPI>(g, row_base)) {
+          gemm_epilogue_lds<EPI, 2, 0>(acc, g, z, row_base, col_base, ocol_base, lane, wbuf);
+          done = true;
+        }
+      }
+      if (!done) gemm_epilogue<EPI, 4, 2>(acc, g, z, row_base, col_base, ocol_base, lane);
+    }
   }
 #ifdef G2_BLKTRACE
   BSTAMP(3);
@@ -469,15 +524,15 @@ extern "C" int ns2_debug_read_blocks(unsigned long long* out, int nblk) {
 }
 #endif
 
-template <int NSPLIT, int EPI, bool F16, int P1 = 0>
+template <int NSPLIT, int EPI, bool F16, int P1 = 0, bool UNI = false>
 static hipError_t launch2_one(const GemmArgs& g, hipStream_t s) {
   const int ntn = (g.N + G2_BN - 1) / G2_BN, ntm = (g.M + G2_BM - 1) / G2_BM;
   const int nz = g.nz > 0 ? g.nz : 1;
   const size_t lds = 8 * EPI_LDS_WAVE_BYTES;          // 144 KiB: 2 x 64 KiB K stages, reused as 8 x 18 KiB epilogue regions
   static DynLdsAttr attr;
-  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, F16, P1>), (int)lds);
+  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, F16, P1, UNI>), (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, F16, P1>), dim3(ntn * ntm * nz), dim3(512), lds, s, g);
+  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, F16, P1, UNI>), dim3(ntn * ntm * nz), dim3(512), lds, s, g);
   return hipGetLastError();
 }
 
@@ -488,9 +543,13 @@ static hipError_t launch2_epi(const GemmArgs& g, hipStream_t s) {
     case EPI_SPLIT: return launch2_one<NSPLIT, EPI_SPLIT, F16>(g, s);
     case EPI_QKV: return launch2_one<NSPLIT, EPI_QKV, F16>(g, s);
     case EPI_GEGLU: return launch2_one<NSPLIT, EPI_GEGLU, F16>(g, s);
-    case EPI_WAVENET:
-      if constexpr (NSPLIT == 2) { if (g.p1_half) return launch2_one<2, EPI_WAVENET, true, 1>(g, s); }
-      return launch2_one<NSPLIT, EPI_WAVENET, F16>(g, s);
+    case EPI_WAVENET: {
+      const bool uni = g.seq_len > 0 && (g.seq_len % 128) == 0 && (g.M % 128) == 0 && (g.N % 64) == 0;   // see gemm2_kernel, UNI
+      if constexpr (NSPLIT == 2) {
+        if (g.p1_half) return uni ? launch2_one<2, EPI_WAVENET, true, 1, true>(g, s) : launch2_one<2, EPI_WAVENET, true, 1, false>(g, s);
+      }
+      return uni ? launch2_one<NSPLIT, EPI_WAVENET, F16, 0, true>(g, s) : launch2_one<NSPLIT, EPI_WAVENET, F16, 0, false>(g, s);
+    }
   }
   return hipErrorInvalidValue;
 }

@@ -6,9 +6,13 @@ pyworld, inflect, num2words, ... none of which are installed here and none of wh
 by the arithmetic of `Model` / `NaturalSpeech2.ddim_sample`.  We pre-populate `sys.modules`
 with inert stand-ins and then execute the reference's own source files unchanged.
 
-Only usable in the build container (where /root/reference exists).  Used by
-`tests/golden/make_golden.py` (fixture generation) and by the CPU-side tests that pin
-`oracle/ns2_oracle.py` against the real reference.  Never imported by the product package.
+Where /root/reference exists (the build container) the reference is imported from there.  On the
+GPU box it is not; there `oracle/_ref/reference_py.tar.gz` (written by `oracle/make_ref.py` from the
+untouched reference sources; git-ignored, travels with the snapshot) is unpacked into a temporary
+directory and imported from it.  Used by `tests/golden/make_golden.py` (fixture generation), by the
+tests that pin `oracle/ns2_oracle.py` against the real reference, by `tests/test_reference_gpu.py`
+(the reference's own `NaturalSpeech2` driving the HIP model) and by `bench.py`'s `cpu_baseline`.
+Never imported by the product package.
 """
 import importlib
 import os
@@ -17,10 +21,35 @@ import types
 import typing
 
 REFERENCE_ROOT = os.environ.get("NS2_REFERENCE_ROOT", "/root/reference")
+ARCHIVE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "reference_py.tar.gz")
+_unpacked = None
+
+
+def reference_source() -> str:
+    """"live" (the reference checkout), "archive" (oracle/_ref, see oracle/make_ref.py) or "" (absent)"""
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "naturalspeech2_pytorch")):
+        return "live"
+    return "archive" if os.path.isfile(ARCHIVE) else ""
 
 
 def reference_available() -> bool:
-    return os.path.isdir(os.path.join(REFERENCE_ROOT, "naturalspeech2_pytorch"))
+    return reference_source() != ""
+
+
+def _reference_root() -> str:
+    global _unpacked
+    if reference_source() == "live":
+        return REFERENCE_ROOT
+    if _unpacked is None:
+        import atexit
+        import shutil
+        import tarfile
+        import tempfile
+        _unpacked = tempfile.mkdtemp(prefix="ns2_ref_")
+        atexit.register(shutil.rmtree, _unpacked, ignore_errors=True)
+        with tarfile.open(ARCHIVE, "r:gz") as tf:
+            tf.extractall(_unpacked)
+    return _unpacked
 
 
 def _mod(name, **attrs):
@@ -72,9 +101,10 @@ def load_reference():
     if _cached is not None:
         return _cached
     if not reference_available():
-        raise RuntimeError(f"reference not present at {REFERENCE_ROOT}")
+        raise RuntimeError(f"reference present neither at {REFERENCE_ROOT} nor as {ARCHIVE} (oracle/make_ref.py)")
     _install_stubs()
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+    root = _reference_root()
+    if root not in sys.path:
+        sys.path.insert(0, root)
     _cached = importlib.import_module("naturalspeech2_pytorch.naturalspeech2_pytorch")
     return _cached
