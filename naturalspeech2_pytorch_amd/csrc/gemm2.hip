@@ -25,6 +25,9 @@
 namespace ns2 {
 
 constexpr int G2_BM = 256, G2_BN = 256;
+#ifndef G2_PHASED
+#define G2_PHASED 1            // -DG2_PHASED=0: the one-barrier-per-tile K loop of rounds 1-2 (A/B builds)
+#endif
 #ifndef G2_CONV3
 #define G2_CONV3 true          // -DG2_CONV3=false: without the tap-shared conv path (A/B builds, tools/ablate_gemm2.sh)
 #endif
@@ -70,11 +73,7 @@ struct KMode {
 // P1 != 0 (EPI_WAVENET only): the first K phase -- the dilated conv taps -- runs in arithmetic P1 instead of NSPLIT, reading
 // the SAME operands: P1 = 1 under NSPLIT = 2 multiplies the IEEE-half parts of the FMT_H8 lines as one product per
 // contraction (64-deep tiles gathered from two lines), the second phase (res_conv) keeps the correction terms.
-// UNI (EPI_WAVENET only, chosen by the launcher): every wave tile lies inside one utterance and is fully valid (seq_len % 128 ==
-// 0, M % 128 == 0, N % 64 == 0), so the FiLM gate between the K phases reads gamma / beta once per column.  A template
-// parameter rather than a run-time branch: two alternative bodies that both rewrite the accumulators cost ~130 VGPRs of
-// tuple copies at their merge point (measured: 87-197 spilled registers, reloaded inside the second K loop).
-template <int NSPLIT, int EPI, bool F16, int P1 = 0, bool UNI = false>
+template <int NSPLIT, int EPI, bool F16, int P1 = 0>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const bf16_t* zero_page = g2_zero_page;
   static_assert(NSPLIT != 2 || F16, "the mixed mode multiplies IEEE-half operands");
@@ -423,20 +422,236 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     }
   };
 
+
+  // ================================================================================================================
+  // Phased K loop (G2_PHASED): the SAME LDS image, DMA pieces and fragment addressing as run_k above, re-scheduled on the
+  // guide's "256^2 8-phase" structure.  run_k waits `vmcnt(0)` + one workgroup barrier per K tile: the tile requested at the
+  // start of tile t must have landed by its end, and the block timeline (profiles/r03_block_timeline_*.txt) shows 54-67 %
+  // MFMA duty -- the K loop waits for DMA latency, not for DMA throughput.  Here:
+  //   * a K tile is consumed in four phases, one accumulator quadrant each: (a, b) = (0,0) (0,1) (1,1) (1,0), quadrant =
+  //     row-tile pair mi in {2a, 2a+1} x column tile ni = b of the wave tile: 8-12 MFMAs = 256-384 matrix-pipe cycles;
+  //   * the tile's operands are four HALF TILES: A0 / A1 = the tile rows with bit 6 clear / set (= the mi < 2 / mi >= 2 rows
+  //     of every wave), B0 / B1 = the W rows with bit 5 clear / set (= ni 0 / 1 of every wave); 16 DMA pieces (16 KiB) each,
+  //     two per wave.  A0 and B0 are read (into registers) in phase 0, B1 in phase 1, A1 in phase 2: a half tile's LDS rows
+  //     are free two phases after its last read and are refilled with the data of tile t + 2 straight away -- half tile X of
+  //     tile u is requested at phase 4u - 6 (A0), 4u - 5 (B0), 4u - 4 (B1), 4u - 3 (A1), five to six phases (>= 1300 matrix
+  //     cycles) before its first read, one half tile per phase, four in flight;
+  //   * one counted `s_waitcnt vmcnt(8)` per phase (everything older than the last four half tiles has landed), raw
+  //     `s_barrier`s (a __syncthreads() would drain the LDS-DMA queue), never vmcnt(0) before the last two tiles;
+  //   * waves 0-3 and 4-7 (one of each per SIMD) run half a phase apart: while one group is in its MFMA cluster (priority 1)
+  //     the other reads fragments and issues DMA, so the SIMD's matrix pipe always has a wave to serve.
+  // Hazards (MI355X_MICROARCH.md "Two waves per SIMD" 7, guide "256^2 8-phase template"): LDS-DMA data is ordered for a
+  // ds_read only by the issuing wave's vmcnt plus a barrier; every wave waits in the load interval of phase p - 1 for the
+  // half tile read in phase p (two barriers in between, also for the lagging group); a half tile is refilled >= 2 phases after
+  // its last read (the reads have retired at the lgkmcnt before that phase's MFMAs, again two barriers earlier).
+  // Accumulation order per accumulator is unchanged: results are bit-identical to run_k.
+  const bf16_t* psrc[4][2];      // [A0, A1, B0, B1][piece]: source row pointer at K offset 0
+  int pnseq[2][2];               // A pieces: position inside the utterance (-1 = row >= M)
+  int pldst[4][2];               // LDS byte offset inside a stage (wave-uniform)
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = 2 * wave + e;                      // piece of the half tile: [0, 16)
+      const int rg = (h < 2) ? ((k & 7) + 16 * (k >> 3) + 8 * h) : ((k & 3) + 8 * (k >> 2) + 4 * (h - 2));   // row group: parity == e
+      const int row = rg * RPI + lrow;
+      pldst[h][e] = (h < 2 ? 0 : REGION) + rg * 1024;
+      if (h < 2) {
+        const long m = (long)tm * G2_BM + row;
+        psrc[h][e] = g.a_hi + pcol((int)(z * g.a_zs), ail) + m * a_rs;
+        pnseq[h][e] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -1;
+      } else {
+        psrc[h][e] = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN + row) * w_rs;
+      }
+    }
+
+  struct TileCoord { int tap, it; };
+  auto tile_coord = [&](auto mode, int kt) __attribute__((always_inline)) {
+    const int tpt = tiles_per_tap(mode);
+    const int nconv = g.conv_taps * tpt;
+    TileCoord c;
+    if (kt < nconv) { c.it = kt / g.conv_taps; c.tap = kt - c.it * g.conv_taps; }      // tap-minor over the shifted taps (see issue_tile)
+    else { c.tap = kt / tpt; c.it = kt - c.tap * tpt; }
+    return c;
+  };
+  // this wave's two pieces of half tile H (0 = A0, 1 = A1, 2 = B0, 3 = B1) of the tile at `c`, into stage `stage`
+  auto issue_half = [&](auto mode, const TileCoord c, int stage, auto hsel) __attribute__((always_inline)) {
+    using M = decltype(mode);
+    constexpr int H = decltype(hsel)::value;
+    constexpr int BK = M::bk;
+    const int tpt = tiles_per_tap(mode);
+    const bool half = !M::line32 && (g.kt_per_tap & 1) && (c.it == tpt - 1);
+    const bool il = (H < 2) ? ail : wil;
+    unsigned char* sbase = smem + stage * STAGE;
+    int coff[2];
+    bool chi[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      coff[e] = M::line32 ? lchunk_par[e] * 8 : pcol(lchunk_par[e] * 8, il);
+      chi[e] = lchunk_par[e] >= 4;
+    }
+    if constexpr (H < 2) {
+      const int pl = g.pad_left < 0 ? g.conv_taps - 1 : g.pad_left;
+      const int shift = (c.tap < g.conv_taps) ? (pl - c.tap) * dil : 0;
+      const unsigned slim = g.seq_len > 0 ? (unsigned)g.seq_len : 0x7fffffffu;
+      const long off = pcol(c.it * BK, ail) - (long)shift * a_rs;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool ok = ((unsigned)(pnseq[H][e] - shift) < slim) && !(half && chi[e]);
+        glds16(ok ? (psrc[H][e] + off + coff[e]) : zero_page, sbase + pldst[H][e]);
+      }
+    } else {
+      const long off = pcol(c.tap * tap_k + c.it * BK, wil);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        glds16((half && chi[e]) ? zero_page : (psrc[H][e] + off + coff[e]), sbase + pldst[H][e]);
+    }
+  };
+  using HA0 = std::integral_constant<int, 0>; using HA1 = std::integral_constant<int, 1>;
+  using HB0 = std::integral_constant<int, 2>; using HB1 = std::integral_constant<int, 3>;
+
+  // fragments of one half tile.  FR = 16-byte fragment reads per row tile: single product 4 (k chunks), bf16 x3 4 (2 planes x 2 k
+  // chunks), mixed 4 (2 half k chunks + the 32 fp8 bytes of the lane's k half)
+  struct AHalf { bf16x8 f[2][4]; };      // [row tile of the pair][read]
+  struct WHalf { bf16x8 f[4]; };
+  auto frag_chunk = [&](auto mode, int j, bool w_side) __attribute__((always_inline)) {     // logical 16-B chunk of read j for this lane
+    using M = decltype(mode);
+    if constexpr (M::ns == 1) return 2 * j + hi;                       // k chunk j of the 64-deep row
+    else if constexpr (M::ns == 3) return 4 * (j >> 1) + 2 * (j & 1) + hi;   // plane j >> 1, k chunk j & 1
+    else return (j < 2) ? (2 * j + hi) : (w_side ? (6 - 2 * hi + (j - 2)) : (4 + 2 * hi + (j - 2)));   // half k chunks, then [h8|l8] / [l8|h8]
+  };
+  auto load_a = [&](auto mode, const unsigned char* sa, const int a_off, const int fz, int a, AHalf& A) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        A.f[i][j] = *reinterpret_cast<const bf16x8*>(sa + a_off + (2 * a + i) * 32 * RB + ((frag_chunk(mode, j, false) ^ fz) * 16));
+  };
+  auto load_w = [&](auto mode, const unsigned char* sw, const int w_off, const int fz, int b, WHalf& W) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      W.f[j] = *reinterpret_cast<const bf16x8*>(sw + w_off + b * 32 * RB + ((frag_chunk(mode, j, true) ^ fz) * 16));
+  };
+  auto mma_quadrant = [&](auto mode, int a, int b, const AHalf& A, const WHalf& W) __attribute__((always_inline)) {
+    using M = decltype(mode);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x16& c = acc[2 * a + i][b];
+      if constexpr (M::ns == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = mma16<F16>(A.f[i][j], W.f[j], c);
+      } else if constexpr (M::ns == 3) {
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {               // per k chunk: lo.hi, hi.lo, hi.hi (the order of compute_tile)
+          c = mma16<F16>(A.f[i][2 + kc], W.f[kc], c);
+          c = mma16<F16>(A.f[i][kc], W.f[2 + kc], c);
+          c = mma16<F16>(A.f[i][kc], W.f[kc], c);
+        }
+      } else {
+        c = mma16<true>(A.f[i][0], W.f[0], c);
+        c = mma16<true>(A.f[i][1], W.f[1], c);
+      }
+    }
+    if constexpr (M::ns == 2) {                         // the correction terms after both half products of the pair (compute_tile's order per accumulator)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int4 a0 = __builtin_bit_cast(int4, A.f[i][2]), a1 = __builtin_bit_cast(int4, A.f[i][3]);
+        const int4 w0 = __builtin_bit_cast(int4, W.f[2]), w1 = __builtin_bit_cast(int4, W.f[3]);
+        const i32x8 a8 = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const i32x8 w8 = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        acc[2 * a + i][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, w8, acc[2 * a + i][b], /*A e5m2*/ 1, /*B e5m2*/ 1,
+                                                                            0, H8_E8M0_LO, 0, H8_E8M0_ONE);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define G2_VMWAIT(fill) do { if (fill) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+
+  auto run_k8 = [&](auto mode, const int kt0, const int kt1) __attribute__((always_inline)) {
+    const int T = kt1 - kt0;
+    if (T <= 0) return;
+    // ---- prologue: tile 0 whole, A0 / B0 of tile 1; A0(0) and B0(0) have landed for every wave at the barrier
+    TileCoord c1 = tile_coord(mode, kt0);               // coordinates of tile t + 1 (in the loop), here: tile 0
+    {
+      const int st = kt0 & 1;
+      issue_half(mode, c1, st, HA0{}); issue_half(mode, c1, st, HB0{}); issue_half(mode, c1, st, HB1{}); issue_half(mode, c1, st, HA1{});
+    }
+    if (T > 1) {
+      c1 = tile_coord(mode, kt0 + 1);
+      issue_half(mode, c1, (kt0 + 1) & 1, HA0{}); issue_half(mode, c1, (kt0 + 1) & 1, HB0{});
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#ifdef G2_BLKTRACE
+    if (bts[1] == 0) BSTAMP(1);
+#endif
+    if (wave >= 4) __builtin_amdgcn_s_barrier();        // the second group runs half a phase behind
+    AHalf A;
+    WHalf W0, W1;
+    for (int t = 0; t < T; ++t) {
+      const int kt = kt0 + t;
+      const unsigned char* sb = smem + (kt & 1) * STAGE;
+      const bool more1 = t + 1 < T, more2 = t + 2 < T;
+      const TileCoord c2 = more2 ? tile_coord(mode, kt + 2) : c1;
+      // ---- phase 0: quadrant (0, 0); request B1 of tile t + 1
+      if (wave_active) { load_a(mode, sb, a_row_off, fswz, 0, A); load_w(mode, sb, w_row_off, fswz, 0, W0); }
+      if (more1) issue_half(mode, c1, (kt + 1) & 1, HB1{});
+      G2_VMWAIT(more1);
+      __builtin_amdgcn_s_barrier();
+      if (wave_active) mma_quadrant(mode, 0, 0, A, W0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 1: quadrant (0, 1); request A1 of tile t + 1
+      if (wave_active) load_w(mode, sb, w_row_off, fswz, 1, W1);
+      if (more1) issue_half(mode, c1, (kt + 1) & 1, HA1{});
+      G2_VMWAIT(more1);
+      __builtin_amdgcn_s_barrier();
+      if (wave_active) mma_quadrant(mode, 0, 1, A, W1);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 2: quadrant (1, 1); request A0 of tile t + 2 (the rows of A0(t) were last read in phase 0)
+      if (wave_active) load_a(mode, sb, a_row_off, fswz, 1, A);
+      if (more2) issue_half(mode, c2, kt & 1, HA0{});
+      G2_VMWAIT(more2);
+      __builtin_amdgcn_s_barrier();
+      if (wave_active) mma_quadrant(mode, 1, 1, A, W1);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 3: quadrant (1, 0); request B0 of tile t + 2
+      if (more2) issue_half(mode, c2, kt & 1, HB0{});
+      G2_VMWAIT(more2);
+      __builtin_amdgcn_s_barrier();
+      if (wave_active) mma_quadrant(mode, 1, 0, A, W0);
+      __builtin_amdgcn_s_barrier();
+      c1 = c2;
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();         // wait for the lagging group's last MFMA phase: LDS is free after this
+  };
+
   if constexpr (EPI == EPI_WAVENET) {
     // phase 1: the taps before mid_kt (dilated conv), phase 2: the rest (res_conv on the unshifted input)
     const int mid_tap = (g.mid_kt > 0) ? g.mid_kt / g.kt_per_tap : 0;
+    const bool mid_uni = g.seq_len > 0 && (g.seq_len & 127) == 0;      // row_base % 128 == 0: the wave tile lies inside one utterance
+    // the one-barrier-per-tile loop: the phased schedule measured 9 % SLOWER on this kernel (two short K phases = two pipeline
+    // ramps per block, and the K loops of this kernel family are bound by LDS-DMA throughput, not by its latency: DESIGN.md)
     run_k(ModeP1{}, 0, mid_tap * tiles_per_tap(ModeP1{}));
-    if constexpr (UNI) wavenet_midgate_fast(acc, g, z, row_base, col_base, l31);
-    else wavenet_midgate<4, 2>(acc, g, z, row_base, col_base, l31, hi);
+    wavenet_midgate<4, 2>(acc, g, z, row_base, col_base, l31, hi, mid_uni);
     run_k(ModeMain{}, mid_tap * tiles_per_tap(ModeMain{}), ntaps * tiles_per_tap(ModeMain{}));
   } else if constexpr (EPI == EPI_SPLIT && G2_CONV3) {
     const bool conv3 = g.conv_taps == 3 && ntaps == 3 && !g.dil_z && g.dil == 1 && g.pad_left < 0 && g.seq_len > 0 &&
                        (g.seq_len % G2_BM) == 0;
     if (conv3) run_k_conv3(ModeMain{});
+#if G2_PHASED
+    else run_k8(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
+#else
     else run_k(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
+#endif
   } else {
+#if G2_PHASED
+    run_k8(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
+#else
     run_k(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
+#endif
   }
   BSTAMP(2);
   // all waves are past the K loop's last barrier: the LDS ring is free, every wave takes a private 18 KiB region
@@ -524,15 +739,15 @@ extern "C" int ns2_debug_read_blocks(unsigned long long* out, int nblk) {
 }
 #endif
 
-template <int NSPLIT, int EPI, bool F16, int P1 = 0, bool UNI = false>
+template <int NSPLIT, int EPI, bool F16, int P1 = 0>
 static hipError_t launch2_one(const GemmArgs& g, hipStream_t s) {
   const int ntn = (g.N + G2_BN - 1) / G2_BN, ntm = (g.M + G2_BM - 1) / G2_BM;
   const int nz = g.nz > 0 ? g.nz : 1;
   const size_t lds = 8 * EPI_LDS_WAVE_BYTES;          // 144 KiB: 2 x 64 KiB K stages, reused as 8 x 18 KiB epilogue regions
   static DynLdsAttr attr;
-  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, F16, P1, UNI>), (int)lds);
+  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, F16, P1>), (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, F16, P1, UNI>), dim3(ntn * ntm * nz), dim3(512), lds, s, g);
+  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, F16, P1>), dim3(ntn * ntm * nz), dim3(512), lds, s, g);
   return hipGetLastError();
 }
 
@@ -543,13 +758,9 @@ static hipError_t launch2_epi(const GemmArgs& g, hipStream_t s) {
     case EPI_SPLIT: return launch2_one<NSPLIT, EPI_SPLIT, F16>(g, s);
     case EPI_QKV: return launch2_one<NSPLIT, EPI_QKV, F16>(g, s);
     case EPI_GEGLU: return launch2_one<NSPLIT, EPI_GEGLU, F16>(g, s);
-    case EPI_WAVENET: {
-      const bool uni = g.seq_len > 0 && (g.seq_len % 128) == 0 && (g.M % 128) == 0 && (g.N % 64) == 0;   // see gemm2_kernel, UNI
-      if constexpr (NSPLIT == 2) {
-        if (g.p1_half) return uni ? launch2_one<2, EPI_WAVENET, true, 1, true>(g, s) : launch2_one<2, EPI_WAVENET, true, 1, false>(g, s);
-      }
-      return uni ? launch2_one<NSPLIT, EPI_WAVENET, F16, 0, true>(g, s) : launch2_one<NSPLIT, EPI_WAVENET, F16, 0, false>(g, s);
-    }
+    case EPI_WAVENET:
+      if constexpr (NSPLIT == 2) { if (g.p1_half) return launch2_one<2, EPI_WAVENET, true, 1>(g, s); }
+      return launch2_one<NSPLIT, EPI_WAVENET, F16>(g, s);
   }
   return hipErrorInvalidValue;
 }

@@ -9,11 +9,15 @@ namespace ns2 {
 
 // WavenetResBlock NS2:629-636: h = conv(x)+b ; h = h*gamma_t+beta_t ; h = tanh(h)*sigmoid(h) ; (then += res_conv(x)).
 // tanh(h)*sigmoid(h) = sign(h) * (1-u) * (h<0 ? u : 1) / (1+u^2),  u = exp(-|h|)   (one exp, no overflow)
+// `uni` (wave-uniform): the wave tile lies inside ONE utterance, so gamma / beta are per column and are loaded once per column tile
+// instead of once per element (with a row / seq_len division each).  The per-element structure (one small diamond per value) is
+// kept on purpose: a straight-line variant of this loop made the register allocator spill 100-300 VGPRs (gemm_epi_fast.h note).
 template <int MI, int NI>
-NS2_DEVINL void wavenet_midgate(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, int row_base, int col_base, int l31, int hi) {
+NS2_DEVINL void wavenet_midgate(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, int row_base, int col_base, int l31, int hi, bool uni = false) {
   const float* film = g.film + (long)z * g.film_zs;
   const float* bias = g.bias + (long)z * g.bias_zs;
   const float* bias2 = g.bias2 + (long)z * g.bias_zs;
+  const float* film_u = film + (long)(uni ? row_base / g.seq_len : 0) * g.film_ld;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -22,14 +26,19 @@ NS2_DEVINL void wavenet_midgate(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z,
       const bool cok = col < g.N;
       const float bc = cok ? bias[col] : 0.f;
       const float b2 = cok ? bias2[col] : 0.f;
+      const float gam_u = (uni && cok) ? film_u[col] : 0.f;
+      const float bet_u = (uni && cok) ? film_u[g.N + col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         float v = 0.f;
         if (cok && row < g.M) {
-          const int b = row / g.seq_len;
-          const float gam = film[(long)b * g.film_ld + col];
-          const float bet = film[(long)b * g.film_ld + g.N + col];
+          float gam = gam_u, bet = bet_u;
+          if (!uni) {
+            const int b = row / g.seq_len;
+            gam = film[(long)b * g.film_ld + col];
+            bet = film[(long)b * g.film_ld + g.N + col];
+          }
           const float h = (acc[mi][ni][r] + bc) * gam + bet;
           const float u = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(h));     // v_exp_f32: <= 1 ulp, |arg| error ~1e-7*|h|
           const float t = (1.f - u) * (h < 0.f ? u : 1.f) * __builtin_amdgcn_rcpf(1.f + u * u);

@@ -12,6 +12,7 @@
 //     one wave-instruction writes whole 128-B / 256-B row segments (the vector-memory path costs ~40-60 cycles per
 //     wave-instruction whatever its width; 4-byte stores were 4-12x as many instructions);
 //   * V^T (EPI_QKV) is transposed in LDS too: 256 contiguous bytes per feature row instead of 8-byte scattered stores;
+//   * the FiLM gate between the Wavenet block's K phases reads gamma / beta once per column (wavenet_midgate's `uni`, gemm_epi.h);
 //   * GEGLU evaluates erfc with a branch-free rational-exponential form (relative error 1.2e-7 everywhere) instead of the
 //     device library's two-branch erff (both branches execute in a divergent wave).
 // Results are bit-identical to the generic path for the plane formats; GEGLU differs by <= ~2e-7 relative (gelu's erf).
@@ -264,38 +265,6 @@ NS2_DEVINL void epi_f32_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_bas
       *reinterpret_cast<float4*>(obase + (long)it * 4 * g.ldo_f) = v;
     }
     __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ---- WavenetResBlock gate between the two K phases (wavenet_midgate of gemm_epi.h) for a wave tile inside ONE utterance and
-// fully valid: FiLM gamma / beta are per column, loaded once per column tile instead of once per element
-NS2_DEVINL void wavenet_midgate_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int z, int row_base, int col_base, int l31) {
-  const int b = row_base / g.seq_len;
-  const float* film = g.film + (long)z * g.film_zs + (long)b * g.film_ld;
-  const float* bias = g.bias + (long)z * g.bias_zs;
-  const float* bias2 = g.bias2 + (long)z * g.bias_zs;
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int col = col_base + ni * 32 + l31;
-    float bcv = bias[col], b2 = bias2[col], gam = film[col], bet = film[g.N + col];
-    // all four have landed before the first chain starts: with a load still in flight the scheduler defers everything that depends
-    // on it (every chain's last two operations) behind all 64 chain heads and spills their ~200 intermediates (measured)
-    asm volatile("" : "+v"(bcv), "+v"(b2), "+v"(gam), "+v"(bet));
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float h = (acc[mi][ni][r] + bcv) * gam + bet;
-        // Each chain is pinned at its head and at its tail.  The empty asm statements keep their order, so chain k is finished
-        // before chain k + 1 starts; left alone, instruction selection emits all 128 chain heads first and spills ~200
-        // intermediates (measured: sched_barrier does not help, the order is already fixed when the DAG is linearised).
-        asm volatile("" : "+v"(h));
-        const float u = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(h));
-        const float t = (1.f - u) * (h < 0.f ? u : 1.f) * __builtin_amdgcn_rcpf(1.f + u * u);
-        float res = copysignf(t, h) + b2;
-        asm volatile("" : "+v"(res));
-        acc[mi][ni][r] = res;
-      }
   }
 }
 
