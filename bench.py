@@ -79,20 +79,38 @@ def physical_cores():
 
 
 def cpu_baseline(sd, dim, depth, B, n):
-    """The CPU oracle (port of NS2:929-1000; attention through F.scaled_dot_product_attention like the reference's default
-    `use_flash_attn=True` branch ATT:98-108) on the FULL batch, once, after a one-utterance warm-up; threads = physical cores."""
+    """The reference timed on the host cores of this box, beside the GPU number (never the target): ONE forward of the full batch
+    after a one-utterance warm-up, fp32, threads = physical cores.
+    kind "reference": the reference's OWN `Model` (NS2:811-1000, default use_flash_attn=True -> CPU SDPA, ATT:98-108), imported
+    unmodified from oracle/_ref/reference_py.tar.gz (oracle/make_ref.py; /root/reference itself does not exist on the GPU box) with
+    the benched weights loaded into it.  kind "port" (only when that archive is absent): the oracle restatement, SDPA attention."""
     import torch
     from oracle import ns2_oracle as O
+    from oracle import ref_stub
     cores = physical_cores()
     old = torch.get_num_threads()
     torch.set_num_threads(cores)
-    O.USE_SDPA = True
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, n, dim, generator=g)
+    t = torch.rand(B, generator=g)
     try:
-        g = torch.Generator().manual_seed(7)
-        x = torch.randn(B, n, dim, generator=g)
-        t = torch.rand(B, generator=g)
+        if ref_stub.reference_available():
+            ns2 = ref_stub.load_reference()
+            ref = ns2.Model(dim=dim, depth=depth).eval()
+            ref.load_state_dict(sd)
+            with torch.no_grad():
+                ref(x[:1], t[:1])                         # warm-up (thread pool, oneDNN primitives)
+                t0 = time.perf_counter()
+                y = ref(x, t)
+                el = time.perf_counter() - t0
+                chk = float(((O.model_forward(sd, x[:1], t[:1]) - y[:1]).norm() / y[:1].norm()).item())   # the oracle against the reference, live
+            return dict(value=round(1.0 / el, 5), unit="steps/s", cores=cores, kind="reference",
+                        sample=f"the reference's own Model.forward (unmodified source, {ref_stub.reference_source()}), fp32, CPU SDPA "
+                               f"attention, ONE forward of the full batch {B} x {n} frames after a 1-utterance warm-up: {el:.2f} s, "
+                               f"{cores} threads = physical cores; oracle-vs-reference rel err on one utterance {chk:.1e}")
+        O.USE_SDPA = True
         with torch.no_grad():
-            O.model_forward(sd, x[:1], t[:1])           # warm-up (thread pool, oneDNN primitives)
+            O.model_forward(sd, x[:1], t[:1])
             t0 = time.perf_counter()
             O.model_forward(sd, x, t)
             el = time.perf_counter() - t0
@@ -101,7 +119,7 @@ def cpu_baseline(sd, dim, depth, B, n):
         torch.set_num_threads(old)
     return dict(value=round(1.0 / el, 5), unit="steps/s", cores=cores, kind="port",
                 sample=f"oracle Model.forward fp32 (SDPA attention), ONE forward of the full batch {B} x {n} frames after a "
-                       f"1-utterance warm-up: {el:.2f} s, {cores} threads = physical cores")
+                       f"1-utterance warm-up: {el:.2f} s, {cores} threads = physical cores (oracle/_ref archive absent)")
 
 
 def free_port():

@@ -151,11 +151,23 @@ int64_t ns2_lstm_state_floats(int B, int H);
 int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_hh, const float* b_hh, float* state, int64_t state_floats,
                    const float* resid, int64_t ld_r, float* out, int64_t ld_o, int B, int64_t T, int H, void* stream);
 
+/* The one-launch-per-layer LSTM recurrence synchronises its 64 workgroups with a device-wide step barrier.  The launcher takes
+ * that path only when the device can hold twice that many of its workgroups (occupancy query); should the barrier still time out
+ * (CU masking, a device saturated by other processes) the kernel gives up -- its output is then incomplete -- and counts the
+ * launch here instead of trapping.  Synchronises; call it after a codec run.  NS2_LSTM_PERSISTENT=0 forces the per-step kernel. */
+int ns2_lstm_abort_count(int reset, int64_t* count);
+
 /* Range guard of precisions 2 and 4 (IEEE-half operands stop at 65504 / 57344; beyond, values are clamped: finite but
  * wrong).  Counts, on the CURRENT device, the conversions that met an out-of-range (or NaN) value since the last reset.
  * Synchronises the device: call it between sampling runs, not per step.  A non-zero count means the model needs
  * precision 3 (bf16 planes: fp32 exponent range). */
 int ns2_saturation_count(int reset, int64_t* count);
+/* The same counters without a synchronisation: enqueues, on `stream`, copies of the four per-translation-unit counters (cumulative
+ * since the last reset) into host4[0..3] -- host memory that stays valid until the stream reaches this point (pinned memory for a
+ * truly asynchronous copy).  The caller records an event behind it and reads the values once the event has completed; the host-side
+ * `Model` does so every few forwards, so that calls from ANY wrapper (this package's sampler, the reference's own
+ * NaturalSpeech2 / Trainer around compat.HipBackedModel, a bare Model.forward) notice clamped activations. */
+int ns2_saturation_peek_async(unsigned int* host4, void* stream);
 
 /* EnCodec RVQ (HFENC:364-369, 424-447; reference call sites NS2:1445, NS2:1611, NS2:1496).
  * cb_norm: [Q, C] scratch filled by ns2_rvq_prepare (once per codebook set). codes: [M, Q] int64; emb/residual [M, D] or null */

@@ -54,7 +54,9 @@ SIGNATURES = {
     "ns2_seanet_unpad": (I, [P, L, I, P, L, I, L, I, P]),
     "ns2_lstm_state_floats": (L, [I, I]),
     "ns2_lstm_layer": (I, [P, L, P, P, P, L, P, L, P, L, I, L, I, P]),
+    "ns2_lstm_abort_count": (I, [I, POINTER(c_int64)]),
     "ns2_saturation_count": (I, [I, POINTER(c_int64)]),
+    "ns2_saturation_peek_async": (I, [P, P]),
     "ns2_rvq_prepare": (I, [P, P, I, I, I, P]),
     "ns2_rvq_encode": (I, [P, P, P, P, P, P, P, I, I, I, I, F, P]),
     "ns2_rvq_decode": (I, [P, P, P, I, I, I, I, P]),

@@ -27,7 +27,7 @@ def _rmsnorm(x, norm, t=None):
     return out * g[:, None] + b[:, None]
 
 
-def _attention(x, attn, heads, context=None, include_queries=False):
+def _attention(x, attn, heads, context=None, include_queries=False, key_mask=None, dropout_p=0.):
     ctx = x if context is None else (torch.cat((x, context), dim=1) if include_queries else context)
     q = attn.to_q(x)
     k, v = attn.to_kv(ctx).chunk(2, dim=-1)
@@ -36,7 +36,8 @@ def _attention(x, attn, heads, context=None, include_queries=False):
     def sp(t):
         return t.reshape(b, t.shape[1], heads, -1).transpose(1, 2)
 
-    o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v))
+    am = None if key_mask is None else key_mask[:, None, None, :].bool()          # ATT:92-94: key-padding mask, True = attend
+    o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v), attn_mask=am, dropout_p=dropout_p)
     return attn.to_out(o.transpose(1, 2).reshape(b, n, -1))
 
 
@@ -110,3 +111,29 @@ def model_forward_autograd(m, x, times, prompt=None, cond=None, cond_drop_prob=N
         h = _feedforward(_rmsnorm(h, getattr(layer, "4"), t), getattr(layer, "5"), True) + h
     tp = m.transformer.to_pred
     return getattr(tp, "1")(_rmsnorm(h, getattr(tp, "0")))
+
+
+# ---- the plain Transformer and the two conditioning encoders under autograd (NS2:1073-1115, 228-341): joint training of
+# prompt_enc / phoneme_enc with the denoiser (NS2:1538-1543) needs gradients through them; the HIP forwards are inference-only.
+def transformer_forward_autograd(tr, x, mask=None):
+    p = tr.dropout if tr.training else 0.
+    for norm1, attn, norm2, ff in tr.layers:
+        x = _attention(_rmsnorm(x, norm1), attn, tr.heads, key_mask=mask, dropout_p=p) + x
+        x = _feedforward(_rmsnorm(x, norm2), ff, False) + x
+    return _rmsnorm(x, tr.norm) if hasattr(tr.norm, "gamma") else x
+
+
+def speech_prompt_encoder_autograd(enc, x):
+    h = x.transpose(1, 2)
+    for m in enc.conv:
+        if isinstance(m, torch.nn.Conv1d):
+            h = F.silu(F.conv1d(h, m.weight, m.bias, padding=enc.padding))
+    return transformer_forward_autograd(enc.transformer, h.transpose(1, 2))
+
+
+def phoneme_encoder_autograd(enc, ids, mask=None):
+    ids = ids.masked_fill(ids < 0, enc.pad_id)
+    h = F.embedding(ids, enc.token_emb.weight)
+    h = F.silu(_causal_conv(h, enc.conv[1]))
+    h = F.dropout(h, enc.conv_dropout, enc.training)
+    return transformer_forward_autograd(enc.transformer, h, mask=mask)

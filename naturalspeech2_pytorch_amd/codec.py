@@ -114,6 +114,8 @@ class EncodecWrapperHIP(nn.Module):
             if self.encoder is None:
                 raise RuntimeError("raw audio needs the SEANet encoder (out of scope of the HIP path): pass encoder=")
             t = x.shape[-1] // self.seq_len_multiple_of * self.seq_len_multiple_of
+            if t == 0:
+                raise ValueError(f"audio shorter than one codec frame ({self.seq_len_multiple_of} samples)")   # x[..., -0:] would keep everything
             x = x[..., -t:] if curtail_from_left else x[..., :t]
             latents = self.encoder(x[:, None]).transpose(1, 2)       # [b, 128, n] -> [b, n, 128]
         else:

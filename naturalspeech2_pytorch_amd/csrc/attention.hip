@@ -16,6 +16,8 @@
 //   * O^T = V^T P^T accumulates with query = lane & 31 again, so the running rescale is a per-lane scalar;
 //   * V arrives already transposed ([b][h*64+d][n]) from the QKV GEMM epilogue (gemm.hip EPI_QKV).
 // NSPLIT = 3 evaluates both products as hi*hi + hi*lo + lo*hi (fp32-class accuracy), NSPLIT = 1 hi only.
+#include <cstdlib>
+
 #include "ns2_common.h"
 #include "ns2_kernels.h"
 
@@ -37,9 +39,15 @@ NS2_DEVINL uint4 mask_chunk(uint4 v, int nvalid) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int NSPLIT, bool F16>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
+// NW waves per workgroup = 32 NW query rows share every staged K / V^T tile.  The vector-memory path of a CU moves ~18 B/clk
+// (profiles/r03_block_timeline_*.txt): with 128-query workgroups every (batch, head) streamed its 256 KiB of K / V^T eight
+// times -- 2 MiB per CU and launch, ~58 us of a 128 us launch at the headline shape; 256-query workgroups halve that.
+template <int NSPLIT, bool F16, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const AttnArgs a) {
   constexpr int NP = (NSPLIT == 3) ? 2 : 1;
+  constexpr int QB = 32 * NW;                        // query rows per workgroup
+  constexpr int NT = 64 * NW;                        // threads
+  constexpr int CPT = 512 / NT;                      // 16-B chunks of one 64 x 64 plane per thread (2 or 1)
   constexpr int STAGE_BYTES = 2 * NP * AT_PLANE;     // K planes then V^T planes
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -47,12 +55,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   const int l31 = lane & 31, hi = lane >> 5;
   // 1-D grid, XCD-aware: the query tiles of one (batch, head) get consecutive remapped ids and therefore share one
   // XCD's L2 for their K / V^T re-reads (rocprofv3 FETCH_SIZE showed ~3x over-fetch with the default round-robin).
-  const int nqt = (a.Nq + 127) / 128;
+  const int nqt = (a.Nq + QB - 1) / QB;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int qt = bid % nqt;
   bid /= nqt;
   const int h = bid % a.H, b = bid / a.H;
-  const int qrow = qt * 128 + wave * 32 + l31;
+  const int qrow = qt * QB + wave * 32 + l31;
   const bool q_ok = qrow < a.Nq;
 
   const bf16_t* q_pl[2] = {a.q_hi, a.q_lo};
@@ -72,19 +80,19 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
       qf[p][c] = *reinterpret_cast<bf16x8*>(&v);
     }
 
-  // ---- staging coordinates: 2 chunks per plane per thread
-  int srow[2], sch[2];
+  // ---- staging coordinates: CPT chunks per plane per thread
+  int srow[CPT], sch[CPT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 256 * i;
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + NT * i;
     srow[i] = c >> 3;
     sch[i] = c & 7;
   }
-  struct Regs { uint4 k[NP][2]; uint4 v[NP][2]; };
+  struct Regs { uint4 k[NP][CPT]; uint4 v[NP][CPT]; };
 
   auto load_tile = [&](Regs& rg, int key0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < CPT; ++i) {
       const int key = key0 + srow[i];
       const bool kok = key < a.Nk;
       const long koff = ((long)b * a.Nk + key) * pld(a.ldk, kil) + pcol(a.k_col0 + h * 64 + sch[i] * 8, kil);
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   auto store_tile = [&](const Regs& rg, int s) {
     unsigned char* base = smem + s * STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < CPT; ++i) {
       const int off = srow[i] * AT_ROWB + sch[i] * 16;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
@@ -254,17 +262,25 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs a) {
   }
 }
 
-template <int NSPLIT, bool F16>
-static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
+template <int NSPLIT, bool F16, int NW>
+static hipError_t launch_attn_w(const AttnArgs& a, hipStream_t s) {
   const size_t lds = 2 * 2 * (NSPLIT == 3 ? 2 : 1) * AT_PLANE;
   static DynLdsAttr attr;
   {
-    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attn_kernel<NSPLIT, F16>), (int)lds);
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attn_kernel<NSPLIT, F16, NW>), (int)lds);
     if (e != hipSuccess) return e;
   }
-  dim3 grid(((a.Nq + 127) / 128) * a.H * a.B);
-  hipLaunchKernelGGL((attn_kernel<NSPLIT, F16>), grid, dim3(256), lds, s, a);
+  dim3 grid(((a.Nq + 32 * NW - 1) / (32 * NW)) * a.H * a.B);
+  hipLaunchKernelGGL((attn_kernel<NSPLIT, F16, NW>), grid, dim3(64 * NW), lds, s, a);
   return hipGetLastError();
+}
+template <int NSPLIT, bool F16>
+static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
+  // 256-query workgroups where the queries fill them and the key sequence is long enough for the K / V^T re-reads to matter
+  const char* e = getenv("NS2_ATTN_NW");
+  const int force = e ? atoi(e) : 0;                   // experiment switch: 4 / 8 forces the workgroup size
+  if (force == 8 || (force != 4 && a.Nq >= 256 && a.Nk >= 256 && (a.Nq % 256) == 0)) return launch_attn_w<NSPLIT, F16, 8>(a, s);
+  return launch_attn_w<NSPLIT, F16, 4>(a, s);
 }
 
 hipError_t launch_attention(const AttnArgs& a_in, int nsplit, hipStream_t s) {

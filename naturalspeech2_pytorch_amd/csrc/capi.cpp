@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 105; }   // 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 106; }   // 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 2, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
   force_gemm_kernel(kernel);
@@ -258,6 +258,25 @@ extern "C" int ns2_saturation_count(int reset, int64_t* count) {
     tot += p;
   }
   *count = tot;
+  return NS2_OK;
+}
+
+extern "C" int ns2_lstm_abort_count(int reset, int64_t* count) {
+  ARGCHK(count != nullptr, "ns2_lstm_abort_count: null pointer");
+  HIPRET(hipDeviceSynchronize());
+  const unsigned int v = lstm_abort_read(reset != 0);
+  ARGCHK(v != ~0u, "ns2_lstm_abort_count: could not read the device counter");
+  *count = v;
+  return NS2_OK;
+}
+
+extern "C" int ns2_saturation_peek_async(unsigned int* host4, void* stream) {
+  ARGCHK(host4 != nullptr, "ns2_saturation_peek_async: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  HIPRET(saturation_peek_gemm(host4 + 0, s));
+  HIPRET(saturation_peek_gemm2(host4 + 1, s));
+  HIPRET(saturation_peek_attention(host4 + 2, s));
+  HIPRET(saturation_peek_elementwise(host4 + 3, s));
   return NS2_OK;
 }
 

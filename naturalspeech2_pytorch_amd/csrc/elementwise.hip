@@ -544,6 +544,7 @@ hipError_t launch_seanet_prep(const float* x, int ldx, int in_prefix, const floa
                               int prefix, int im2col_k, bf16_t* out_hi, bf16_t* out_lo, int ldo, int fmt, hipStream_t s) {
   if (B <= 0 || T <= 0 || C <= 0 || (ldo & 3) || prefix < 0 || prefix >= T || in_prefix < 0) return hipErrorInvalidValue;
   if (im2col_k > 0 ? (ldo < im2col_k || prefix != 0 || add) : ldo < C) return hipErrorInvalidValue;
+  if (im2col_k > 0 && T < im2col_k) return hipErrorInvalidValue;      // the reflected index |p - (k - 1) + j| must stay inside the utterance
   if (!planes_ok(out_hi, out_lo) || (out_lo && (ldo & 31)) || (fmt == FMT_F16 && out_lo) || (fmt == FMT_H8 && !out_lo))
     return hipErrorInvalidValue;
   const long total = (long)B * (prefix + T) * (ldo >> 2);
@@ -624,7 +625,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* xproj, long
 constexpr int LP_UNITS = 8;
 constexpr int LP_LDH = 512 + 4;                   // LDS row stride of the staged h (floats)
 constexpr int LP_MAXB = 32;
-constexpr unsigned LP_SPIN_LIMIT = 1u << 22;      // ~ seconds of polling: a lost workgroup turns into a trap, not a hang
+constexpr unsigned LP_SPIN_LIMIT = 1u << 22;      // ~ seconds of polling: a lost workgroup turns into a reported abort, not a hang
+// launches whose step barrier timed out (a workgroup that never became resident: CU masking, a partitioned device, a GPU
+// saturated by other processes).  The kernel then gives up -- every workgroup leaves at its next barrier -- instead of trapping
+// (a trap kills the HIP context and the process); the host reads this counter after a codec run (ns2_lstm_abort_count).
+__device__ unsigned int ns2_lstm_aborts;
 
 NS2_DEVINL float ld_agent(const float* p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -643,6 +648,7 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* xproj
                                                               unsigned* bar) {
   constexpr int H = 512;
   extern __shared__ __attribute__((aligned(16))) float s_h[];      // [8 BG][LP_LDH]
+  __shared__ int s_abort;
   const int tid = threadIdx.x, kq = tid & 7, r = tid >> 3;
   const int gate = r & 3, u = r >> 2;
   const int j = blockIdx.x * LP_UNITS + u;                         // hidden unit
@@ -747,11 +753,20 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* xproj
       __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = nwg * (unsigned)(t + 1);
       unsigned spins = 0;
+      int gave_up = 0;
       while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (++spins > LP_SPIN_LIMIT) __builtin_trap();
+        ++spins;
+        if ((spins & 1023u) == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = 1; break; }
+        if (spins > LP_SPIN_LIMIT) {               // first to time out: tell the others, count the aborted launch once
+          if (__hip_atomic_exchange(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicAdd(&ns2_lstm_aborts, 1u);
+          gave_up = 1;
+          break;
+        }
       }
+      s_abort = gave_up;
     }
     __syncthreads();
+    if (s_abort) return;                           // wave-uniform: the whole workgroup leaves
   }
 }
 
@@ -762,6 +777,22 @@ static hipError_t launch_lstm_persistent(const float* xproj, long ld_x, const fl
   static DynLdsAttr attr;
   hipError_t e = attr.ensure(reinterpret_cast<const void*>(&lstm_persistent_kernel<BG>), (int)lds);
   if (e != hipSuccess) return e;
+  // The step barrier needs all 64 workgroups resident at once.  Ask the occupancy API (per device, once) and require twice the
+  // grid: the API is known to be one block per CU optimistic in places (MI355X_MICROARCH.md), and a CU-masked or partitioned
+  // device (32 CUs) must not take this path on a borderline count.  hipErrorNotReady = "use the per-step kernel".
+  static std::atomic<int> capacity[DynLdsAttr::kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DynLdsAttr::kMaxDev) return hipErrorNotReady;
+  int cap = capacity[dev].load(std::memory_order_acquire);
+  if (cap == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lstm_persistent_kernel<BG>), 256, lds) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return hipErrorNotReady;
+    cap = per_cu * cus > 0 ? per_cu * cus : -1;
+    capacity[dev].store(cap, std::memory_order_release);
+  }
+  if (cap < 2 * (512 / LP_UNITS)) return hipErrorNotReady;
   hipLaunchKernelGGL((lstm_persistent_kernel<BG>), dim3(512 / LP_UNITS), dim3(256), lds, s, xproj, ld_x, T, w_hh, b_hh, hbuf, resid, ld_r,
                      out, ld_o, B, bar);
   return hipGetLastError();
@@ -789,11 +820,12 @@ hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, c
       hipError_t e = hipMemsetAsync(bar, 0, 64 * sizeof(float), s);
       if (e != hipSuccess) return e;
       switch ((B + 7) / 8) {
-        case 1: return launch_lstm_persistent<1>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s);
-        case 2: return launch_lstm_persistent<2>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s);
-        case 3: return launch_lstm_persistent<3>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s);
-        default: return launch_lstm_persistent<4>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s);
+        case 1: e = launch_lstm_persistent<1>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s); break;
+        case 2: e = launch_lstm_persistent<2>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s); break;
+        case 3: e = launch_lstm_persistent<3>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s); break;
+        default: e = launch_lstm_persistent<4>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s); break;
       }
+      if (e != hipErrorNotReady) return e;         // NotReady: not enough resident workgroups on this device -> the per-step kernel below
     }
   }
   hipError_t e = hipMemsetAsync(h_a, 0, (size_t)B * H * sizeof(float), s);
@@ -807,6 +839,13 @@ hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, c
     hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, s, xproj, ld_x, T, t, w_hh, b_hh, hp, hn, c_state, resid, ld_r, out, ld_o, B, H);
   }
   return hipGetLastError();
+}
+
+unsigned int lstm_abort_read(bool reset) {
+  unsigned int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(ns2_lstm_aborts), sizeof v) != hipSuccess) return ~0u;
+  if (reset && v) { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(ns2_lstm_aborts), &z, sizeof z); }
+  return v;
 }
 
 NS2_DEFINE_SATURATION_READER(elementwise)

@@ -28,6 +28,9 @@ constexpr int G2_BM = 256, G2_BN = 256;
 #ifndef G2_PHASED
 #define G2_PHASED 1            // -DG2_PHASED=0: the one-barrier-per-tile K loop of rounds 1-2 (A/B builds)
 #endif
+#ifndef G2_PHASED_CONV3
+#define G2_PHASED_CONV3 1      // -DG2_PHASED_CONV3=0: the tap-shared conv on the one-barrier-per-step loop (A/B builds)
+#endif
 #ifndef G2_CONV3
 #define G2_CONV3 true          // -DG2_CONV3=false: without the tap-shared conv path (A/B builds, tools/ablate_gemm2.sh)
 #endif
@@ -628,6 +631,122 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     if (wave < 4) __builtin_amdgcn_s_barrier();         // wait for the lagging group's last MFMA phase: LDS is free after this
   };
 
+  // ---- the tap-shared causal conv (run_k_conv3) on the phased schedule.  One step = one (k chunk, tap): A fragments come from the
+  // shared 264-row tile A'(it) (rows shifted by the tap), W from W(it, tap).  Per step four phases as in run_k8; requests:
+  //   phase 0: W.B1 of step + 1      phase 3: W.B0 of step + 2      (a W half tile is requested 5 phases before its first read)
+  //   phases 1, 2 of tap 0 and phase 1 of tap 1: the three 11-piece parts of A'(it + 1) (a whole `it` ahead, other buffer)
+  // A wave issues 2 pieces per W request and 1 or 2 per A' part (33 = 3 x 11 row groups over 8 waves), so the counted waits
+  // differ per wave and tap: before phase 0 of step s + 1 and before phase 1 of step s the wave allows exactly the requests
+  // younger than the half tile it is about to read: 4 (two W halves) + its A' pieces of the previous step.
+  auto run_k8_conv3 = [&](auto mode) __attribute__((always_inline)) {
+    using M = decltype(mode);
+    constexpr int BK = M::bk;
+    constexpr int A_BUF = 264 * RB, W_BUF = REGION;
+    unsigned char* const sA = smem;
+    unsigned char* const sW = smem + 2 * A_BUF;
+    const int tpt = tiles_per_tap(mode);
+    const int nst = 3 * tpt;
+    const bool half_tail = !M::line32 && (g.kt_per_tap & 1);
+    const int m0 = tm * G2_BM;
+    const int n0 = m0 % g.seq_len;
+    const bf16_t* a_base = g.a_hi + pcol((int)(z * g.a_zs), ail) + (long)(m0 - 2) * a_rs;
+    const bf16_t* w_base = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN) * w_rs;
+    const int lc0 = pchunk ^ (lrow >> 1), lc1 = pchunk ^ (4 + (lrow >> 1));
+    const int cofA0 = M::line32 ? lc0 * 8 : pcol(lc0 * 8, ail), cofA1 = M::line32 ? lc1 * 8 : pcol(lc1 * 8, ail);
+    const int cofW0 = M::line32 ? lc0 * 8 : pcol(lc0 * 8, wil), cofW1 = M::line32 ? lc1 * 8 : pcol(lc1 * 8, wil);
+    const bool chi0 = lc0 >= 4, chi1 = lc1 >= 4;
+    const int nA = wave < 3 ? 2 : 1;                          // A' pieces of this wave per 11-piece part
+
+    auto issue_wh = [&](int st, int b) __attribute__((always_inline)) {        // this wave's 2 pieces of half tile B<b> of W(step st)
+      const int it = st / 3, tap = st - 3 * it;
+      const bool half = half_tail && (it == tpt - 1);
+      const long off = pcol(tap * tap_k + it * BK, wil);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = 2 * wave + e;
+        const int rg = (k & 3) + 8 * (k >> 2) + 4 * b;       // parity == e
+        const bf16_t* p = (half && (e ? chi1 : chi0)) ? zero_page : (w_base + (long)(8 * rg + lrow) * w_rs + off + (e ? cofW1 : cofW0));
+        glds16(p, sW + (st & 1) * W_BUF + rg * 1024);
+      }
+    };
+    auto issue_ap = [&](int it, int part) __attribute__((always_inline)) {      // this wave's 1-2 of the 11 pieces of part `part` of A'(it)
+      const bool half = half_tail && (it == tpt - 1);
+      const long off = pcol(it * BK, ail);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (e == 1 && wave >= 3) break;
+        const int j = 11 * part + 8 * e + wave;              // row group [0, 33)
+        const bool par = j & 1;
+        const int row = 8 * j + lrow;                        // A' row: input row m0 - 2 + row
+        const bool ok = (n0 + row - 2 >= 0) && ((long)m0 - 2 + row < g.M) && !(half && (par ? chi1 : chi0));
+        glds16(ok ? (a_base + (long)row * a_rs + off + (par ? cofA1 : cofA0)) : zero_page, sA + (it & 1) * A_BUF + j * 1024);
+      }
+    };
+    auto vmwait = [&](int n) __attribute__((always_inline)) {                   // wave-uniform n in {0, 4, 5, 6, 8}
+      if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    // ---- prologue: A'(0), W(0), B0 of W(1)
+    issue_ap(0, 0); issue_ap(0, 1); issue_ap(0, 2);
+    issue_wh(0, 0); issue_wh(0, 1);
+    if (nst > 1) { issue_wh(1, 0); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#ifdef G2_BLKTRACE
+    if (bts[1] == 0) BSTAMP(1);
+#endif
+    if (wave >= 4) __builtin_amdgcn_s_barrier();
+    const int w_off = (wn * 64 + l31) * RB;
+    AHalf A;
+    WHalf W0, W1;
+    for (int it = 0; it < tpt; ++it) {
+      const bool next_it = it + 1 < tpt;
+      const unsigned char* sa = sA + (it & 1) * A_BUF;
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        const int st = 3 * it + tap;
+        const unsigned char* sw = sW + (st & 1) * W_BUF;
+        const bool more1 = st + 1 < nst, more2 = st + 2 < nst;
+        const int a_off = (wm * 128 + l31 + tap) * RB;
+        const int fz_a = ((l31 + tap) >> 1) & 7;
+        // A' pieces this wave issued in the previous step / issues in this one (younger than the W half tiles it waits for)
+        const int a_prev = (tap == 0) ? 0 : (next_it ? (tap == 1 ? 2 * nA : nA) : 0);
+        const int a_this = next_it ? (tap == 0 ? 2 * nA : (tap == 1 ? nA : 0)) : 0;
+        // ---- phase 0: quadrant (0, 0); request B1 of W(step + 1); B1 of this step must have landed for phase 1
+        if (wave_active) { load_a(mode, sa, a_off, fz_a, 0, A); load_w(mode, sw, w_off, fswz, 0, W0); }
+        if (more1) issue_wh(st + 1, 1);
+        vmwait(more1 ? 4 + a_prev : 0);
+        __builtin_amdgcn_s_barrier();
+        if (wave_active) mma_quadrant(mode, 0, 0, A, W0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 1: quadrant (0, 1); request a part of A'(it + 1)
+        if (wave_active) load_w(mode, sw, w_off, fswz, 1, W1);
+        if (next_it && tap == 0) issue_ap(it + 1, 0);
+        if (next_it && tap == 1) issue_ap(it + 1, 2);
+        __builtin_amdgcn_s_barrier();
+        if (wave_active) mma_quadrant(mode, 0, 1, A, W1);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: quadrant (1, 1)
+        if (wave_active) load_a(mode, sa, a_off, fz_a, 1, A);
+        if (next_it && tap == 0) issue_ap(it + 1, 1);
+        __builtin_amdgcn_s_barrier();
+        if (wave_active) mma_quadrant(mode, 1, 1, A, W1);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3: quadrant (1, 0); request B0 of W(step + 2); B0 of step + 1 (and, before tap 0, A'(it + 1)) must have landed
+        if (more2) issue_wh(st + 2, 0);
+        vmwait(more2 ? 4 + a_this : 0);
+        __builtin_amdgcn_s_barrier();
+        if (wave_active) mma_quadrant(mode, 1, 0, A, W0);
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();
+  };
+
   if constexpr (EPI == EPI_WAVENET) {
     // phase 1: the taps before mid_kt (dilated conv), phase 2: the rest (res_conv on the unshifted input)
     const int mid_tap = (g.mid_kt > 0) ? g.mid_kt / g.kt_per_tap : 0;
@@ -640,7 +759,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   } else if constexpr (EPI == EPI_SPLIT && G2_CONV3) {
     const bool conv3 = g.conv_taps == 3 && ntaps == 3 && !g.dil_z && g.dil == 1 && g.pad_left < 0 && g.seq_len > 0 &&
                        (g.seq_len % G2_BM) == 0;
+#if G2_PHASED && G2_PHASED_CONV3
+    if (conv3) run_k8_conv3(ModeMain{});
+#else
     if (conv3) run_k_conv3(ModeMain{});
+#endif
 #if G2_PHASED
     else run_k8(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
 #else

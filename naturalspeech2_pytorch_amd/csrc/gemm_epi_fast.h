@@ -178,28 +178,6 @@ NS2_DEVINL void epi_vt_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_base
   if constexpr (F16) rt.flush(65504.f);
 }
 
-// erfc(z), relative error < 1.2e-7 for every z (Chebyshev fit of erfc(z) * exp(z^2) in t = 1 / (1 + |z| / 2), Numerical Recipes
-// "erfcc"); branch-free: one v_rcp_f32, nine fmas, one v_exp_f32
-NS2_DEVINL float erfc_fast(float z) {
-  const float az = fabsf(z);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, az, 1.0f));
-  float p = 0.17087277f;
-  p = fmaf(p, t, -0.82215223f);
-  p = fmaf(p, t, 1.48851587f);
-  p = fmaf(p, t, -1.13520398f);
-  p = fmaf(p, t, 0.27886807f);
-  p = fmaf(p, t, -0.18628806f);
-  p = fmaf(p, t, 0.09678418f);
-  p = fmaf(p, t, 0.37409196f);
-  p = fmaf(p, t, 1.00002368f);
-  p = fmaf(p, t, -1.26551223f);
-  const float e = __builtin_amdgcn_exp2f((p - az * az) * 1.4426950408889634f);
-  const float r = t * e;
-  return z >= 0.f ? r : 2.0f - r;
-}
-// gelu(x) = x * Phi(x) = 0.5 * x * erfc(-x / sqrt(2))   (NS2:1006-1007, F.gelu's erf form)
-NS2_DEVINL float gelu_fast(float x) { return 0.5f * x * erfc_fast(-0.70710678118654752440f * x); }
-
 // ---- GEGLU: wave tile = [x(32 cols) | gate(32 cols)] -> 32 output columns gelu(gate) * x
 template <int PF>
 NS2_DEVINL void epi_geglu_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_base, int col_base, int ocol_base, int lane, unsigned char* wbuf) {
@@ -216,8 +194,8 @@ NS2_DEVINL void epi_geglu_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_b
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int rp = 0; rp < 8; ++rp) {
-      float v0 = gelu_fast(acc[mi][1][2 * rp] + bg) * (acc[mi][0][2 * rp] + bx);
-      float v1 = gelu_fast(acc[mi][1][2 * rp + 1] + bg) * (acc[mi][0][2 * rp + 1] + bx);
+      float v0 = gelu_erf(acc[mi][1][2 * rp] + bg) * (acc[mi][0][2 * rp] + bx);
+      float v1 = gelu_erf(acc[mi][1][2 * rp + 1] + bg) * (acc[mi][0][2 * rp + 1] + bx);
       asm volatile("" : "+v"(v0), "+v"(v1));      // finish this pair before the next one starts (see wavenet_midgate_fast)
       const float recv = lane_xor1(odd ? v0 : v1);
       const float c_lo = odd ? recv : v0, c_hi = odd ? v1 : recv;

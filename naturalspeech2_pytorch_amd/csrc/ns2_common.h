@@ -79,6 +79,9 @@ NS2_DEVINL void note_out_of_range(float a, float b, float limit) {
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(ns2_sat_counter), sizeof v) != hipSuccess) return ~0u;     \
     if (reset && v) { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(ns2_sat_counter), &z, sizeof z); } \
     return v;                                                                                         \
+  }                                                                                                   \
+  hipError_t saturation_peek_##tu(unsigned int* dst, hipStream_t s) {                                 \
+    return hipMemcpyFromSymbolAsync(dst, HIP_SYMBOL(ns2_sat_counter), sizeof(unsigned int), 0, hipMemcpyDeviceToHost, s); \
   }
 
 // ---- IEEE half operands ("half" precision: ONE fp16 product per contraction, fp32 accumulate).  fp16 carries 11
@@ -195,7 +198,30 @@ NS2_DEVINL float wave_sum(float v) {
 }
 
 NS2_DEVINL float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
-NS2_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erfc(z), relative error < 1.2e-7 for every z (Chebyshev fit of erfc(z) * exp(z^2) in t = 1 / (1 + |z| / 2), Numerical Recipes
+// "erfcc"); branch-free: one v_rcp_f32, nine fmas, one v_exp_f32
+NS2_DEVINL float erfc_fast(float z) {
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, az, 1.0f));
+  float p = 0.17087277f;
+  p = fmaf(p, t, -0.82215223f);
+  p = fmaf(p, t, 1.48851587f);
+  p = fmaf(p, t, -1.13520398f);
+  p = fmaf(p, t, 0.27886807f);
+  p = fmaf(p, t, -0.18628806f);
+  p = fmaf(p, t, 0.09678418f);
+  p = fmaf(p, t, 0.37409196f);
+  p = fmaf(p, t, 1.00002368f);
+  p = fmaf(p, t, -1.26551223f);
+  const float e = __builtin_amdgcn_exp2f((p - az * az) * 1.4426950408889634f);
+  const float r = t * e;
+  return z >= 0.f ? r : 2.0f - r;
+}
+// gelu(x) = x * Phi(x) = 0.5 * x * erfc(-x / sqrt(2))   (NS2:1006-1007, F.gelu's erf form).  ONE definition for every GEGLU epilogue
+// (both GEMM kernels, fast and generic paths): a row's result must not depend on which path its tile took (batch independence
+// is asserted to 1e-6).  The device library's erff is two divergent branches (~60 instructions in a mixed wave); this is 16.
+NS2_DEVINL float gelu_erf(float x) { return 0.5f * x * erfc_fast(-0.70710678118654752440f * x); }
+
 NS2_DEVINL float siluf(float x) { return x / (1.0f + expf(-x)); }
 
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive ids land on one XCD's L2.

@@ -173,11 +173,18 @@ hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, c
                              float* c_state, long state_floats, const float* resid, long ld_r, float* out, long ld_o, int B,
                              long T, int H, hipStream_t s);
 
+unsigned int lstm_abort_read(bool reset);   // persistent-LSTM launches that gave up at their step barrier since the last reset (synchronising)
+
 // values that left the IEEE-half range in this translation unit's kernels since the last reset (synchronising reads)
 unsigned int saturation_read_gemm(bool reset);
 unsigned int saturation_read_gemm2(bool reset);
 unsigned int saturation_read_attention(bool reset);
 unsigned int saturation_read_elementwise(bool reset);
+// stream-ordered, non-synchronising copy of the same counter into (pinned) host memory
+hipError_t saturation_peek_gemm(unsigned int* dst, hipStream_t s);
+hipError_t saturation_peek_gemm2(unsigned int* dst, hipStream_t s);
+hipError_t saturation_peek_attention(unsigned int* dst, hipStream_t s);
+hipError_t saturation_peek_elementwise(unsigned int* dst, hipStream_t s);
 
 hipError_t launch_rvq_prepare(const float* codebooks, float* cb_norm, int Q, int C, int D, hipStream_t s);
 hipError_t launch_rvq_encode(const RvqArgs& a, hipStream_t s);

@@ -44,9 +44,17 @@ class SpeechPromptEncoder(nn.Module):
                                        use_flash=use_flash_attn, precision=precision)
         self._stack = _ConvStack()
 
-    @torch.no_grad()
     def forward(self, x):
+        """Under autograd (the reference trains prompt_enc jointly, NS2:1542-1543) the differentiable composite runs; inference
+        runs in the HIP kernels."""
         assert x.shape[-1] == self.dim
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .autograd_path import speech_prompt_encoder_autograd
+            return speech_prompt_encoder_autograd(self, x)
+        return self._forward_hip(x)
+
+    @torch.no_grad()
+    def _forward_hip(self, x):
         b, n, _ = x.shape
         prec = _PRECISIONS[self.precision]
         convs = [m for m in self.conv if isinstance(m, nn.Conv1d)]
@@ -58,7 +66,7 @@ class SpeechPromptEncoder(nn.Module):
                 h = ops.linear_split(pw, h, **kw)
             else:
                 h = ops.linear_f32(pw, h, **kw)
-        return self.transformer(h.reshape(b, n, self.dim_out)).to(x.dtype)
+        return self.transformer._forward_hip(h.reshape(b, n, self.dim_out)).to(x.dtype)
 
 
 class PhonemeEncoder(nn.Module):
@@ -72,20 +80,26 @@ class PhonemeEncoder(nn.Module):
         self.token_emb = nn.Embedding(num_tokens + 1, dim)
         self.pad_id = num_tokens
         assert precision in _PRECISIONS, f"precision must be one of {sorted(_PRECISIONS)}"
-        self.kernel_size, self.dim_hidden, self.precision = kernel_size, dim_hidden, precision
+        self.kernel_size, self.dim_hidden, self.precision, self.conv_dropout = kernel_size, dim_hidden, precision, conv_dropout
         self.conv = nn.Sequential(_NoParams(), nn.Conv1d(dim, dim_hidden, kernel_size), _NoParams(), _NoParams(), _NoParams())
         self.transformer = Transformer(dim=dim_hidden, depth=depth, dim_head=dim_head, heads=heads, dropout=attn_dropout,
                                        use_flash=use_flash, precision=precision)
         self._stack = _ConvStack()
 
-    @torch.no_grad()
     def forward(self, x, mask=None):
         if not torch.is_tensor(x):
             raise NotImplementedError("List[str] input needs the tokenizer / espeak front-end (out of scope); pass token ids")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd_path import phoneme_encoder_autograd
+            return phoneme_encoder_autograd(self, x, mask)
+        return self._forward_hip(x, mask)
+
+    @torch.no_grad()
+    def _forward_hip(self, x, mask=None):
         b, n = x.shape
         prec = _PRECISIONS[self.precision]
         emb = ops.embedding(x, self.token_emb.weight.detach().float().contiguous(), self.pad_id)     # NS2:281-284
         (pw, bias), = self._stack.packed_for([self.conv[1]], prec)
         h = ops.linear_f32(pw, ops.split(emb.reshape(b * n, -1), precision=prec), bias=bias, conv_taps=self.kernel_size, dilation=1, seq_len=n,
                            pad_left=-1, act=1, precision=prec)                                        # CausalConv1d + SiLU
-        return self.transformer(h.reshape(b, n, self.dim_hidden), mask=mask)
+        return self.transformer._forward_hip(h.reshape(b, n, self.dim_hidden), mask=mask)

@@ -14,6 +14,7 @@ initialisation; their arithmetic lives in HIP.  PyTorch provides device memory a
 """
 import ctypes
 import math
+import time
 from typing import Optional
 
 import torch
@@ -99,6 +100,16 @@ class _NativeState:
         self.ws = None
         self.cond_cache = {}
         self.keepalive = None
+        # staleness / range guards (HipDenoiserMixin._guards)
+        self.last_call = None            # wall clock of the last HIP forward
+        self.calls_since_refresh = 0
+        self.mode_flag = None            # module.training at the last HIP forward
+        self.autograd_seen = False       # an autograd forward ran since the last HIP forward (a training step happened)
+        self.sat_pinned = None           # pinned int32[4]: target of ns2_saturation_peek_async
+        self.sat_event = None
+        self.sat_seen = 0                # counter total already accounted for
+        self.calls_since_peek = 0
+        self.peek_now = True             # read the counters right behind the next forward (first forward of a run)
 
     def __deepcopy__(self, memo):
         return _NativeState()
@@ -119,6 +130,7 @@ class _NativeState:
         self.sig = None
         self.fingerprint = None
         self.cond_cache = {}
+        self.sat_event = None
 
     def __del__(self):
         self.release()
@@ -144,22 +156,89 @@ class HipDenoiserMixin:
         self.precision = precision
         self._native = _NativeState()
 
-    # ---- cache invalidation: version counters do not see `.data` writes
+    # ---- cache invalidation: version counters do not see `.data` writes (ema_pytorch updates its shadow model that way)
+    REFRESH_IDLE_S = 0.25      # a pause this long between two HIP forwards marks a new sampling run
+    REFRESH_EVERY = 256        # ... and the content check runs at least this often inside a run
+    SAT_PEEK_EVERY = 16        # forwards between two asynchronous reads of the range-guard counters
+
     def invalidate(self):
         """drop the packed weights; the next inference forward re-packs from the current parameters"""
         self._native.release()
 
     def refresh_weights(self):
-        """re-pack iff the parameter CONTENTS changed since they were packed (one device reduction + one host read).
-        `NaturalSpeech2.sample` calls this once per sampling run, which covers EMA shadow models updated through `.data`."""
+        """re-pack iff the parameter CONTENTS changed since they were packed (one device reduction + one host read)."""
         ns = self._native
         if ns.handle is None:
             return False
+        ns.calls_since_refresh = 0
         fp = tensors_fingerprint(list(self.parameters()))
         if fp != ns.fingerprint:
             ns.release()
             return True
         return False
+
+    def _guards(self):
+        """Called at the top of every HIP forward, whoever the caller is (this package's sampler, the reference's own
+        `NaturalSpeech2` / `Trainer` around `compat.HipBackedModel`, a bare `Model.forward`):
+
+          * staleness: `(data_ptr, _version)` cannot see writes through `.data`.  The content fingerprint (a device reduction + a
+            host read, i.e. a synchronisation) is therefore re-taken at every RUN BOUNDARY -- the first HIP forward after a pause of
+            REFRESH_IDLE_S, after an autograd forward (a training step), after a train()/eval() flip -- and every REFRESH_EVERY
+            forwards inside a run.  Sampling steps are enqueued milliseconds apart and pay nothing;
+          * range: in the IEEE-half modes a clamped activation is finite but wrong.  Every SAT_PEEK_EVERY forwards the per-device
+            counters are copied to pinned memory behind the step (no synchronisation) and looked at on a later call; a new count
+            raises Ns2Error.  `check_saturation(sync=True)` closes a run (the sampler of this package calls it)."""
+        ns = self._native
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return                           # inside a HIP-graph capture nothing may synchronise; the caller checked before capturing
+        now = time.monotonic()
+        if ns.handle is not None:
+            boundary = (ns.last_call is None or now - ns.last_call > self.REFRESH_IDLE_S or ns.autograd_seen
+                        or ns.mode_flag != self.training or ns.calls_since_refresh >= self.REFRESH_EVERY)
+            if boundary:
+                self.refresh_weights()
+                ns.peek_now = True
+        ns.autograd_seen, ns.mode_flag = False, self.training     # (last_call is stamped when the forward has been enqueued)
+        ns.calls_since_refresh += 1
+        self.check_saturation(sync=False)
+
+    def _range_guarded(self):
+        return self.precision in ("half", "mixed", "hybrid")
+
+    def check_saturation(self, sync=False):
+        """look at the last asynchronous counter read (sync=True: take one now and wait for it); raises Ns2Error on a new count"""
+        ns = self._native
+        if not self._range_guarded() or ns.handle is None:
+            return
+        if sync:
+            self._peek_saturation()
+        ev = ns.sat_event
+        if ev is None or not (sync or ev.query()):
+            return
+        if sync:
+            ev.synchronize()
+        ns.sat_event = None
+        tot = int(ns.sat_pinned.sum().item())
+        new, ns.sat_seen = tot - ns.sat_seen, tot
+        if new > 0:
+            raise _lib.Ns2Error(
+                f"{new} activation conversions left the IEEE-half range (|x| > 65504) at precision='{self.precision}': the "
+                f"results of the last forwards are clamped and wrong.  Use precision='exact' (bf16 planes keep the fp32 exponent "
+                f"range) for this checkpoint.")
+
+    def _peek_saturation(self):
+        ns = self._native
+        dev = next(self.parameters()).device
+        if ns.sat_pinned is None:
+            ns.sat_pinned = torch.zeros(4, dtype=torch.int32).pin_memory()
+        with torch.cuda.device(dev):
+            if ns.sat_event is not None:
+                ns.sat_event.synchronize()          # the pinned words are about to be rewritten
+            check(_lib.load().ns2_saturation_peek_async(ns.sat_pinned.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                  "ns2_saturation_peek_async")
+            ns.sat_event = torch.cuda.Event()
+            ns.sat_event.record()
+        ns.calls_since_peek = 0
 
     def _apply(self, fn, *args, **kwargs):               # .to() / .cuda() / .float(): parameters move or are rewritten
         out = super()._apply(fn, *args, **kwargs)
@@ -210,6 +289,11 @@ class HipDenoiserMixin:
         ns.sig = sig
         ns.fingerprint = tensors_fingerprint(list(self.parameters()))
         ns.cond_cache = {}
+        ns.calls_since_refresh = 0
+        if self._range_guarded():          # what the device counters hold already (other models, earlier runs) is not ours
+            from . import ops
+            ns.sat_seen = ops.saturation_count(reset=False, device=dev)
+            ns.sat_event = None
         return ns
 
     def _workspace(self, ns, B, N, n_prompt, n_cond):
@@ -248,6 +332,7 @@ class HipDenoiserMixin:
         if needs_grad or stochastic:
             # training (loss.backward(), NS2:1635/1886) and per-utterance stochastic conditioning dropout (a training /
             # validation feature, NS2:79-85) run the differentiable PyTorch composite; sampling never gets here
+            self._native.autograd_seen = True
             return self._forward_autograd(x, times, prompt=prompt, prompt_mask=prompt_mask, cond=cond, cond_drop_prob=cond_drop_prob)
         return self._forward_hip(x, times, prompt, prompt_mask, cond, cond_drop_prob)
 
@@ -260,6 +345,7 @@ class HipDenoiserMixin:
         if conditional and p not in (0, 0., 1, 1.):
             raise NotImplementedError("the HIP inference path supports cond_drop_prob 0 or 1 (what forward_with_cond_scale uses)")
         dim = self._hip_cfg["dim"]
+        self._guards()
         ns = self._ensure_native()
         assert x.ndim == 3 and x.shape[-1] == dim, f"x must be [b, n, {dim}]"
         B, N, _ = x.shape
@@ -279,6 +365,12 @@ class HipDenoiserMixin:
             ws = self._workspace(ns, B, N, 0, 0)
         check(_lib.load().ns2_model_forward(ns.handle, xin.data_ptr(), t.data_ptr(), state_ptr, n_c, out.data_ptr(), B, N,
                                             ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "ns2_model_forward")
+        if self._range_guarded() and not torch.cuda.is_current_stream_capturing():
+            ns.calls_since_peek += 1
+            if ns.sat_event is None and (ns.peek_now or ns.calls_since_peek >= self.SAT_PEEK_EVERY):
+                self._peek_saturation()
+                ns.peek_now = False
+        ns.last_call = time.monotonic()
         return out if out.dtype == x.dtype else out.to(x.dtype)
 
     def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):

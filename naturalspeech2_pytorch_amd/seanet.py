@@ -202,6 +202,14 @@ class _SEANetHIP(nn.Module):
             check(lib.ns2_lstm_layer(xproj.data_ptr(), 4 * H, l["w_hh"].data_ptr(), l["b_hh"].data_ptr(), state.data_ptr(), nstate,
                                      ops._p(resid), H, out.data_ptr(), H, B, T, H, _stream()), "ns2_lstm_layer")
             x = out
+        import ctypes
+        n = ctypes.c_int64(0)
+        check(lib.ns2_lstm_abort_count(1, ctypes.byref(n)), "ns2_lstm_abort_count")       # one synchronisation per codec run
+        if n.value:
+            raise _lib.Ns2Error(
+                f"the persistent LSTM recurrence gave up at its device-wide step barrier in {n.value} launch(es): not all of its "
+                f"workgroups were resident (CU masking / a device shared with other work).  Set NS2_LSTM_PERSISTENT=0 to use the "
+                f"one-launch-per-step recurrence.")
         return _Act(x, B, T, H, 0)
 
     @torch.no_grad()

@@ -44,9 +44,22 @@ class Transformer(nn.Module):
                 w2=ops.PackedWeight(w2.weight.detach().float().contiguous(), precision=prec), b2=w2.bias.detach().float().contiguous()))
         return packed
 
-    @torch.no_grad()
+    def _needs_autograd(self, x):
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+
     def forward(self, x, mask=None):
-        """x [b, n, dim]; mask: optional bool [b, n] key-padding mask (True = attend)."""
+        """x [b, n, dim]; mask: optional bool [b, n] key-padding mask (True = attend).  Under autograd (training: the reference
+        trains its encoders jointly with the denoiser, NS2:1538-1543) the differentiable composite of autograd_path.py runs
+        instead of the forward-only HIP kernels."""
+        if self.causal:
+            raise NotImplementedError("causal=True is not used by any reference caller of Transformer (NS2:252, 315)")
+        if self._needs_autograd(x):
+            from .autograd_path import transformer_forward_autograd
+            return transformer_forward_autograd(self, x, mask)
+        return self._forward_hip(x, mask)
+
+    @torch.no_grad()
+    def _forward_hip(self, x, mask=None):
         if self.causal:
             raise NotImplementedError("causal=True is not used by any reference caller of Transformer (NS2:252, 315)")
         if self.training and self.dropout > 0:

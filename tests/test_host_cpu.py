@@ -271,3 +271,41 @@ def test_parity_record_merges_key_by_key(tmp_path, monkeypatch):
     got = json.load(open(scratch))
     assert got["a"] == 10 and got["b"] == {"max": 2} and got["c"] == 3
     assert got["_meta"]["updated_keys_r03"] == ["a", "c"]
+
+
+def test_conditional_training_reaches_the_encoders():
+    """the conditional NaturalSpeech2.forward in its default train() mode (SpeechPromptEncoder dropout 0.2) must run
+    and give prompt_enc gradients -- the reference trains it jointly (NS2:1542-1543).  Under autograd the encoders run the
+    differentiable composite (autograd_path.py); the HIP forwards stay inference-only."""
+    from naturalspeech2_pytorch_amd import Model, NaturalSpeech2
+    torch.manual_seed(0)
+    m = Model(dim=64, depth=1, dim_prompt=512, condition_on_prompt=True)
+    d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, dim_codebook=32)
+    d.train()
+    audio = torch.randn(2, 24, 64)
+    prompt = torch.randn(2, 10, 32)                   # codec latents of the prompt [b, n_p, dim_codebook]
+    cond = torch.randn(2, 512, 24)
+    loss = d(audio, prompt=prompt, cond=cond)
+    loss.backward()
+    g = [p.grad for p in d.prompt_enc.parameters()]
+    assert all(x is not None for x in g) and sum(float(x.abs().sum()) for x in g) > 0
+    assert all(p.grad is not None for p in m.parameters() if p.requires_grad and p.numel() and p is not m.null_cond
+               and p is not m.null_prompt_cond and p is not m.null_prompt_tokens)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="live reference only exists in the build container")
+def test_encoder_composites_equal_the_reference():
+    from oracle.ref_stub import load_reference
+    from naturalspeech2_pytorch_amd.encoders import PhonemeEncoder, SpeechPromptEncoder
+    ns2 = load_reference()
+    torch.manual_seed(0)
+    r = ns2.SpeechPromptEncoder(dim_codebook=32, dims=(48, 64), depth=2, dropout=0.)
+    o = SpeechPromptEncoder(dim_codebook=32, dims=(48, 64), depth=2, dropout=0.)
+    o.load_state_dict(r.state_dict())
+    x = torch.randn(2, 20, 32, requires_grad=True)
+    assert torch.allclose(r(x), o(x), atol=1e-6)
+    r = ns2.PhonemeEncoder(num_tokens=50, dim=32, dim_hidden=64, depth=2, conv_dropout=0.).eval()
+    o = PhonemeEncoder(num_tokens=50, dim=32, dim_hidden=64, depth=2, conv_dropout=0.).eval()
+    o.load_state_dict(r.state_dict())
+    ids = torch.randint(0, 50, (2, 17)); ids[1, 12:] = -1
+    assert torch.allclose(r(ids, mask=ids >= 0), o(ids, mask=ids >= 0), atol=1e-5)
