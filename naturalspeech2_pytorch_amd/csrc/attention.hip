@@ -16,8 +16,6 @@
 //   * O^T = V^T P^T accumulates with query = lane & 31 again, so the running rescale is a per-lane scalar;
 //   * V arrives already transposed ([b][h*64+d][n]) from the QKV GEMM epilogue (gemm.hip EPI_QKV).
 // NSPLIT = 3 evaluates both products as hi*hi + hi*lo + lo*hi (fp32-class accuracy), NSPLIT = 1 hi only.
-#include <cstdlib>
-
 #include "ns2_common.h"
 #include "ns2_kernels.h"
 
@@ -39,11 +37,14 @@ NS2_DEVINL uint4 mask_chunk(uint4 v, int nvalid) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// NW waves per workgroup = 32 NW query rows share every staged K / V^T tile.  The vector-memory path of a CU moves ~18 B/clk
-// (profiles/r03_block_timeline_*.txt): with 128-query workgroups every (batch, head) streamed its 256 KiB of K / V^T eight
-// times -- 2 MiB per CU and launch, ~58 us of a 128 us launch at the headline shape; 256-query workgroups halve that.
+// NW waves per workgroup = 32 NW query rows share every staged K / V^T tile.  NW = 8 (256-query workgroups, half the K / V^T
+// re-reads) was built and measured neutral (0.1434 vs 0.1439 ms): the re-reads are not what bounds this kernel; NW = 4 is used.
+// Occupancy: the single-product kernel compiled to 169 VGPRs -- one register over the 168 that let three waves share a SIMD.  Asked
+// for three (one 4-byte spill outside the loop) it runs 9.5 % faster at the headline shape (0.1439 -> 0.1302 ms, 478 -> 528 TF):
+// the loop is VALU-bound (softmax) and lock-stepped by one barrier per tile, so a third wave per SIMD is what overlaps one
+// wave's exp / max / convert work with another's MFMAs.  Four waves (<= 128 VGPRs) spills 60+ registers.
 template <int NSPLIT, bool F16, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(const AttnArgs a) {
   constexpr int NP = (NSPLIT == 3) ? 2 : 1;
   constexpr int QB = 32 * NW;                        // query rows per workgroup
   constexpr int NT = 64 * NW;                        // threads
@@ -275,13 +276,7 @@ static hipError_t launch_attn_w(const AttnArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 template <int NSPLIT, bool F16>
-static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
-  // 256-query workgroups where the queries fill them and the key sequence is long enough for the K / V^T re-reads to matter
-  const char* e = getenv("NS2_ATTN_NW");
-  const int force = e ? atoi(e) : 0;                   // experiment switch: 4 / 8 forces the workgroup size
-  if (force == 8 || (force != 4 && a.Nq >= 256 && a.Nk >= 256 && (a.Nq % 256) == 0)) return launch_attn_w<NSPLIT, F16, 8>(a, s);
-  return launch_attn_w<NSPLIT, F16, 4>(a, s);
-}
+static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) { return launch_attn_w<NSPLIT, F16, 4>(a, s); }
 
 hipError_t launch_attention(const AttnArgs& a_in, int nsplit, hipStream_t s) {
   AttnArgs a = a_in;

@@ -642,10 +642,13 @@ NS2_DEVINL void st_agent(float* p, float v) {
   __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int BG>                                 // batch rows in groups of 8: B <= 8 BG
+// Batch rows are independent through the recurrence: blockIdx.y selects a group of 8 BG rows with its OWN step barrier (64
+// workgroups each).  Round 3: B = 32 runs as four 8-row groups side by side (256 workgroups, one per CU) instead of one group of
+// 32 rows -- the per-step cost (h staging 64 KiB per workgroup + 2048 FMAs per thread) was 21.4 us, four times the 8-row step.
+template <int BG>                                 // batch rows per group in units of 8
 __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* xproj, long ld_x, long T, const float* w_hh, const float* b_hh,
-                                                              float* hbuf, const float* resid, long ld_r, float* out, long ld_o, int B,
-                                                              unsigned* bar) {
+                                                              float* hbuf, const float* resid, long ld_r, float* out, long ld_o, int B_all,
+                                                              unsigned* bar_all) {
   constexpr int H = 512;
   extern __shared__ __attribute__((aligned(16))) float s_h[];      // [8 BG][LP_LDH]
   __shared__ int s_abort;
@@ -653,6 +656,14 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* xproj
   const int gate = r & 3, u = r >> 2;
   const int j = blockIdx.x * LP_UNITS + u;                         // hidden unit
   const unsigned nwg = gridDim.x;
+  // this group's rows [b_off, b_off + 8 BG): shift every per-row pointer, keep the group-local indexing below
+  const int b_off = blockIdx.y * 8 * BG;
+  const int B = min(B_all - b_off, 8 * BG);
+  unsigned* bar = bar_all + 16 * blockIdx.y;                        // one 64-byte line per group: {arrival counter, abort flag}
+  xproj += (long)b_off * T * ld_x;
+  hbuf += (long)b_off * H;
+  out += (long)b_off * T * ld_o;
+  if (resid) resid += (long)b_off * T * ld_r;
 
   float w[64];
   {
@@ -774,10 +785,12 @@ template <int BG>
 static hipError_t launch_lstm_persistent(const float* xproj, long ld_x, const float* w_hh, const float* b_hh, float* hbuf, unsigned* bar,
                                          const float* resid, long ld_r, float* out, long ld_o, int B, long T, hipStream_t s) {
   const size_t lds = (size_t)8 * BG * LP_LDH * sizeof(float);
+  const int ngroups = (B + 8 * BG - 1) / (8 * BG);
+  const int nwg = (512 / LP_UNITS) * ngroups;
   static DynLdsAttr attr;
   hipError_t e = attr.ensure(reinterpret_cast<const void*>(&lstm_persistent_kernel<BG>), (int)lds);
   if (e != hipSuccess) return e;
-  // The step barrier needs all 64 workgroups resident at once.  Ask the occupancy API (per device, once) and require twice the
+  // The step barriers need every workgroup resident at once.  Ask the occupancy API (per device, once) and require twice the
   // grid: the API is known to be one block per CU optimistic in places (MI355X_MICROARCH.md), and a CU-masked or partitioned
   // device (32 CUs) must not take this path on a borderline count.  hipErrorNotReady = "use the per-step kernel".
   static std::atomic<int> capacity[DynLdsAttr::kMaxDev];
@@ -792,8 +805,8 @@ static hipError_t launch_lstm_persistent(const float* xproj, long ld_x, const fl
     cap = per_cu * cus > 0 ? per_cu * cus : -1;
     capacity[dev].store(cap, std::memory_order_release);
   }
-  if (cap < 2 * (512 / LP_UNITS)) return hipErrorNotReady;
-  hipLaunchKernelGGL((lstm_persistent_kernel<BG>), dim3(512 / LP_UNITS), dim3(256), lds, s, xproj, ld_x, T, w_hh, b_hh, hbuf, resid, ld_r,
+  if (cap < 2 * nwg) return hipErrorNotReady;
+  hipLaunchKernelGGL((lstm_persistent_kernel<BG>), dim3(512 / LP_UNITS, ngroups), dim3(256), lds, s, xproj, ld_x, T, w_hh, b_hh, hbuf, resid, ld_r,
                      out, ld_o, B, bar);
   return hipGetLastError();
 }
@@ -819,12 +832,10 @@ hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, c
       unsigned* bar = reinterpret_cast<unsigned*>(h_a + 2L * LP_MAXB * 512);
       hipError_t e = hipMemsetAsync(bar, 0, 64 * sizeof(float), s);
       if (e != hipSuccess) return e;
-      switch ((B + 7) / 8) {
-        case 1: e = launch_lstm_persistent<1>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s); break;
-        case 2: e = launch_lstm_persistent<2>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s); break;
-        case 3: e = launch_lstm_persistent<3>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s); break;
-        default: e = launch_lstm_persistent<4>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s); break;
-      }
+      // 8-row groups side by side (see the kernel); a single group of up to 32 rows (BG = 4) remains for devices too small
+      // to hold 64 workgroups per group twice over
+      e = launch_lstm_persistent<1>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s);
+      if (e == hipErrorNotReady && B > 8) e = launch_lstm_persistent<4>(xproj, ld_x, w_hh, b_hh, hbuf, bar, resid, ld_r, out, ld_o, B, T, s);
       if (e != hipErrorNotReady) return e;         // NotReady: not enough resident workgroups on this device -> the per-step kernel below
     }
   }
