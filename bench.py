@@ -37,6 +37,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PMC_TRAFFIC = "r03_pmc_traffic.json"  # profiles/: committed PMC profile of the dominant kernel (tools/final_profile_r3.sh)
 PARITY_RECORD = "r03_parity.json"    # profiles/: the tracked key-wise parity record (tests/parity_record.py)
 PEAK_16BIT_TFLOPS = 2500.0         # dense bf16 / f16 MFMA peak, MI355X_MICROARCH.md (spec; 2495 measured)
 PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (RVQ)
@@ -267,12 +268,12 @@ def main():
         avg_ms = kern_ms_v / kern_n_v
         ach = (fl / nl) / (avg_ms * 1e-3) / 1e12
         traffic, tsrc = None, None
-        pj = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        pj = os.path.join(ROOT, "profiles", PMC_TRAFFIC)
         if os.path.exists(pj) and (dim, depth) == (512, 12):
             tj = json.load(open(pj))
             traffic = tj.get("hbm_bytes_per_launch_by_precision", {}).get(precision)
             if traffic is not None:
-                tsrc = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command "
+                tsrc = (f"profiles/{PMC_TRAFFIC}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command "
                         "(tools/pmc_bench.sh), read side doubled per MI355X_MICROARCH.md; a committed profile, NOT measured in this run")
         what = f"FF causal conv k3 x{depth}" + ("" if precision == "hybrid" else ", wavenet init conv, skip-sum GEMM") + \
                (f", cross-attention q projection x{depth}" if conditioned and precision != "hybrid" else "")
@@ -392,15 +393,27 @@ def main():
             ndiff = int((codes_c[:2] != codes_hf).any(dim=-1).sum())
             dec_err = float(((rec[:2] - rec_hf).double().norm() / rec_hf.double().norm()).item())
             secs = nb * nf * 320 / 24000.0
+            # algorithmic work of the encode, counted from the layer shapes (seanet.py): 2 x MACs of every conv / LSTM Linear + the
+            # 8-stage RVQ; compulsory bytes = audio in + latents / codes out + fp32 weights.  The arithmetic is bf16 x3 (3 MFMA units
+            # per FLOP), so the MFMA floor is 3 x flops / 2.5 PF; the measured time is far above both floors: the path is bound by
+            # its 2 x 1024 dependent LSTM steps and by the HBM passes over the early, wide activations (prep -> GEMM -> unpad).
+            fl_enc, by_enc = codec.encoder.algorithmic_work(nb, nf * 320, 1)
+            fl_enc += 2.0 * nb * nf * 128 * 1024 * 8
+            by_enc += nb * nf * 8 * 8
             side["codec_seanet_rvq"] = dict(
                 metric=f"EnCodec 24 kHz front end to end on the HIP path: {nb} x {nf * 320} samples -> SEANet encoder -> 8-stage RVQ "
                        f"(codes + latents); latents -> SEANet decoder -> audio; random-init HF EncodecModel weights",
                 encode_ms=round(1e3 * t_enc, 2), decode_ms=round(1e3 * t_dec, 2),
                 encode_x_realtime=round(secs / t_enc, 1), decode_x_realtime=round(secs / t_dec, 1),
                 parity=dict(frames_checked=2 * nf, frames_with_codes_differing_from_hf=ndiff, decode_rel_err_vs_hf=dec_err),
-                note="the 2-layer LSTM recurrence is one persistent launch per layer with a device-wide barrier per frame "
-                     "(2 x 1024 dependent steps of ~6 us, up to 32 utterances per step): latency-bound; with one launch per step an "
-                     "encode of 8 utterances measured 63 ms against 21 ms now")
+                roofline=dict(bound="latency (2 x 1024 dependent LSTM steps) + hbm (activation passes of the wide early layers)",
+                              algorithmic_gflop_per_encode=round(fl_enc / 1e9, 1), algorithmic_mb_per_encode=round(by_enc / 1e6, 1),
+                              achieved=round(fl_enc / t_enc / 1e12, 2), unit="TFLOP/s", peak=PEAK_16BIT_TFLOPS,
+                              frac=round(fl_enc / t_enc / 1e12 / PEAK_16BIT_TFLOPS, 5),
+                              mfma_floor_ms=round(3.0 * fl_enc / (PEAK_16BIT_TFLOPS * 1e12) * 1e3, 3),
+                              hbm_floor_ms=round(by_enc / 8e12 * 1e3, 4)),
+                note="the 2-layer LSTM recurrence is one persistent launch per layer, the batch in independent 8-row groups side by "
+                     "side, each with its own device-wide barrier per frame; kernel breakdown: profiles/r03_codec_kernel_stats.csv")
             del hf, codec, wav, emb_c, codes_c, rec
         except Exception as e:                                        # transformers missing / API drift: report, do not fail the line
             side["codec_seanet_rvq"] = dict(skipped=f"{type(e).__name__}: {e}")

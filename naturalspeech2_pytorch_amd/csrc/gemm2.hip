@@ -890,14 +890,18 @@ static hipError_t launch2_epi(const GemmArgs& g, hipStream_t s) {
 
 hipError_t launch_gemm1(const GemmArgs& g, int precision, hipStream_t s);   // gemm.hip (128x128 register-staged kernel)
 
-static int g_forced_kernel = -1;     // -1: read NS2_GEMM once; 0 auto; 1 / 2 force a kernel (tests exercise both)
-void force_gemm_kernel(int k) { g_forced_kernel = k; }
+// Test hook (ns2_debug_force_gemm / NS2_GEMM): the only switch of the GEMM family, process-wide by design, atomic so that two
+// host threads (one per device) may read it while a test flips it.  -1: read NS2_GEMM once; 0 auto; 1 / 2 force a kernel.
+static std::atomic<int> g_forced_kernel{-1};
+void force_gemm_kernel(int k) { g_forced_kernel.store(k, std::memory_order_relaxed); }
 static int forced_kernel() {
-  if (g_forced_kernel < 0) {
+  int f = g_forced_kernel.load(std::memory_order_relaxed);
+  if (f < 0) {
     const char* e = getenv("NS2_GEMM");
-    g_forced_kernel = e ? atoi(e) : 0;
+    f = e ? atoi(e) : 0;
+    g_forced_kernel.store(f, std::memory_order_relaxed);
   }
-  return g_forced_kernel;
+  return f;
 }
 
 // Dispatch: the 256x256 LDS-DMA kernel for wide outputs, the 128x128 kernel when N <= 128 (half of a 256-wide tile

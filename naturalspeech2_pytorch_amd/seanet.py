@@ -212,6 +212,41 @@ class _SEANetHIP(nn.Module):
                 f"one-launch-per-step recurrence.")
         return _Act(x, B, T, H, 0)
 
+    def algorithmic_work(self, B, T, C):
+        """(FLOPs, compulsory bytes) of one pass over B utterances of T rows x C channels, counted from the layer shapes:
+        2 x MACs of every convolution / transposed convolution / LSTM Linear (HFENC:81-347), and the bytes that must cross HBM
+        at least once (input, output, fp32 weights) -- what a fully fused codec would move; used for bench.py's roofline."""
+        flops, wbytes = 0.0, 0.0
+        t, c = T, C
+
+        def conv(p, t, c):
+            k = p.get("k", 1)
+            if p["kind"] == "im2col":
+                return 2.0 * B * t * k * p["co"], t, p["co"], 4.0 * k * p["co"]
+            if p["kind"] == "conv":
+                return 2.0 * B * t * p["ci"] * p["co"] * k, t, p["co"], 4.0 * k * p["ci"] * p["co"]
+            if p["kind"] == "down":
+                r = p["r"]
+                return 2.0 * B * (t // r) * p["ci"] * p["co"] * 2 * r, t // r, p["co"], 4.0 * 2 * r * p["ci"] * p["co"]
+            r = p["r"]                                           # "up"
+            return 2.0 * B * t * p["ci"] * p["co"] * 2 * r, t * r, p["co"], 4.0 * 2 * r * p["ci"] * p["co"]
+
+        for p in self._packed():
+            if p["kind"] == "res":
+                for q in (p["c1"], p["sc"]):
+                    f, _, _, w = conv(q, t, c)
+                    flops += f; wbytes += w
+                f, _, _, w = conv(p["c2"], t, p["c1"]["co"])
+                flops += f; wbytes += w
+            elif p["kind"] == "lstm":
+                H = p["H"]
+                flops += len(p["layers"]) * 2.0 * B * t * (8 * H * H)            # W_ih and W_hh: 4H x H each
+                wbytes += len(p["layers"]) * 4.0 * 8 * H * H
+            else:
+                f, t, c, w = conv(p, t, c)
+                flops += f; wbytes += w
+        return flops, 4.0 * B * T * C + 4.0 * B * t * c + wbytes
+
     @torch.no_grad()
     def _run(self, x_rows, B, T, C):
         a = _Act(x_rows, B, T, C, 0)
