@@ -53,8 +53,12 @@ def _reference_root() -> str:
 
 
 def _mod(name, **attrs):
+    import importlib.machinery
     m = types.ModuleType(name)
     m.__dict__.update(attrs)
+    # a spec, so that `importlib.util.find_spec(name)` (transformers probes torchaudio that way) answers instead of raising
+    # "ValueError: torchaudio.__spec__ is None"; there is no distribution metadata, so availability probes still say "absent"
+    m.__spec__ = importlib.machinery.ModuleSpec(name, loader=None)
     sys.modules[name] = m
     return m
 
