@@ -357,6 +357,28 @@ def test_skinny_linear(B, K, J, act):
     assert rel(y, ref) < 2e-6
 
 
+def test_skinny_linear_uniform_batch_rows():
+    """Round 3: a block whose batch rows are identical over its K range multiplies once for all rows (the sampler's time
+    conditioning).  Same FMA order per row: a uniform batch equals the single-row call bit for bit; a batch that is uniform only
+    over part of K (conditioned model: time half shared, prompt half per utterance) matches fp64; a NaN row takes the per-row body."""
+    B, K, J = 32, 4096, 3072
+    w = rnd(J, K, seed=130, scale=1 / math.sqrt(K)).t().contiguous()
+    b = rnd(J, seed=131)
+    x1 = rnd(1, K, seed=132)
+    y1 = ops.skinny_linear(x1, w, b, 0)
+    yu = ops.skinny_linear(x1.expand(B, K).contiguous(), w, b, 0)
+    assert torch.equal(yu, y1.expand(B, J))
+    xm = x1.expand(B, K).clone()
+    xm[:, K // 2:] = rnd(B, K // 2, seed=133)
+    ym = ops.skinny_linear(xm, w, b, 1)
+    ref = F.silu(xm.double() @ w.double() + b.double())
+    assert rel(ym, ref) < 2e-6
+    assert rel(ym[5:6], ops.skinny_linear(xm[5:6].contiguous(), w, b, 1)) < 1e-6          # a row in the batch == the row alone
+    xn = x1.expand(4, K).clone()
+    xn[:, 7] = float("nan")
+    assert torch.isnan(ops.skinny_linear(xn, w, b, 0)).all()
+
+
 def test_time_embed():
     dim, B = 128, 5
     freqs = rnd(dim // 2, seed=32)
