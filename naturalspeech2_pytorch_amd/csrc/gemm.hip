@@ -204,6 +204,44 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     run_k(0, g.nkt);
   }
 
+  // Round 3: interior wave tiles of the fp32 epilogue (the SEANet codec's 16 ... 128-channel convolutions run here, 80 k blocks
+  // per launch on the early layers) leave through the wave's share of the now idle LDS ring as 16-byte stores of whole row
+  // segments, with the bounds tested once per wave -- the generic epilogue below tests and branches per stored value.
+  if constexpr (EPI == EPI_F32 && NP == 2) {
+    const int nvc = min(64, g.N - col_base);                     // valid columns of this wave tile
+    if (nvc <= 0) return;
+    if (row_base + 64 <= g.M && nvc >= 16 && (nvc & (nvc - 1)) == 0 && g.act == 0 && (g.ldo_f & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(g.out_f) & 15) == 0 &&
+        (!g.resid || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.resid) & 15) == 0))) {
+      constexpr int RS = 272;                                     // 64 fp32 + 16 B pad per staged row: 64 rows = 17 KiB of the wave's 20 KiB
+      unsigned char* wbuf = smem + wave * (STAGE_BYTES / 2);
+      const float bc0 = (g.bias && col_base + l31 < g.N) ? g.bias[col_base + l31] : 0.f;
+      const float bc1 = (g.bias && col_base + 32 + l31 < g.N) ? g.bias[col_base + 32 + l31] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            *reinterpret_cast<float*>(wbuf + lr * RS + (ni * 32 + l31) * 4) = acc[mi][ni][r] + (ni ? bc1 : bc0);
+          }
+      __builtin_amdgcn_wave_barrier();
+      const int lcpr = 31 - __builtin_clz(nvc >> 2);              // log2(16-byte chunks per row): 2, 3 or 4
+      const int lr0 = lane >> lcpr, ch = lane & ((1 << lcpr) - 1), rpi = 64 >> lcpr;
+      for (int it = 0; it < (1 << lcpr); ++it) {
+        const int lr = it * rpi + lr0;
+        float4 v = *reinterpret_cast<const float4*>(wbuf + lr * RS + ch * 16);
+        const long row = row_base + lr;
+        if (g.resid) {
+          const float4 rr = *reinterpret_cast<const float4*>(g.resid + row * g.ldr + col_base + ch * 4);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        *reinterpret_cast<float4*>(g.out_f + row * g.ldo_f + col_base + ch * 4) = v;
+      }
+      return;
+    }
+  }
   gemm_epilogue<EPI, 2, 2>(acc, g, z, row_base, col_base, tn * 64 + wn * 32, lane);
 }
 
