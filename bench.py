@@ -382,14 +382,17 @@ def main():
                 emb_c, codes_c, _ = codec(wav)                       # warm-up: packs the weights
                 rec = codec.decode(emb_c)
                 torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                emb_c, codes_c, _ = codec(wav)
-                torch.cuda.synchronize()
-                t_enc = time.perf_counter() - t0
-                t0 = time.perf_counter()
-                rec = codec.decode(emb_c)
-                torch.cuda.synchronize()
-                t_dec = time.perf_counter() - t0
+                t_encs, t_decs = [], []
+                for _ in range(3):                                   # median of three: a single call is at the mercy of the allocator
+                    t0 = time.perf_counter()
+                    emb_c, codes_c, _ = codec(wav)
+                    torch.cuda.synchronize()
+                    t_encs.append(time.perf_counter() - t0)
+                    t0 = time.perf_counter()
+                    rec = codec.decode(emb_c)
+                    torch.cuda.synchronize()
+                    t_decs.append(time.perf_counter() - t0)
+                t_enc, t_dec = sorted(t_encs)[1], sorted(t_decs)[1]
                 lat_hf = hf.encoder(wav[:2, None])
                 codes_hf = hf.quantizer.encode(lat_hf, bandwidth=6.0).permute(1, 2, 0)            # [b, n, Q]
                 rec_hf = hf.decoder(emb_c[:2].transpose(1, 2))

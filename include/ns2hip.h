@@ -42,6 +42,7 @@ extern "C" {
 #define NS2_ERR_ARG -1
 #define NS2_ERR_HIP -2
 #define NS2_ERR_STATE -3
+#define NS2_UNAVAILABLE 1 /* not an error: this fast path does not apply here, take the general one (ns2_lstm2) */
 
 const char* ns2_last_error(void);
 int ns2_version(void);
@@ -151,10 +152,21 @@ int64_t ns2_lstm_state_floats(int B, int H);
 int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_hh, const float* b_hh, float* state, int64_t state_floats,
                    const float* resid, int64_t ld_r, float* out, int64_t ld_o, int B, int64_t T, int H, void* stream);
 
-/* The one-launch-per-layer LSTM recurrence synchronises its 64 workgroups with a device-wide step barrier.  The launcher takes
- * that path only when the device can hold twice that many of its workgroups (occupancy query); should the barrier still time out
- * (CU masking, a device saturated by other processes) the kernel gives up -- its output is then incomplete -- and counts the
- * launch here instead of trapping.  Synchronises; call it after a codec run.  NS2_LSTM_PERSISTENT=0 forces the per-step kernel. */
+/* ns2_lstm2: BOTH layers of EnCodec's 2-layer nn.LSTM (HFENC:253-266, H = 512) in one launch, layer 2 running one frame behind
+ *   layer 1 on its own workgroups and layer 1 forming layer 2's input projections (no GEMM between the layers).  xproj1 [B*T, 4H] =
+ *   x W_ih1^T + b_ih1; w_hh1 / w_ih2 / w_hh2 [4H, H]; b_* [4H]; state = ns2_lstm2_state_floats() floats of caller scratch;
+ *   out[b*T + t, :H] = h2_t (+ resid row).  Returns NS2_UNAVAILABLE -- nothing launched -- when the device cannot hold all the
+ *   workgroups at once, B > 32, or NS2_LSTM_FUSED=0 / NS2_LSTM_PERSISTENT=0: call ns2_lstm_layer per layer instead. */
+int64_t ns2_lstm2_state_floats(void);
+int ns2_lstm2(const float* xproj1, int64_t ld_x, const float* w_hh1, const float* b_hh1, const float* w_ih2, const float* b_ih2,
+              const float* w_hh2, const float* b_hh2, float* state, int64_t state_floats, const float* resid, int64_t ld_r, float* out,
+              int64_t ld_o, int B, int64_t T, void* stream);
+
+/* The one-launch LSTM recurrences synchronise their workgroups frame by frame through tagged values in global memory, which needs
+ * every workgroup resident.  The launchers take that path only when the occupancy query says the device can hold them; should a
+ * wait still time out (CU masking, a device saturated by other processes) the kernel gives up -- its output is then incomplete --
+ * and counts the launch here instead of trapping.  Synchronises; call it after a codec run.  NS2_LSTM_PERSISTENT=0 forces the
+ * per-step kernel. */
 int ns2_lstm_abort_count(int reset, int64_t* count);
 
 /* Range guard of precisions 2 and 4 (IEEE-half operands stop at 65504 / 57344; beyond, values are clamped: finite but

@@ -54,6 +54,8 @@ SIGNATURES = {
     "ns2_seanet_unpad": (I, [P, L, I, P, L, I, L, I, P]),
     "ns2_lstm_state_floats": (L, [I, I]),
     "ns2_lstm_layer": (I, [P, L, P, P, P, L, P, L, P, L, I, L, I, P]),
+    "ns2_lstm2_state_floats": (L, []),
+    "ns2_lstm2": (I, [P, L, P, P, P, P, P, P, P, L, P, L, P, L, I, L, P]),
     "ns2_lstm_abort_count": (I, [I, POINTER(c_int64)]),
     "ns2_saturation_count": (I, [I, POINTER(c_int64)]),
     "ns2_saturation_peek_async": (I, [P, P]),
@@ -72,6 +74,8 @@ SIGNATURES = {
     "ns2_model_profile_end": (I, [P, POINTER(ctypes.c_double), POINTER(c_int64)]),
     "ns2_model_destroy": (None, [P]),
 }
+
+NS2_UNAVAILABLE = 1          # include/ns2hip.h: "this fast path does not apply here" (not an error)
 
 _lib = None
 

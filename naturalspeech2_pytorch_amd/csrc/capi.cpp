@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 106; }   // 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 107; }   // 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 2, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
   force_gemm_kernel(kernel);
@@ -244,6 +244,20 @@ extern "C" int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_h
   float* c = state + 2 * (size_t)B * H;
   HIPRET(launch_lstm_layer(xproj, (long)ld_x, w_hh, b_hh, h_a, h_b, c, (long)state_floats, resid, (long)ld_r, out, (long)ld_o, B,
                            (long)T, H, (hipStream_t)stream));
+  return NS2_OK;
+}
+
+extern "C" int64_t ns2_lstm2_state_floats(void) { return (int64_t)lstm2_state_floats(); }
+extern "C" int ns2_lstm2(const float* xproj1, int64_t ld_x, const float* w_hh1, const float* b_hh1, const float* w_ih2, const float* b_ih2,
+                         const float* w_hh2, const float* b_hh2, float* state, int64_t state_floats, const float* resid, int64_t ld_r,
+                         float* out, int64_t ld_o, int B, int64_t T, void* stream) {
+  ARGCHK(xproj1 && w_hh1 && b_hh1 && w_ih2 && b_ih2 && w_hh2 && b_hh2 && state && out, "ns2_lstm2: null pointer");
+  ARGCHK(B > 0 && T > 0, "ns2_lstm2: empty batch or sequence");
+  ARGCHK(state_floats >= (int64_t)lstm2_state_floats(), "ns2_lstm2: state scratch too small (ns2_lstm2_state_floats)");
+  const hipError_t e = launch_lstm2(xproj1, (long)ld_x, w_hh1, b_hh1, w_ih2, b_ih2, w_hh2, b_hh2, state, (long)state_floats, resid, (long)ld_r,
+                                    out, (long)ld_o, B, (long)T, (hipStream_t)stream);
+  if (e == hipErrorNotReady) return NS2_UNAVAILABLE;
+  HIPRET(e);
   return NS2_OK;
 }
 

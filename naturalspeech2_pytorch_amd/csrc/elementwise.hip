@@ -631,202 +631,371 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* xproj, long
   h_next[sidx] = h;
   out[row * ld_o + j] = h + (resid ? resid[row * ld_r + j] : 0.f);
 }
-// ---- persistent recurrence: ONE launch per layer instead of T.  H = 512 only (EnCodec's LSTM width); 64 workgroups, each owning
-// 8 hidden units = 32 gate rows of W_hh, which live in REGISTERS for the whole sequence: thread (r = tid >> 3, kq = tid & 7)
-// holds row r's columns k = 4 kq + 32 i .. + 3 (i < 16).  Per step a workgroup stages h_{t-1} [B, 512] into LDS, every thread
-// forms its partial dot products for all batch rows, an 8-lane transpose-reduction leaves lane kq with the complete sums of
-// batch rows kq, kq + 8, .., the four gates of a unit meet through two lane exchanges, and the gate-0 lanes apply the cell
-// update (the cell state never leaves their registers).  Steps are separated by a device-wide barrier on a global counter.
+// ---- persistent recurrence: ONE launch per layer instead of T.  H = 512 only (EnCodec's LSTM width); 64 workgroups per group
+// of 8 batch rows, each owning 8 hidden units = 32 gate rows of W_hh, which live in REGISTERS for the whole sequence: thread
+// (u = tid >> 5, kq = tid & 31) holds the four gate rows of unit u, columns 4 kq + 128 i .. + 3 (i < 4).  Per step a workgroup
+// stages h_{t-1} [8, 512] into LDS, every thread forms its 4 x 8 partial dot products (32 LDS reads of 16 bytes: round 3's first
+// mapping, one gate row and 64 columns per thread, read 128 and spent 1.9 us of every step on LDS bandwidth), a five-stage
+// transpose-reduction over the 32 kq lanes leaves lane kq with the complete sum of gate kq >> 3, batch row kq & 7, the four gates
+// meet through three lane exchanges, and the gate-0 lanes apply the cell update (the cell state never leaves their registers).
 // The XCDs' L2s are not coherent with each other, so h travels through global memory with agent-scope (sc1) loads and stores
 // -- individually coherent accesses of the few KB that are shared -- instead of release / acquire fences, whose L2 write-back
 // and invalidate cost 10 us per step (measured: 16.6 us per step with fences).  The next step's input projections are
-// fetched before the barrier wait: they do not depend on the recurrence.
+// fetched before the wait: they do not depend on the recurrence.
+// Step synchronisation: every exchanged value is an 8-byte {h, step tag} pair written and read as ONE 64-bit agent-scope access,
+// and a consumer simply re-reads the pairs whose tag is not yet the step it needs.  A step then costs one store -> load trip
+// through the memory side instead of three dependent ones (store + wait for the write acknowledge, atomic arrival, counter
+// poll): the counter barrier this replaces measured 7.5 us per frame, 36.0 ms per encode against 32.8 (tools/gpu_r3_k.sh).
+// Two exchange buffers suffice: a workgroup can write h_{t+2} into the buffer that held h_t only after it has read every
+// h_{t+1}, and those are written by workgroups that have finished reading h_t.  Tags are t + 1 (never 0 = the host's memset).
 constexpr int LP_UNITS = 8;
 constexpr int LP_LDH = 512 + 4;                   // LDS row stride of the staged h (floats)
 constexpr int LP_MAXB = 32;
-constexpr unsigned LP_SPIN_LIMIT = 1u << 22;      // ~ seconds of polling: a lost workgroup turns into a reported abort, not a hang
-// launches whose step barrier timed out (a workgroup that never became resident: CU masking, a partitioned device, a GPU
-// saturated by other processes).  The kernel then gives up -- every workgroup leaves at its next barrier -- instead of trapping
+constexpr unsigned LP_SPIN_LIMIT = 1u << 20;      // ~ seconds of polling: a lost workgroup turns into a reported abort, not a hang
+// launches whose step wait timed out (a workgroup that never became resident: CU masking, a partitioned device, a GPU
+// saturated by other processes).  The kernel then gives up -- every workgroup leaves at its next wait -- instead of trapping
 // (a trap kills the HIP context and the process); the host reads this counter after a codec run (ns2_lstm_abort_count).
 __device__ unsigned int ns2_lstm_aborts;
 
-NS2_DEVINL float ld_agent(const float* p) {
-  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+NS2_DEVINL unsigned long long ld_agent_u64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-NS2_DEVINL float2 ld_agent2(const float* p) {       // 8-byte aligned
-  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
-}
-NS2_DEVINL void st_agent(float* p, float v) {
-  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+NS2_DEVINL void st_agent_u64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Batch rows are independent through the recurrence: blockIdx.y selects a group of 8 BG rows with its OWN step barrier (64
-// workgroups each).  Round 3: B = 32 runs as four 8-row groups side by side (256 workgroups, one per CU) instead of one group of
-// 32 rows -- the per-step cost (h staging 64 KiB per workgroup + 2048 FMAs per thread) was 21.4 us, four times the 8-row step.
+// ---- pieces shared by the one-layer and the two-layer kernel.  A "block" of h is 8 batch rows x 512 {h, tag} pairs,
+// contiguous in global memory; pair q of a thread is element tid + 256 q of it (row q >> 1).
+struct LstmWait {
+  unsigned* abort_flag;
+  int gave_up = 0;
+};
+// Stage NS blocks into LDS (block n -> s_h + n * 8 * LP_LDH), each once every lane of the wave sees tag want[n] in it;
+// zero[n]: the block is h_{-1} = 0, nothing is read.  Bit 16 n + q of `pend` (wave-uniform) = that pair has not been staged
+// yet: every round reads the pending pairs, and a pair goes to LDS in the round in which all 64 lanes see the wanted tag --
+// nothing but the mask is carried between rounds.
+template <int NS>
+NS2_DEVINL void lstm_stage(const unsigned long long* const (&src)[NS], const unsigned (&want)[NS], const bool (&zero)[NS], float* s_h,
+                           int rows, int tid, LstmWait& wt) {
+  unsigned pend = 0;
+#pragma unroll
+  for (int n = 0; n < NS; ++n)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if ((q >> 1) >= rows) continue;              // rows past the batch are never read by the dot products
+      if (zero[n]) s_h[(8 * n + (q >> 1)) * LP_LDH + 256 * (q & 1) + tid] = 0.f;
+      else pend |= 1u << (16 * n + q);
+    }
+  unsigned spins = 0;
+  while (pend) {
+    unsigned long long v[16 * NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (pend & (1u << (16 * n + q))) v[16 * n + q] = ld_agent_u64(src[n] + tid + 256 * q);
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if ((pend & (1u << (16 * n + q))) && !__builtin_amdgcn_ballot_w64((unsigned)(v[16 * n + q] >> 32) != want[n])) {
+          s_h[(8 * n + (q >> 1)) * LP_LDH + 256 * (q & 1) + tid] = __uint_as_float((unsigned)v[16 * n + q]);
+          pend &= ~(1u << (16 * n + q));
+        }
+    if (!pend) break;
+    if (((++spins) & 255u) == 0) {
+      if (__hip_atomic_load(wt.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { wt.gave_up = 1; break; }
+      if (spins > LP_SPIN_LIMIT) {                 // first to time out: tell the others, count the aborted launch once
+        if (__hip_atomic_exchange(wt.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicAdd(&ns2_lstm_aborts, 1u);
+        wt.gave_up = 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+struct LstmRows { float4 w[4][4]; };              // [gate][i]: columns 4 kq + 128 i .. + 3 of row gate * 512 + j of a [2048, 512] matrix
+NS2_DEVINL void lstm_load_rows(LstmRows& r, const float* w, int j, int kq) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.w[g][i] = *reinterpret_cast<const float4*>(w + ((long)g * 512 + j) * 512 + 4 * kq + 128 * i);
+}
+NS2_DEVINL void lstm_dot(const LstmRows& r, const float* s_blk, int rows, int kq, float (&acc)[4][8]) {     // acc += rows of r . block
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb) {
+    if (bb >= rows) continue;
+    const float* hb = s_blk + bb * LP_LDH + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 h4 = *reinterpret_cast<const float4*>(hb + 128 * i);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float a = acc[g][bb];
+        a = fmaf(r.w[g][i].x, h4.x, a); a = fmaf(r.w[g][i].y, h4.y, a); a = fmaf(r.w[g][i].z, h4.z, a); a = fmaf(r.w[g][i].w, h4.w, a);
+        acc[g][bb] = a;
+      }
+    }
+  }
+}
+NS2_DEVINL void lstm_dot2(const LstmRows& r1, const LstmRows& r2, const float* s_blk, int rows, int kq, float (&acc1)[4][8],
+                          float (&acc2)[4][8]) {                                                  // two matrices, one pass over the block
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb) {
+    if (bb >= rows) continue;
+    const float* hb = s_blk + bb * LP_LDH + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 h4 = *reinterpret_cast<const float4*>(hb + 128 * i);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float a = acc1[g][bb], b = acc2[g][bb];
+        a = fmaf(r1.w[g][i].x, h4.x, a); a = fmaf(r1.w[g][i].y, h4.y, a); a = fmaf(r1.w[g][i].z, h4.z, a); a = fmaf(r1.w[g][i].w, h4.w, a);
+        b = fmaf(r2.w[g][i].x, h4.x, b); b = fmaf(r2.w[g][i].y, h4.y, b); b = fmaf(r2.w[g][i].z, h4.z, b); b = fmaf(r2.w[g][i].w, h4.w, b);
+        acc1[g][bb] = a; acc2[g][bb] = b;
+      }
+    }
+  }
+}
+// Transpose-reduction over the 32 kq lanes of a unit through LDS: lane kq ends with the complete sum of value m = kq, i.e. gate
+// kq >> 3, batch row kq & 7.  s_red = this unit's [32 values][LP_RED lanes] floats, rows padded to 33: the writes (fixed m, 32
+// lanes) and the reads (lane m walks its row) both touch 32 different banks, and every address is one base register plus an
+// immediate.  The two units of a wave use their own regions and a wave's LDS operations execute in order: no workgroup barrier.
+// (The register-only version -- five rounds of select + lane exchange -- cost ~100 VGPRs next to the packed accumulators and
+// pushed the two-layer kernel into scratch.)
+constexpr int LP_RED = 33;
+NS2_DEVINL float lstm_reduce(const float (&acc)[4][8], float* s_red, int kq) {
+  float* wr = s_red + kq;
+#pragma unroll
+  for (int m = 0; m < 32; ++m) wr[m * LP_RED] = acc[m >> 3][m & 7];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float* rd = s_red + kq * LP_RED;
+  float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 32; ++i) r[i & 3] += rd[i];
+  __builtin_amdgcn_wave_barrier();                 // the region is rewritten by the next reduction
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+// lane kq holds x = pre-activation of gate kq >> 3 (i, f, g, o) for batch row kq & 7; lanes kq ^ 8, ^ 16, ^ 24 hold the other
+// three gates.  Every lane must call (lane exchanges); the result is meaningful on the gate-0 lanes, which own the cell state.
+NS2_DEVINL float lstm_cell(float x, float& c) {
+  const float x1 = __shfl_xor(x, 8, 64), x2 = __shfl_xor(x, 16, 64), x3 = __shfl_xor(x, 24, 64);
+  const float ig = sigmoidf_acc(x), fg = sigmoidf_acc(x1), gg = tanhf(x2), og = sigmoidf_acc(x3);
+  c = fg * c + ig * gg;
+  return og * tanhf(c);
+}
+NS2_DEVINL unsigned long long lstm_pair(float h, long t) { return ((unsigned long long)(unsigned)(t + 1) << 32) | __float_as_uint(h); }
+
+// Batch rows are independent through the recurrence: blockIdx.y selects a group of 8 BG rows that synchronises only with itself
+// (64 workgroups each).  B = 32 runs as four 8-row groups side by side (256 workgroups, one per CU) instead of one group of
+// 32 rows -- the per-step cost of a 32-row group (h staging 64 KiB per workgroup + 2048 FMAs per thread) was four times the 8-row step.
 template <int BG>                                 // batch rows per group in units of 8
-__global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* xproj, long ld_x, long T, const float* w_hh, const float* b_hh,
-                                                              float* hbuf, const float* resid, long ld_r, float* out, long ld_o, int B_all,
-                                                              unsigned* bar_all) {
+__global__ __launch_bounds__(256, 2) void lstm_persistent_kernel(const float* xproj, long ld_x, long T, const float* w_hh, const float* b_hh,
+                                                              unsigned long long* hx, const float* resid, long ld_r, float* out, long ld_o,
+                                                              int B_all, unsigned* flags_all) {
   constexpr int H = 512;
-  extern __shared__ __attribute__((aligned(16))) float s_h[];      // [8 BG][LP_LDH]
-  __shared__ int s_abort;
-  const int tid = threadIdx.x, kq = tid & 7, r = tid >> 3;
-  const int gate = r & 3, u = r >> 2;
+  extern __shared__ __attribute__((aligned(16))) float s_h[];      // [8 BG][LP_LDH] staged h, then [8 units][32][32] reduction scratch
+  const int tid = threadIdx.x, kq = tid & 31, u = tid >> 5;
+  const int gate = kq >> 3, bl = kq & 7;                           // this lane's role after the reduction
+  float* s_red = s_h + 8 * BG * LP_LDH + u * (32 * LP_RED);
   const int j = blockIdx.x * LP_UNITS + u;                         // hidden unit
-  const unsigned nwg = gridDim.x;
   // this group's rows [b_off, b_off + 8 BG): shift every per-row pointer, keep the group-local indexing below
   const int b_off = blockIdx.y * 8 * BG;
   const int B = min(B_all - b_off, 8 * BG);
-  unsigned* bar = bar_all + 16 * blockIdx.y;                        // one 64-byte line per group: {arrival counter, abort flag}
+  LstmWait wt{flags_all + 16 * blockIdx.y + 1};                     // one 64-byte line per group
   xproj += (long)b_off * T * ld_x;
-  hbuf += (long)b_off * H;
+  hx += (long)b_off * H;                                           // {h, tag} pairs, [2][LP_MAXB][H]
   out += (long)b_off * T * ld_o;
   if (resid) resid += (long)b_off * T * ld_r;
 
-  float w[64];
-  {
-    const float* wr = w_hh + ((long)gate * H + j) * H + 4 * kq;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float4 v = *reinterpret_cast<const float4*>(wr + 32 * i);
-      w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-    }
-  }
+  LstmRows wr;
+  lstm_load_rows(wr, w_hh, j, kq);
   const float bias = b_hh[gate * H + j];
   float c[BG], xp[BG];
 #pragma unroll
   for (int g = 0; g < BG; ++g) {
     c[g] = 0.f;
-    const int b = 8 * g + kq;
+    const int b = 8 * g + bl;
     xp[g] = (b < B) ? xproj[((long)b * T) * ld_x + (long)gate * H + j] : 0.f;      // step 0's input projection
   }
 
   for (long t = 0; t < T; ++t) {
-    // ---- stage h_{t-1} (zeros at t = 0)
-    const float* hp = hbuf + (t & 1) * (long)LP_MAXB * H;
+    // ---- stage h_{t-1} (zeros at t = 0): written at step t - 1 with tag t
+    const unsigned long long* hp = hx + (t & 1) * (long)LP_MAXB * H;
 #pragma unroll
-    for (int g = 0; g < BG; ++g) {                 // 8 rows x 512 floats = 2048 pairs: 8 per thread, all in flight together
-      float2 v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int i = tid + 256 * q, b = 8 * g + (i >> 8), k = 2 * (i & 255);
-        v[q] = (t > 0 && b < B) ? ld_agent2(hp + (long)b * H + k) : make_float2(0.f, 0.f);
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int i = tid + 256 * q, b = 8 * g + (i >> 8), k = 2 * (i & 255);
-        *reinterpret_cast<float2*>(s_h + b * LP_LDH + k) = v[q];
-      }
+    for (int g = 0; g < BG; ++g) {
+      const unsigned long long* const src[1] = {hp + (long)(8 * g) * H};
+      const unsigned want[1] = {(unsigned)t};
+      const bool zero[1] = {t == 0};
+      lstm_stage<1>(src, want, zero, s_h + 8 * g * LP_LDH, B - 8 * g, tid, wt);
     }
-    __syncthreads();
-    // ---- partial dot products over this thread's 64 columns, all batch rows
-    float acc[8 * BG];
-#pragma unroll
-    for (int b = 0; b < 8 * BG; ++b) {
-      float a0 = 0.f, a1 = 0.f;
-      if (b < B) {
-        const float* hb = s_h + b * LP_LDH + 4 * kq;
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          const float4 h0 = *reinterpret_cast<const float4*>(hb + 32 * i);
-          const float4 h1 = *reinterpret_cast<const float4*>(hb + 32 * i + 32);
-          a0 = fmaf(w[4 * i], h0.x, a0); a0 = fmaf(w[4 * i + 1], h0.y, a0); a0 = fmaf(w[4 * i + 2], h0.z, a0); a0 = fmaf(w[4 * i + 3], h0.w, a0);
-          a1 = fmaf(w[4 * i + 4], h1.x, a1); a1 = fmaf(w[4 * i + 5], h1.y, a1); a1 = fmaf(w[4 * i + 6], h1.z, a1); a1 = fmaf(w[4 * i + 7], h1.w, a1);
-        }
-      }
-      acc[b] = a0 + a1;
-    }
-    __syncthreads();                               // s_h is free for the next step's staging
-    // ---- transpose-reduce over the 8 kq lanes: lane kq ends with the full sum of batch rows 8 g + kq
+    if (__syncthreads_or(wt.gave_up)) return;      // uniform: the whole workgroup leaves
+    // ---- partial dot products over this thread's 16 columns: four gate rows x all batch rows, then the transpose-reduction
     float pre[BG];
 #pragma unroll
     for (int g = 0; g < BG; ++g) {
-      float v4[4], v2[2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float keep = (kq & 4) ? acc[8 * g + 4 + q] : acc[8 * g + q];
-        const float send = (kq & 4) ? acc[8 * g + q] : acc[8 * g + 4 + q];
-        v4[q] = keep + __shfl_xor(send, 4, 64);
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float keep = (kq & 2) ? v4[2 + q] : v4[q];
-        const float send = (kq & 2) ? v4[q] : v4[2 + q];
-        v2[q] = keep + __shfl_xor(send, 2, 64);
-      }
-      const float keep = (kq & 1) ? v2[1] : v2[0];
-      const float send = (kq & 1) ? v2[0] : v2[1];
-      pre[g] = keep + __shfl_xor(send, 1, 64);
+      float acc[4][8] = {};
+      lstm_dot(wr, s_h + 8 * g * LP_LDH, B - 8 * g, kq, acc);
+      pre[g] = lstm_reduce(acc, s_red, kq);
     }
-    // ---- gates of unit u, batch row b = 8 g + kq: lanes tid ^ 8, ^ 16, ^ 24 hold the other three
-    float* hn = hbuf + ((t + 1) & 1) * (long)LP_MAXB * H;
+    __syncthreads();                               // s_h is free for the next step's staging
+    unsigned long long* hn = hx + ((t + 1) & 1) * (long)LP_MAXB * H;
 #pragma unroll
     for (int g = 0; g < BG; ++g) {
-      const int b = 8 * g + kq;
+      const int b = 8 * g + bl;
       const float x = pre[g] + bias + xp[g];
-      if (b < B && t + 1 < T) xp[g] = xproj[((long)b * T + t + 1) * ld_x + (long)gate * H + j];   // in flight across the barrier
-      const float x1 = __shfl_xor(x, 8, 64), x2 = __shfl_xor(x, 16, 64), x3 = __shfl_xor(x, 24, 64);
-      if (gate == 0 && b < B) {                    // x = i, x1 = f, x2 = g, x3 = o
-        const float ig = sigmoidf_acc(x), fg = sigmoidf_acc(x1), gg = tanhf(x2), og = sigmoidf_acc(x3);
-        c[g] = fg * c[g] + ig * gg;
-        const float h = og * tanhf(c[g]);
-        st_agent(hn + (long)b * H + j, h);
+      if (b < B && t + 1 < T) xp[g] = xproj[((long)b * T + t + 1) * ld_x + (long)gate * H + j];   // in flight across the wait
+      const float h = lstm_cell(x, c[g]);
+      if (gate == 0 && b < B) {
+        st_agent_u64(hn + (long)b * H + j, lstm_pair(h, t));
         const long row = (long)b * T + t;
         out[row * ld_o + j] = h + (resid ? resid[row * ld_r + j] : 0.f);
       }
     }
-    // ---- device-wide step barrier: every thread's h stores have completed (write-through) before its workgroup arrives
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned target = nwg * (unsigned)(t + 1);
-      unsigned spins = 0;
-      int gave_up = 0;
-      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        ++spins;
-        if ((spins & 1023u) == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = 1; break; }
-        if (spins > LP_SPIN_LIMIT) {               // first to time out: tell the others, count the aborted launch once
-          if (__hip_atomic_exchange(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicAdd(&ns2_lstm_aborts, 1u);
-          gave_up = 1;
-          break;
-        }
-      }
-      s_abort = gave_up;
-    }
-    __syncthreads();
-    if (s_abort) return;                           // wave-uniform: the whole workgroup leaves
   }
 }
 
+// ---- both layers of a 2-layer nn.LSTM in ONE launch: the layers overlap instead of following each other (the recurrences are
+// latency-bound: a step is mostly the store -> load trip of h), and the [B T, 512] x [512, 2048] GEMM between them disappears.
+// blockIdx.z = 0, layer 1: as above, and -- from the h1_{t-1} block it has staged anyway -- the layer-2 input projection
+// W_ih2 h1_{t-1} + b_ih2 of ITS OWN 8 units x 4 gates x 8 batch rows (a second set of 64 weights per thread, the same LDS reads),
+// one value per thread after the reduction.  blockIdx.z = 1, layer 2: the one-layer recurrence on W_hh2, its input projections
+// coming lane-to-lane from the layer-1 workgroup of the same units (blockIdx.x, blockIdx.y) through a ring of LP_XDEPTH tagged
+// slots per thread.  Layer 1 does not depend on layer 2 and could run ahead without bound: before it reuses a ring slot it checks
+// the consumer workgroup's acknowledge word (the last frame that workgroup has taken in; read at the top of the step, normally
+// far ahead of what is required).  All 128 workgroups of a group must be resident.
+constexpr int LP_XDEPTH = 32;
+__global__ __launch_bounds__(256, 2) void lstm2_persistent_kernel(const float* xproj, long ld_x, long T, const float* w_hh1,
+                                                                  const float* b_hh1, const float* w_ih2, const float* b_ih2,
+                                                                  const float* w_hh2, const float* b_hh2, unsigned long long* h1,
+                                                                  unsigned long long* h2, unsigned long long* xs, unsigned* acks,
+                                                                  const float* resid, long ld_r, float* out, long ld_o, int B_all,
+                                                                  unsigned* flags_all) {
+  constexpr int H = 512;
+  extern __shared__ __attribute__((aligned(16))) float s_h[];      // [8][LP_LDH] staged h, then [8 units][32][32] reduction scratch
+  const int tid = threadIdx.x, kq = tid & 31, u = tid >> 5;
+  const int gate = kq >> 3, bl = kq & 7;
+  float* s_red = s_h + 8 * LP_LDH + u * (32 * LP_RED);
+  const int j = blockIdx.x * LP_UNITS + u;
+  const int b_off = blockIdx.y * 8;
+  const int B = min(B_all - b_off, 8);
+  const bool mine = gate == 0 && bl < B;                            // this lane owns (batch row b_off + bl, unit j)
+  LstmWait wt{flags_all + 16 * blockIdx.y + 1};
+  const long pair_wg = blockIdx.y * gridDim.x + blockIdx.x;         // producer / consumer workgroup pair
+  xs += pair_wg * ((long)LP_XDEPTH * 256) + tid;                    // this thread's ring: slot s at + 256 s
+  unsigned* ack = acks + pair_wg;
+  float c = 0.f;
+
+  if (blockIdx.z == 0) {
+    h1 += (long)b_off * H;                                         // ring [2][LP_MAXB][H]
+    xproj += (long)b_off * T * ld_x;
+    LstmRows wr, wi;
+    lstm_load_rows(wr, w_hh1, j, kq);
+    lstm_load_rows(wi, w_ih2, j, kq);
+    const float bias = b_hh1[gate * H + j], bias2 = b_ih2[gate * H + j];
+    float xp = (bl < B) ? xproj[((long)bl * T) * ld_x + (long)gate * H + j] : 0.f;
+    for (long t = 0; t <= T; ++t) {                // step T only forms the last input projection of layer 2
+      const unsigned acked = t >= LP_XDEPTH ? __hip_atomic_load(ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const unsigned long long* const src[1] = {h1 + (t & 1) * (long)LP_MAXB * H};
+      const unsigned want[1] = {(unsigned)t};
+      const bool zero[1] = {t == 0};
+      lstm_stage<1>(src, want, zero, s_h, B, tid, wt);
+      if (__syncthreads_or(wt.gave_up)) return;
+      float acc[4][8] = {}, acc2[4][8] = {};
+      lstm_dot2(wr, wi, s_h, B, kq, acc, acc2);
+      const float x = lstm_reduce(acc, s_red, kq) + bias + xp;
+      const float x2 = lstm_reduce(acc2, s_red, kq) + bias2;
+      __syncthreads();
+      if (t > 0) {                                 // W_ih2 h1_{t-1} + b_ih2 -> frame t - 1 of layer 2, ring slot (t - 1) % LP_XDEPTH
+        if (t - 1 >= LP_XDEPTH) {                  // the slot still holds frame t - 1 - LP_XDEPTH until the consumer has taken it in
+          unsigned a = acked, spins = 0;
+          while (a < (unsigned)(t - LP_XDEPTH) && !wt.gave_up) {
+            __builtin_amdgcn_s_sleep(8);
+            a = __hip_atomic_load(ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > LP_SPIN_LIMIT || __hip_atomic_load(wt.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) wt.gave_up = 1;
+          }
+        }
+        st_agent_u64(xs + 256 * ((t - 1) % LP_XDEPTH), lstm_pair(x2, t - 1));
+      }
+      if (t == T) break;
+      if (bl < B && t + 1 < T) xp = xproj[((long)bl * T + t + 1) * ld_x + (long)gate * H + j];
+      const float h = lstm_cell(x, c);
+      if (mine) st_agent_u64(h1 + ((t + 1) & 1) * (long)LP_MAXB * H + (long)bl * H + j, lstm_pair(h, t));
+    }
+  } else {
+    h2 += (long)b_off * H;                                         // ring [2][LP_MAXB][H]
+    out += (long)b_off * T * ld_o;
+    if (resid) resid += (long)b_off * T * ld_r;
+    LstmRows wr;
+    lstm_load_rows(wr, w_hh2, j, kq);
+    const float bias = b_hh2[gate * H + j];
+    for (long t = 0; t < T; ++t) {
+      // this lane's input projection of frame t (tag t + 1: normally long there) rides along with the wait for h2_{t-1}
+      const unsigned long long* xsrc = xs + 256 * (t % LP_XDEPTH);
+      unsigned long long xv = ld_agent_u64(xsrc);
+      const unsigned long long* const src[1] = {h2 + (t & 1) * (long)LP_MAXB * H};
+      const unsigned want[1] = {(unsigned)t};
+      const bool zero[1] = {t == 0};
+      lstm_stage<1>(src, want, zero, s_h, B, tid, wt);
+      for (unsigned spins = 0; (unsigned)(xv >> 32) != (unsigned)(t + 1) && !wt.gave_up;) {
+        __builtin_amdgcn_s_sleep(2);
+        xv = ld_agent_u64(xsrc);
+        if (++spins > LP_SPIN_LIMIT || (((spins & 255u) == 0) && __hip_atomic_load(wt.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
+          wt.gave_up = 1;
+      }
+      if (__syncthreads_or(wt.gave_up)) return;
+      if (tid == 0) __hip_atomic_store(ack, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // frames 0 .. t are taken in
+      float acc[4][8] = {};
+      lstm_dot(wr, s_h, B, kq, acc);
+      const float x = lstm_reduce(acc, s_red, kq) + bias + __uint_as_float((unsigned)xv);
+      __syncthreads();
+      const float h = lstm_cell(x, c);
+      if (mine) {
+        st_agent_u64(h2 + ((t + 1) & 1) * (long)LP_MAXB * H + (long)bl * H + j, lstm_pair(h, t));
+        const long row = (long)bl * T + t;
+        out[row * ld_o + j] = h + (resid ? resid[row * ld_r + j] : 0.f);
+      }
+    }
+  }
+}
+
+// The step waits need every workgroup resident at once: ask the occupancy API (per device and kernel, once).
+struct LstmCapacity {
+  std::atomic<int> cap[DynLdsAttr::kMaxDev];
+  int get(const void* fn, size_t lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DynLdsAttr::kMaxDev) return -1;
+    int v = cap[dev].load(std::memory_order_acquire);
+    if (v == 0) {
+      int per_cu = 0, cus = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return -1;
+      v = per_cu * cus > 0 ? per_cu * cus : -1;
+      cap[dev].store(v, std::memory_order_release);
+    }
+    return v;
+  }
+};
+
 template <int BG>
-static hipError_t launch_lstm_persistent(const float* xproj, long ld_x, const float* w_hh, const float* b_hh, float* hbuf, unsigned* bar,
+static hipError_t launch_lstm_persistent(const float* xproj, long ld_x, const float* w_hh, const float* b_hh, float* hbuf, unsigned* flags,
                                          const float* resid, long ld_r, float* out, long ld_o, int B, long T, hipStream_t s) {
-  const size_t lds = (size_t)8 * BG * LP_LDH * sizeof(float);
+  const size_t lds = ((size_t)8 * BG * LP_LDH + LP_UNITS * 32 * LP_RED) * sizeof(float);
   const int ngroups = (B + 8 * BG - 1) / (8 * BG);
   const int nwg = (512 / LP_UNITS) * ngroups;
+  const void* fn = reinterpret_cast<const void*>(&lstm_persistent_kernel<BG>);
   static DynLdsAttr attr;
-  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&lstm_persistent_kernel<BG>), (int)lds);
+  hipError_t e = attr.ensure(fn, (int)lds);
   if (e != hipSuccess) return e;
-  // The step barriers need every workgroup resident at once.  Ask the occupancy API (per device, once) and require twice the
-  // grid: the API is known to be one block per CU optimistic in places (MI355X_MICROARCH.md), and a CU-masked or partitioned
-  // device (32 CUs) must not take this path on a borderline count.  hipErrorNotReady = "use the per-step kernel".
-  static std::atomic<int> capacity[DynLdsAttr::kMaxDev];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DynLdsAttr::kMaxDev) return hipErrorNotReady;
-  int cap = capacity[dev].load(std::memory_order_acquire);
-  if (cap == 0) {
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&lstm_persistent_kernel<BG>), 256, lds) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      return hipErrorNotReady;
-    cap = per_cu * cus > 0 ? per_cu * cus : -1;
-    capacity[dev].store(cap, std::memory_order_release);
-  }
-  if (cap < 2 * nwg) return hipErrorNotReady;
-  hipLaunchKernelGGL((lstm_persistent_kernel<BG>), dim3(512 / LP_UNITS, ngroups), dim3(256), lds, s, xproj, ld_x, T, w_hh, b_hh, hbuf, resid, ld_r,
-                     out, ld_o, B, bar);
+  // Require twice the grid: the API is known to be one block per CU optimistic in places (MI355X_MICROARCH.md), and a CU-masked or
+  // partitioned device (32 CUs) must not take this path on a borderline count.  hipErrorNotReady = "use the per-step kernel".
+  static LstmCapacity capacity;
+  if (capacity.get(fn, lds) < 2 * nwg) return hipErrorNotReady;
+  hipLaunchKernelGGL((lstm_persistent_kernel<BG>), dim3(512 / LP_UNITS, ngroups), dim3(256), lds, s, xproj, ld_x, T, w_hh, b_hh,
+                     reinterpret_cast<unsigned long long*>(hbuf), resid, ld_r, out, ld_o, B, flags);
   return hipGetLastError();
 }
 
@@ -834,22 +1003,24 @@ static bool lstm_persistent_enabled() {              // NS2_LSTM_PERSISTENT=0: t
   static const bool on = [] { const char* e = getenv("NS2_LSTM_PERSISTENT"); return !(e && e[0] == '0'); }();
   return on;
 }
+constexpr long LP_STATE_FLOATS = 4L * LP_MAXB * 512 + 64;     // two exchange buffers of {h, tag} pairs + one abort-flag line per group
 long lstm_state_floats(int B, int H) {
-  const long step = 3L * B * H, pers = 2L * LP_MAXB * 512 + 64;
-  return (H == 512 && B <= LP_MAXB) ? (step > pers ? step : pers) : step;
+  const long step = 3L * B * H;
+  return (H == 512 && B <= LP_MAXB) ? (step > LP_STATE_FLOATS ? step : LP_STATE_FLOATS) : step;
 }
 hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, const float* b_hh, float* h_a, float* h_b,
                              float* c_state, long state_floats, const float* resid, long ld_r, float* out, long ld_o, int B,
                              long T, int H, hipStream_t s) {
   if (B <= 0 || T <= 0 || H <= 0 || H > 512 || (H & 3)) return hipErrorInvalidValue;
   if (H == 512 && B <= LP_MAXB && lstm_persistent_enabled()) {
-    // the persistent kernel needs 2 x 32 x 512 floats of h exchange + the barrier counter: the caller's scratch is
-    // 3 x B x H floats (h_a, h_b, c contiguous, include/ns2hip.h), enough only from B >= 22 on -- smaller batches take the step kernel
-    // unless the caller handed over the larger scratch (state_floats)
-    if (state_floats >= 2L * LP_MAXB * 512 + 64) {
+    // the persistent kernel needs 2 x 32 x 512 {h, tag} pairs of exchange + the abort flags: the caller's scratch
+    // (3 x B x H floats at least: h_a, h_b, c contiguous, include/ns2hip.h) is large enough when it was sized by
+    // ns2_lstm_state_floats; a caller that handed over less takes the step kernel
+    if (state_floats >= LP_STATE_FLOATS) {
       float* hbuf = h_a;
-      unsigned* bar = reinterpret_cast<unsigned*>(h_a + 2L * LP_MAXB * 512);
-      hipError_t e = hipMemsetAsync(bar, 0, 64 * sizeof(float), s);
+      unsigned* bar = reinterpret_cast<unsigned*>(h_a + 4L * LP_MAXB * 512);
+      // tags of an earlier launch must not be mistaken for this one's: the whole exchange area starts as zeros (tag 0 is never written)
+      hipError_t e = hipMemsetAsync(hbuf, 0, (size_t)LP_STATE_FLOATS * sizeof(float), s);
       if (e != hipSuccess) return e;
       // 8-row groups side by side (see the kernel); a single group of up to 32 rows (BG = 4) remains for devices too small
       // to hold 64 workgroups per group twice over
@@ -868,6 +1039,41 @@ hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, c
     float* hn = (t & 1) ? h_a : h_b;
     hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, s, xproj, ld_x, T, t, w_hh, b_hh, hp, hn, c_state, resid, ld_r, out, ld_o, B, H);
   }
+  return hipGetLastError();
+}
+
+// scratch of launch_lstm2: h1 ring and h2 ring [2][LP_MAXB][512] pairs each, the projection rings [groups][64][LP_XDEPTH][256]
+// pairs, one acknowledge word per workgroup pair, one flag line per group
+static long lstm2_pairs() { return 4L * LP_MAXB * 512 + (LP_MAXB / 8) * 64L * LP_XDEPTH * 256; }
+long lstm2_state_floats() { return 2 * lstm2_pairs() + (LP_MAXB / 8) * 64 + 64; }
+// hipErrorNotReady: this device cannot hold all the workgroups at once (or the two-layer path is switched off, NS2_LSTM_FUSED=0)
+// -- the caller runs the layers one after the other (launch_lstm_layer)
+hipError_t launch_lstm2(const float* xproj, long ld_x, const float* w_hh1, const float* b_hh1, const float* w_ih2, const float* b_ih2,
+                        const float* w_hh2, const float* b_hh2, float* state, long state_floats, const float* resid, long ld_r, float* out,
+                        long ld_o, int B, long T, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("NS2_LSTM_FUSED"); return !(e && e[0] == '0'); }();
+  if (B <= 0 || T <= 0 || state_floats < lstm2_state_floats()) return hipErrorInvalidValue;
+  if (!on || !lstm_persistent_enabled() || B > LP_MAXB) return hipErrorNotReady;
+  const size_t lds = ((size_t)8 * LP_LDH + LP_UNITS * 32 * LP_RED) * sizeof(float);
+  const int ngroups = (B + 7) / 8;
+  const int nwg = 2 * (512 / LP_UNITS) * ngroups;
+  const void* fn = reinterpret_cast<const void*>(&lstm2_persistent_kernel);
+  static DynLdsAttr attr;
+  hipError_t e = attr.ensure(fn, (int)lds);
+  if (e != hipSuccess) return e;
+  // B = 32 fills the device exactly (two workgroups per CU, bounded by registers, where the occupancy API is exact): no factor
+  // of two here; a launch that still cannot get resident ends through the abort flag and the caller is told (lstm_abort_read)
+  static LstmCapacity capacity;
+  if (capacity.get(fn, lds) < nwg) return hipErrorNotReady;
+  e = hipMemsetAsync(state, 0, (size_t)lstm2_state_floats() * sizeof(float), s);       // no tag of an earlier launch survives
+  if (e != hipSuccess) return e;
+  unsigned long long* h1 = reinterpret_cast<unsigned long long*>(state);
+  unsigned long long* h2 = h1 + 2L * LP_MAXB * 512;
+  unsigned long long* xs = h2 + 2L * LP_MAXB * 512;
+  unsigned* acks = reinterpret_cast<unsigned*>(h1 + lstm2_pairs());
+  unsigned* flags = acks + (LP_MAXB / 8) * 64;
+  hipLaunchKernelGGL(lstm2_persistent_kernel, dim3(512 / LP_UNITS, ngroups, 2), dim3(256), lds, s, xproj, ld_x, T, w_hh1, b_hh1, w_ih2, b_ih2,
+                     w_hh2, b_hh2, h1, h2, xs, acks, resid, ld_r, out, ld_o, B, flags);
   return hipGetLastError();
 }
 

@@ -173,6 +173,13 @@ hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, c
                              float* c_state, long state_floats, const float* resid, long ld_r, float* out, long ld_o, int B,
                              long T, int H, hipStream_t s);
 
+// both layers of a 2-layer LSTM (H = 512) in one launch, layer 2 overlapped with layer 1; hipErrorNotReady = not available on
+// this device / switched off: run the layers one after the other
+long lstm2_state_floats();
+hipError_t launch_lstm2(const float* xproj, long ld_x, const float* w_hh1, const float* b_hh1, const float* w_ih2, const float* b_ih2,
+                        const float* w_hh2, const float* b_hh2, float* state, long state_floats, const float* resid, long ld_r, float* out,
+                        long ld_o, int B, long T, hipStream_t s);
+
 unsigned int lstm_abort_read(bool reset);   // persistent-LSTM launches that gave up at their step barrier since the last reset (synchronising)
 
 // values that left the IEEE-half range in this translation unit's kernels since the last reset (synchronising reads)

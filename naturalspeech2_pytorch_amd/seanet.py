@@ -120,8 +120,10 @@ class _SEANetHIP(nn.Module):
         layers = []
         for l in range(lstm.num_layers):
             g = lambda n: getattr(lstm, f"{n}_l{l}").detach().float().contiguous()     # noqa: E731
+            # w_ih as a GEMM operand (input projections of a whole sequence) and, past the first layer, as plain fp32 rows: the
+            # two-layer launch (ns2_lstm2) forms layer 2's input projections itself, frame by frame
             layers.append(dict(w_ih=ops.PackedWeight(g("weight_ih"), precision=prec), b_ih=g("bias_ih"), w_hh=g("weight_hh"),
-                               b_hh=g("bias_hh")))
+                               b_hh=g("bias_hh"), w_ih_f32=g("weight_ih") if l else None))
         return dict(kind="lstm", layers=layers, H=lstm.hidden_size)
 
     def _build(self):
@@ -191,26 +193,44 @@ class _SEANetHIP(nn.Module):
         B, T, H = a.B, a.T, p["H"]
         lib = _lib.load()
         x = a.x
-        nstate = int(lib.ns2_lstm_state_floats(B, H))
-        state = torch.empty(nstate, dtype=torch.float32, device=x.device)
-        for i, l in enumerate(p["layers"]):
-            pl = _prep(x, B, T, H, precision=prec)
-            xproj = ops.linear_f32(l["w_ih"], pl, bias=l["b_ih"], precision=prec)                       # [B T, 4H]
+        layers = p["layers"]
+        out = None
+        if len(layers) == 2 and H == 512:
+            # both layers in one launch, layer 2 one frame behind layer 1 (ns2_lstm2); NS2_UNAVAILABLE -> layer by layer below
+            l1, l2 = layers
+            xproj = ops.linear_f32(l1["w_ih"], _prep(x, B, T, H, precision=prec), bias=l1["b_ih"], precision=prec)   # [B T, 4H]
+            nstate = int(lib.ns2_lstm2_state_floats())
+            state = torch.empty(nstate, dtype=torch.float32, device=x.device)
             out = torch.empty(B * T, H, dtype=torch.float32, device=x.device)
-            last = i + 1 == len(p["layers"])
-            resid = a.x if last else None                                                                 # HFENC:264: lstm(x) + x
-            check(lib.ns2_lstm_layer(xproj.data_ptr(), 4 * H, l["w_hh"].data_ptr(), l["b_hh"].data_ptr(), state.data_ptr(), nstate,
-                                     ops._p(resid), H, out.data_ptr(), H, B, T, H, _stream()), "ns2_lstm_layer")
-            x = out
+            rc = lib.ns2_lstm2(xproj.data_ptr(), 4 * H, l1["w_hh"].data_ptr(), l1["b_hh"].data_ptr(), l2["w_ih_f32"].data_ptr(),
+                               l2["b_ih"].data_ptr(), l2["w_hh"].data_ptr(), l2["b_hh"].data_ptr(), state.data_ptr(), nstate,
+                               a.x.data_ptr(), H, out.data_ptr(), H, B, T, _stream())                      # HFENC:264: lstm(x) + x
+            if rc == _lib.NS2_UNAVAILABLE:
+                out = None
+            else:
+                check(rc, "ns2_lstm2")
+        if out is None:
+            nstate = int(lib.ns2_lstm_state_floats(B, H))
+            state = torch.empty(nstate, dtype=torch.float32, device=x.device)
+            xproj = None
+            for i, l in enumerate(layers):
+                if not (i == 0 and xproj is not None):
+                    xproj = ops.linear_f32(l["w_ih"], _prep(x, B, T, H, precision=prec), bias=l["b_ih"], precision=prec)
+                out = torch.empty(B * T, H, dtype=torch.float32, device=x.device)
+                last = i + 1 == len(layers)
+                resid = a.x if last else None                                                             # HFENC:264: lstm(x) + x
+                check(lib.ns2_lstm_layer(xproj.data_ptr(), 4 * H, l["w_hh"].data_ptr(), l["b_hh"].data_ptr(), state.data_ptr(), nstate,
+                                         ops._p(resid), H, out.data_ptr(), H, B, T, H, _stream()), "ns2_lstm_layer")
+                x, xproj = out, None
         import ctypes
         n = ctypes.c_int64(0)
         check(lib.ns2_lstm_abort_count(1, ctypes.byref(n)), "ns2_lstm_abort_count")       # one synchronisation per codec run
         if n.value:
             raise _lib.Ns2Error(
-                f"the persistent LSTM recurrence gave up at its device-wide step barrier in {n.value} launch(es): not all of its "
-                f"workgroups were resident (CU masking / a device shared with other work).  Set NS2_LSTM_PERSISTENT=0 to use the "
-                f"one-launch-per-step recurrence.")
-        return _Act(x, B, T, H, 0)
+                f"the one-launch LSTM recurrence gave up waiting for a frame in {n.value} launch(es): not all of its workgroups were "
+                f"resident (CU masking / a device shared with other work).  Set NS2_LSTM_FUSED=0 (one launch per layer) or "
+                f"NS2_LSTM_PERSISTENT=0 (one launch per frame).")
+        return _Act(out, B, T, H, 0)
 
     def algorithmic_work(self, B, T, C):
         """(FLOPs, compulsory bytes) of one pass over B utterances of T rows x C channels, counted from the layer shapes:

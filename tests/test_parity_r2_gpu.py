@@ -504,13 +504,14 @@ def test_seanet_pieces():
     assert rel(out.reshape(3, 20, 64), ref) < 1e-5
 
 
-@pytest.mark.parametrize("B", [1, 5, 8, 19, 32])
-def test_lstm_persistent_recurrence(B):
-    """EnCodec's LSTM width (H = 512): the one-launch persistent recurrence (device-wide step barrier) against torch.nn.LSTM and
-    against the per-step kernel (the same entry point with only the minimal scratch), ragged batch sizes across the 8-row groups"""
+@pytest.mark.parametrize("B,T", [(1, 37), (5, 37), (8, 37), (19, 37), (32, 37), (32, 700), (3, 1024)])
+def test_lstm_persistent_recurrence(B, T):
+    """EnCodec's LSTM width (H = 512): the one-launch persistent recurrence (steps synchronised through tagged {h, step} pairs)
+    against torch.nn.LSTM and against the per-step kernel (the same entry point with only the minimal scratch), ragged batch sizes
+    across the 8-row groups, and sequences long enough that every exchange buffer is reused hundreds of times"""
     from naturalspeech2_pytorch_amd import _lib
     lib = _lib.load()
-    H, T = 512, 37
+    H = 512
     torch.manual_seed(B)
     lstm = torch.nn.LSTM(H, H, 1).to(DEV)
     xin = make_input("xl", (B, T, H), seed=96 + B).to(DEV)
@@ -520,15 +521,46 @@ def test_lstm_persistent_recurrence(B):
     outs = []
     for nstate in (int(lib.ns2_lstm_state_floats(B, H)), 3 * B * H):
         state = torch.empty(nstate, device=DEV)
-        out = torch.full((B * T, H), float("nan"), device=DEV)
-        _lib.check(lib.ns2_lstm_layer(xproj.data_ptr(), 4 * H, lstm.weight_hh_l0.data_ptr(), lstm.bias_hh_l0.data_ptr(), state.data_ptr(), nstate,
-                                      xin.reshape(B * T, H).data_ptr(), H, out.data_ptr(), H, B, T, H,
-                                      torch.cuda.current_stream().cuda_stream), "lstm")
-        torch.cuda.synchronize()
+        for _ in range(2):                                           # the second launch finds the first one's tags in the scratch
+            out = torch.full((B * T, H), float("nan"), device=DEV)
+            _lib.check(lib.ns2_lstm_layer(xproj.data_ptr(), 4 * H, lstm.weight_hh_l0.data_ptr(), lstm.bias_hh_l0.data_ptr(), state.data_ptr(),
+                                          nstate, xin.reshape(B * T, H).data_ptr(), H, out.data_ptr(), H, B, T, H,
+                                          torch.cuda.current_stream().cuda_stream), "lstm")
+            torch.cuda.synchronize()
         outs.append(out.reshape(B, T, H))
         assert rel(outs[-1], ref) < 1e-5, f"scratch {nstate}: {rel(outs[-1], ref)}"
     if int(lib.ns2_lstm_state_floats(B, H)) > 3 * B * H:            # the two calls really took different kernels
         assert rel(outs[0], outs[1]) < 1e-5
+
+
+@pytest.mark.parametrize("B,T", [(3, 40), (8, 33), (19, 150), (32, 700), (32, 31)])
+def test_lstm2_both_layers_in_one_launch(B, T):
+    """ns2_lstm2: EnCodec's 2-layer LSTM with layer 2 overlapped one frame behind layer 1 (layer 1 forms layer 2's input
+    projections, handed over through a ring of 32 tagged slots per lane with an acknowledge word) against torch.nn.LSTM(num_layers=2)
+    + skip; sequences shorter and much longer than the ring, ragged batch groups, and a second launch on the same scratch"""
+    from naturalspeech2_pytorch_amd import _lib
+    lib = _lib.load()
+    H = 512
+    torch.manual_seed(100 + B)
+    lstm = torch.nn.LSTM(H, H, 2).to(DEV)
+    xin = make_input("xl2", (B, T, H), seed=196 + B).to(DEV)
+    with torch.no_grad():
+        ref = lstm(xin.transpose(0, 1))[0].transpose(0, 1) + xin
+        xproj = F_linear(xin.reshape(B * T, H), lstm.weight_ih_l0, lstm.bias_ih_l0).contiguous()
+    nstate = int(lib.ns2_lstm2_state_floats())
+    state = torch.randn(nstate, device=DEV)                            # garbage in the scratch must not matter
+    for _ in range(2):
+        out = torch.full((B * T, H), float("nan"), device=DEV)
+        rc = lib.ns2_lstm2(xproj.data_ptr(), 4 * H, lstm.weight_hh_l0.data_ptr(), lstm.bias_hh_l0.data_ptr(), lstm.weight_ih_l1.data_ptr(),
+                           lstm.bias_ih_l1.data_ptr(), lstm.weight_hh_l1.data_ptr(), lstm.bias_hh_l1.data_ptr(), state.data_ptr(), nstate,
+                           xin.reshape(B * T, H).data_ptr(), H, out.data_ptr(), H, B, T, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, f"ns2_lstm2 rc={rc} (1 = unavailable: a whole MI355X must be able to hold its workgroups)"
+        torch.cuda.synchronize()
+        assert rel(out.reshape(B, T, H), ref) < 1e-5, rel(out.reshape(B, T, H), ref)
+    import ctypes
+    n = ctypes.c_int64(0)
+    _lib.check(lib.ns2_lstm_abort_count(1, ctypes.byref(n)), "abort count")
+    assert n.value == 0
 
 
 def test_encodec_wrapper_with_hf_seanet():
