@@ -72,7 +72,7 @@ int ns2_join_f32(const uint16_t* hi, const uint16_t* lo, int ld, float* out, int
 /* nn.Linear / CausalConv1d as one GEMM (NS2:1051-1069, 1021-1024, 583-595).
  * conv_taps = 0 for a Linear, k for a Conv1d(kernel k) with `dilation`; seq_len = tokens per utterance (rows never read
  * across utterances); pad_left = zero frames in front of the sequence: -1 = causal (k-1, CausalConv1d NS2:583-595),
- * (k-1)/2 = the "same" padding of SpeechPromptEncoder's convs (NS2:316).  act: 0 none, 1 SiLU after the bias.
+ * (k-1)/2 = the "same" padding of SpeechPromptEncoder's convs (NS2:316).  act: 0 none, 1 SiLU, 2 ELU (after the bias).
  * out = act(A W^T + bias) (+ resid), fp32 */
 int ns2_linear_f32(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
                    int dilation, int seq_len, const float* bias, const float* resid, int ldr, float* out, int ldo,

@@ -92,7 +92,7 @@ extern "C" int ns2_linear_f32(const ns2_weight* w, const uint16_t* a_hi, const u
   WFMT(w, precision, "ns2_linear_f32");
   ARGCHK(!w->geglu && !w->has_extra && (conv_taps == 0 ? w->taps == 1 : w->taps == conv_taps), "ns2_linear_f32: weight packing does not match");
   ARGCHK(lda >= w->cols_p, "ns2_linear_f32: lda smaller than the padded K");
-  ARGCHK(pad_left >= -1 && pad_left < (conv_taps > 0 ? conv_taps : 1) && (act == 0 || act == 1), "ns2_linear_f32: bad pad_left / act");
+  ARGCHK(pad_left >= -1 && pad_left < (conv_taps > 0 ? conv_taps : 1) && (act >= 0 && act <= 2), "ns2_linear_f32: bad pad_left / act");
   return gemm_f32(w->w, a_hi, a_lo, lda, M, conv_taps, dilation, seq_len, bias, resid, ldr, out, ldo, precision, (hipStream_t)stream,
                   pad_left, act);
 }
@@ -103,7 +103,7 @@ extern "C" int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const
   WFMT(w, precision, "ns2_linear_split");
   ARGCHK(!w->geglu && !w->has_extra && (conv_taps == 0 ? w->taps == 1 : w->taps == conv_taps), "ns2_linear_split: weight packing does not match");
   ARGCHK(lda >= w->cols_p && (ldo & 1) == 0, "ns2_linear_split: bad leading dimensions");
-  ARGCHK(pad_left >= -1 && pad_left < (conv_taps > 0 ? conv_taps : 1) && (act == 0 || act == 1), "ns2_linear_split: bad pad_left / act");
+  ARGCHK(pad_left >= -1 && pad_left < (conv_taps > 0 ? conv_taps : 1) && (act >= 0 && act <= 2), "ns2_linear_split: bad pad_left / act");
   return gemm_split(w->w, a_hi, a_lo, lda, M, conv_taps, dilation, seq_len, bias, out_hi, out_lo, ldo, precision, (hipStream_t)stream,
                     pad_left, act);
 }

@@ -519,7 +519,6 @@ hipError_t launch_pack_weight(const float* src, int C, int T, int Cp, const int*
 //     Linear with K = 7 instead of 7 taps of a 32-column-padded single channel.
 // x: fp32 [B, in_prefix + T, ldx] (channel-last; the first in_prefix rows of every utterance are skipped: x may be the output of
 // a convolution over prefixed rows), out planes [B, prefix + T, ldo]; add: optional fp32 [B, T, lda] added before the ELU.
-NS2_DEVINL float eluf(float x) { return x > 0.f ? x : expm1f(x); }
 
 __global__ __launch_bounds__(256) void seanet_prep_kernel(const float* x, int ldx, int in_prefix, const float* add, int ldadd, int B,
                                                           long T, int C, int elu, int prefix, int im2col_k, bf16_t* out_hi,
@@ -738,25 +737,6 @@ NS2_DEVINL void lstm_dot(const LstmRows& r, const float* s_blk, int rows, int kq
     }
   }
 }
-NS2_DEVINL void lstm_dot2(const LstmRows& r1, const LstmRows& r2, const float* s_blk, int rows, int kq, float (&acc1)[4][8],
-                          float (&acc2)[4][8]) {                                                  // two matrices, one pass over the block
-#pragma unroll
-  for (int bb = 0; bb < 8; ++bb) {
-    if (bb >= rows) continue;
-    const float* hb = s_blk + bb * LP_LDH + 4 * kq;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 h4 = *reinterpret_cast<const float4*>(hb + 128 * i);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float a = acc1[g][bb], b = acc2[g][bb];
-        a = fmaf(r1.w[g][i].x, h4.x, a); a = fmaf(r1.w[g][i].y, h4.y, a); a = fmaf(r1.w[g][i].z, h4.z, a); a = fmaf(r1.w[g][i].w, h4.w, a);
-        b = fmaf(r2.w[g][i].x, h4.x, b); b = fmaf(r2.w[g][i].y, h4.y, b); b = fmaf(r2.w[g][i].z, h4.z, b); b = fmaf(r2.w[g][i].w, h4.w, b);
-        acc1[g][bb] = a; acc2[g][bb] = b;
-      }
-    }
-  }
-}
 // Transpose-reduction over the 32 kq lanes of a unit through LDS: lane kq ends with the complete sum of value m = kq, i.e. gate
 // kq >> 3, batch row kq & 7.  s_red = this unit's [32 values][LP_RED lanes] floats, rows padded to 33: the writes (fixed m, 32
 // lanes) and the reads (lane m walks its row) both touch 32 different banks, and every address is one base register plus an
@@ -903,12 +883,19 @@ __global__ __launch_bounds__(256, 2) void lstm2_persistent_kernel(const float* x
       const bool zero[1] = {t == 0};
       lstm_stage<1>(src, want, zero, s_h, B, tid, wt);
       if (__syncthreads_or(wt.gave_up)) return;
-      float acc[4][8] = {}, acc2[4][8] = {};
-      lstm_dot2(wr, wi, s_h, B, kq, acc, acc2);
-      const float x = lstm_reduce(acc, s_red, kq) + bias + xp;
-      const float x2 = lstm_reduce(acc2, s_red, kq) + bias2;
-      __syncthreads();
+      // the recurrence first -- h1_t is what the other workgroups are waiting for -- then, off that path, layer 2's projection
+      if (t < T) {
+        float acc[4][8] = {};
+        lstm_dot(wr, s_h, B, kq, acc);
+        const float x = lstm_reduce(acc, s_red, kq) + bias + xp;
+        if (bl < B && t + 1 < T) xp = xproj[((long)bl * T + t + 1) * ld_x + (long)gate * H + j];
+        const float h = lstm_cell(x, c);
+        if (mine) st_agent_u64(h1 + ((t + 1) & 1) * (long)LP_MAXB * H + (long)bl * H + j, lstm_pair(h, t));
+      }
       if (t > 0) {                                 // W_ih2 h1_{t-1} + b_ih2 -> frame t - 1 of layer 2, ring slot (t - 1) % LP_XDEPTH
+        float acc2[4][8] = {};
+        lstm_dot(wi, s_h, B, kq, acc2);
+        const float x2 = lstm_reduce(acc2, s_red, kq) + bias2;
         if (t - 1 >= LP_XDEPTH) {                  // the slot still holds frame t - 1 - LP_XDEPTH until the consumer has taken it in
           unsigned a = acked, spins = 0;
           while (a < (unsigned)(t - LP_XDEPTH) && !wt.gave_up) {
@@ -919,10 +906,7 @@ __global__ __launch_bounds__(256, 2) void lstm2_persistent_kernel(const float* x
         }
         st_agent_u64(xs + 256 * ((t - 1) % LP_XDEPTH), lstm_pair(x2, t - 1));
       }
-      if (t == T) break;
-      if (bl < B && t + 1 < T) xp = xproj[((long)bl * T + t + 1) * ld_x + (long)gate * H + j];
-      const float h = lstm_cell(x, c);
-      if (mine) st_agent_u64(h1 + ((t + 1) & 1) * (long)LP_MAXB * H + (long)bl * H + j, lstm_pair(h, t));
+      __syncthreads();                             // s_h is free for the next step's staging
     }
   } else {
     h2 += (long)b_off * H;                                         // ring [2][LP_MAXB][H]

@@ -126,6 +126,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   const int row_base = tm * BM + wm * 64;     // + mi*32 + (r&3) + 8*(r>>2) + 4*hi
   const int col_base = tn * BN + wn * 64;     // + ni*32 + l31
 
+  // 32-column sub-tiles of this wave that hold real output columns (wave-uniform): the SEANet codec's 1 ... 32-channel
+  // convolutions over 10 M rows would otherwise spend 4 x their MFMA time on columns nobody stores
+  const int nv = g.N - col_base > 32 ? 2 : (g.N - col_base > 0 ? 1 : 0);
+
   const int a_frag_off = (wm * 64 + l31) * ROWB + hi * 16;
   const int w_frag_off = (wn * 64 + l31) * ROWB + hi * 16;
 
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
+            if (ni >= nv) continue;
             acc[mi][ni] = mma16<true>(af[0][mi], wf[0][ni], acc[mi][ni]);
             acc[mi][ni] = mma16<true>(af[1][mi], wf[1][ni], acc[mi][ni]);
             acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[mi], w8[ni], acc[mi][ni], 1, 1, 0, H8_E8M0_LO, 0,
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
+            if (ni >= nv) continue;
             if constexpr (NSPLIT == 3) {
               acc[mi][ni] = mma16<F16>(af[1][mi], wf[0][ni], acc[mi][ni]);
               acc[mi][ni] = mma16<F16>(af[0][mi], wf[1][ni], acc[mi][ni]);

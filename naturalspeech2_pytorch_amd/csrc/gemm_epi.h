@@ -71,7 +71,7 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
           const int row = row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           if (row >= g.M) continue;
           float v = acc[mi][ni][r] + bc;
-          if (g.act == 1) v = siluf(v);
+          if (g.act) v = apply_act(v, g.act);
           if (g.resid) v += g.resid[(long)row * g.ldr + col];
           g.out_f[(long)row * g.ldo_f + col] = v;
         }
@@ -123,7 +123,7 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
 #pragma unroll
           for (int rp = 0; rp < 8; ++rp) {
             float v0 = acc[mi][ni][2 * rp] + bc, v1 = acc[mi][ni][2 * rp + 1] + bc;
-            if (EPI == EPI_SPLIT && g.act == 1) { v0 = siluf(v0); v1 = siluf(v1); }
+            if (EPI == EPI_SPLIT && g.act) { v0 = apply_act(v0, g.act); v1 = apply_act(v1, g.act); }
             const float send = odd ? v0 : v1;
             const float recv = __shfl_xor(send, 1, 64);
             // columns (col&~1, col|1): even lane holds its own col then the neighbour's, odd lane the reverse
@@ -213,7 +213,7 @@ NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][NIT], const GemmArgs& g, int 
           for (int r = 0; r < 16; ++r) {
             const int lr = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             float t = acc[half * 2 + mh][NI0 + ni][r] + bc;
-            if (g.act == 1) t = siluf(t);
+            if (g.act) t = apply_act(t, g.act);
             *reinterpret_cast<float*>(wbuf + lr * RS + (ni * 32 + l31) * 4) = t;
           }
         }

@@ -223,6 +223,9 @@ NS2_DEVINL float erfc_fast(float z) {
 NS2_DEVINL float gelu_erf(float x) { return 0.5f * x * erfc_fast(-0.70710678118654752440f * x); }
 
 NS2_DEVINL float siluf(float x) { return x / (1.0f + expf(-x)); }
+NS2_DEVINL float eluf(float x) { return x > 0.f ? x : expm1f(x); }
+// epilogue activations of the linear entry points (include/ns2hip.h): 0 none, 1 SiLU, 2 ELU
+NS2_DEVINL float apply_act(float v, int act) { return act == 1 ? siluf(v) : (act == 2 ? eluf(v) : v); }
 
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive ids land on one XCD's L2.
 NS2_DEVINL int xcd_remap(int bid, int nwg) {

@@ -18,6 +18,8 @@ The module wraps an existing SEANet (`transformers.EncodecModel().encoder / .dec
 structure) and reads its EFFECTIVE weights (weight-norm applied: `conv.weight`); it re-packs when their content changes.
 Inference only (like the codec in the reference: `codec.eval()` + `torch.no_grad()`, NS2:1443-1445, 1608-1611).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -25,6 +27,9 @@ from . import _lib, ops
 from ._cache import PackedCache
 from ._lib import check
 from .model import _PRECISIONS
+
+
+_FUSED_ELU = os.environ.get("NS2_SEANET_FUSED_ELU", "0") == "1"
 
 
 def _stream():
@@ -182,10 +187,31 @@ class _SEANetHIP(nn.Module):
         raise NotImplementedError(p["kind"])
 
     def _resblock(self, a: _Act, p):
-        a = a.clean() if a.prefix else a
-        h = self._conv(a, p["c1"], elu=True)
-        sc = self._conv(a, p["sc"], elu=False)
-        return self._conv(h, p["c2"], elu=True, resid=sc.x)
+        """EncodecResnetBlock (HFENC:268-301): conv2(elu(conv1(elu(x)))) + shortcut(x).  All three GEMMs run on the row layout of
+        conv1 -- `prefix` reflected rows in front of every utterance, whose outputs are not data and are skipped by whoever reads
+        the result -- so neither the input nor the hidden activation is ever copied just to drop prefix rows.
+        NS2_SEANET_FUSED_ELU=1: conv1's epilogue applies the second ELU and writes conv2's operand planes itself (act = 2); it
+        saves the fp32 round trip of the hidden activation but leaves through the generic plane epilogue, which measured slower
+        than fp32 epilogue + prep pass on the decoder (tools/gpu_r3_k.sh: encode 26.9 / decode 27.0 ms against 27.7 / 26.4)."""
+        prec = _PRECISIONS[self.precision]
+        c1, c2, sc = p["c1"], p["c2"], p["sc"]
+        if not (c1["kind"] == "conv" and c2["kind"] == "conv" and sc["kind"] == "conv" and c2["k"] == 1 and sc["k"] == 1):
+            a = a.clean() if a.prefix else a                      # any other block shape: layer by layer
+            h = self._conv(a, c1, elu=True)
+            s = self._conv(a, sc, elu=False)
+            return self._conv(h, c2, elu=True, resid=s.x)
+        B, T, P = a.B, a.T, c1["prefix"]
+        xe = _prep(a.x, B, T, a.C, in_prefix=a.prefix, elu=True, prefix=P, precision=prec)
+        kw = dict(conv_taps=c1["k"], dilation=c1["dil"], seq_len=P + T) if c1["k"] > 1 else {}
+        if _FUSED_ELU:
+            h = ops.linear_split(c1["w"], xe, bias=c1["b"], precision=prec, act=2, **kw)
+        else:
+            hf = ops.linear_f32(c1["w"], xe, bias=c1["b"], precision=prec, **kw)                         # [B (P + T), co]
+            h = _prep(hf, B, P + T, c1["co"], elu=True, precision=prec)
+        xs = _prep(a.x, B, T, a.C, in_prefix=a.prefix, elu=False, prefix=P, precision=prec)
+        s = ops.linear_f32(sc["w"], xs, bias=sc["b"], precision=prec)
+        y = ops.linear_f32(c2["w"], h, bias=c2["b"], resid=s, precision=prec)
+        return _Act(y, B, T, c2["co"], P)
 
     def _lstm(self, a: _Act, p):
         prec = _PRECISIONS[self.precision]

@@ -149,6 +149,25 @@ def test_conv_k9_same_padding_silu(B, N, Cin, Cout, k, pad, gemm_kernel):
     assert rel(ops.join(ys, Cout), ref) < 3e-5
 
 
+@pytest.mark.parametrize("M,Cin,Cout,k", [(700, 32, 16, 3), (300, 64, 32, 3), (513, 256, 128, 1), (260, 512, 300, 3)])
+def test_conv_elu_epilogue(M, Cin, Cout, k, gemm_kernel):
+    """act = 2: ELU in the epilogue (EnCodec's residual block, HFENC:268-301: conv1 hands ELU(h) to conv2 as operand planes);
+    narrow outputs (16 of 32 plane columns are K padding of the consumer and must be zeros)"""
+    x = rnd(M, Cin, seed=190)
+    w = rnd(Cout, Cin, k, seed=191, scale=3 / math.sqrt(k * Cin))
+    b = rnd(Cout, seed=192)
+    pw = ops.PackedWeight(w)
+    a = ops.split(x)
+    xe = exact(a)[:, :Cin].reshape(1, M, Cin).transpose(1, 2)
+    ref = F.elu(F.conv1d(F.pad(xe, (k - 1, 0)), w.double(), b.double())).transpose(1, 2).reshape(M, Cout)
+    kw = dict(conv_taps=k, seq_len=M) if k > 1 else {}
+    y = ops.linear_f32(pw, a, bias=b, act=2, **kw)
+    assert rel(y, ref) < 2e-5
+    ys = ops.linear_split(pw, a, bias=b, act=2, **kw)
+    assert rel(ops.join(ys, Cout), ref) < 3e-5
+    assert ops.join(ys)[:, Cout:].abs().sum().item() == 0.0
+
+
 def test_embedding_padding_ids():
     table = rnd(11, 32, seed=93)
     ids = torch.tensor([[0, 5, -1, 9], [-3, 10, 2, 2]], device=DEV)
