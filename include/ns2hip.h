@@ -147,6 +147,14 @@ int ns2_cfg_mix(const float* cond_out, const float* null_out, float* out, int64_
  *   out[b*T + t, :H] = h_t (+ resid row). */
 int ns2_seanet_prep(const float* x, int ldx, int in_prefix, const float* add, int ldadd, int B, int64_t T, int C, int elu, int prefix,
                     int im2col_k, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream);
+/* ns2_seanet_prep2: one pass over fp32 x [B, in_prefix + T, C] for the two operands EnCodec's residual block (HFENC:268-301) needs
+ *   of it -- ELU(x) and x -- each (either may be NULL) into the column window [col0, col0 + cols) of a plane buffer of row stride
+ *   ld (logical columns; col0 a multiple of 32, cols >= C a multiple of 4, zero filled past C), rows laid out as ns2_seanet_prep
+ *   does (`prefix` mirrored rows per utterance).  Lets x and the hidden activation share one operand, so that
+ *   conv2(elu(h)) + shortcut(x) is ONE GEMM over the concatenated K. */
+int ns2_seanet_prep2(const float* x, int ldx, int in_prefix, int B, int64_t T, int C, int prefix, uint16_t* elu_hi, uint16_t* elu_lo,
+                     int elu_ld, int elu_col0, int elu_cols, uint16_t* raw_hi, uint16_t* raw_lo, int raw_ld, int raw_col0, int raw_cols,
+                     int precision, void* stream);
 int ns2_seanet_unpad(const float* src, int64_t ld_src, int prefix, float* dst, int64_t ld_dst, int B, int64_t T, int C, void* stream);
 int64_t ns2_lstm_state_floats(int B, int H);
 int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_hh, const float* b_hh, float* state, int64_t state_floats,

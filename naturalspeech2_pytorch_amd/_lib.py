@@ -51,6 +51,7 @@ SIGNATURES = {
     "ns2_ddim_step": (I, [P, P, P, P, P, I, L, I, I, F, P]),
     "ns2_cfg_mix": (I, [P, P, P, L, F, P]),
     "ns2_seanet_prep": (I, [P, I, I, P, I, I, L, I, I, I, I, P, P, I, I, P]),
+    "ns2_seanet_prep2": (I, [P, I, I, I, L, I, I, P, P, I, I, I, P, P, I, I, I, I, P]),
     "ns2_seanet_unpad": (I, [P, L, I, P, L, I, L, I, P]),
     "ns2_lstm_state_floats": (L, [I, I]),
     "ns2_lstm_layer": (I, [P, L, P, P, P, L, P, L, P, L, I, L, I, P]),

@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 107; }   // 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 108; }   // 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 2, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
   force_gemm_kernel(kernel);
@@ -225,6 +225,14 @@ extern "C" int ns2_seanet_prep(const float* x, int ldx, int in_prefix, const flo
   ARGCHK(x && out_hi && prec_ok(precision), "ns2_seanet_prep: bad arguments");
   HIPRET(launch_seanet_prep(x, ldx, in_prefix, add, ldadd, B, (long)T, C, elu, prefix, im2col_k, out_hi, out_lo, ldo,
                             op_fmt(precision), (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_seanet_prep2(const float* x, int ldx, int in_prefix, int B, int64_t T, int C, int prefix, uint16_t* elu_hi,
+                                uint16_t* elu_lo, int elu_ld, int elu_col0, int elu_cols, uint16_t* raw_hi, uint16_t* raw_lo, int raw_ld,
+                                int raw_col0, int raw_cols, int precision, void* stream) {
+  ARGCHK(x && (elu_hi || raw_hi) && prec_ok(precision), "ns2_seanet_prep2: bad arguments");
+  HIPRET(launch_seanet_prep2(x, ldx, in_prefix, B, (long)T, C, prefix, elu_hi, elu_lo, elu_ld, elu_col0, elu_cols, raw_hi, raw_lo, raw_ld,
+                             raw_col0, raw_cols, op_fmt(precision), (hipStream_t)stream));
   return NS2_OK;
 }
 extern "C" int ns2_seanet_unpad(const float* src, int64_t ld_src, int prefix, float* dst, int64_t ld_dst, int B, int64_t T, int C,

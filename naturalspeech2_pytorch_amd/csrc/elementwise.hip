@@ -580,6 +580,62 @@ __global__ void seanet_unpad_kernel(const float* src, long ld_src, int prefix, f
   const long b = r / T, t = r - b * T;
   dst[r * ld_dst + c] = src[(b * (prefix + T) + prefix + t) * ld_src + c];
 }
+// One pass over an fp32 activation for the two operands EnCodec's residual block needs of it: ELU(x) (conv1's input) and x
+// itself (the shortcut's), each into a column window [col0, col0 + cols) of its own plane buffer -- so that x and the hidden
+// activation can sit side by side in ONE operand and conv2 + shortcut become one GEMM over the concatenated K.  Same row
+// layout as seanet_prep_kernel: `prefix` mirrored rows in front of every utterance.
+struct PrepOut {
+  bf16_t* hi;
+  bf16_t* lo;
+  int ld, col0, cols;
+};
+__global__ __launch_bounds__(256) void seanet_prep2_kernel(const float* x, int ldx, int in_prefix, int B, long T, int C, int prefix,
+                                                           PrepOut eo, PrepOut ro, int chunks, int fmt) {
+  const long rows = (long)B * (prefix + T);
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * chunks) return;
+  const long orow = idx / chunks;
+  const int c = (int)(idx - orow * chunks) * 4;
+  const long b = orow / (prefix + T);
+  const long p = orow - b * (prefix + T);
+  const long t = p >= prefix ? p - prefix : prefix - p;    // prefix row p mirrors row (prefix - p)
+  const float* xr = x + (b * (in_prefix + T) + in_prefix + t) * ldx;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c + 3 < C && (ldx & 3) == 0) {
+    const float4 q = *reinterpret_cast<const float4*>(xr + c);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < C) v[e] = xr[c + e];
+  }
+  if (eo.hi && c < eo.cols) {
+    const bool il = fmt_il(fmt, eo.lo);
+    store_cols4(eo.hi + orow * pld(eo.ld, il), eo.col0 + c, eluf(v[0]), eluf(v[1]), eluf(v[2]), eluf(v[3]), fmt, il);
+  }
+  if (ro.hi && c < ro.cols) {
+    const bool il = fmt_il(fmt, ro.lo);
+    store_cols4(ro.hi + orow * pld(ro.ld, il), ro.col0 + c, v[0], v[1], v[2], v[3], fmt, il);
+  }
+}
+static bool prep_out_ok(const PrepOut& o, int C, int fmt) {
+  if (!o.hi) return o.lo == nullptr;
+  if (o.ld <= 0 || (o.ld & 31) || (o.col0 & 31) || o.col0 < 0 || (o.cols & 3) || o.cols < C || o.col0 + o.cols > o.ld) return false;
+  return planes_ok(o.hi, o.lo) && !(fmt == FMT_F16 && o.lo) && !(fmt == FMT_H8 && !o.lo);
+}
+hipError_t launch_seanet_prep2(const float* x, int ldx, int in_prefix, int B, long T, int C, int prefix, bf16_t* elu_hi, bf16_t* elu_lo,
+                               int elu_ld, int elu_col0, int elu_cols, bf16_t* raw_hi, bf16_t* raw_lo, int raw_ld, int raw_col0,
+                               int raw_cols, int fmt, hipStream_t s) {
+  if (B <= 0 || T <= 0 || C <= 0 || prefix < 0 || prefix >= T || in_prefix < 0 || (!elu_hi && !raw_hi)) return hipErrorInvalidValue;
+  const PrepOut eo{elu_hi, elu_lo, elu_ld, elu_col0, elu_cols}, ro{raw_hi, raw_lo, raw_ld, raw_col0, raw_cols};
+  if (!prep_out_ok(eo, C, fmt) || !prep_out_ok(ro, C, fmt)) return hipErrorInvalidValue;
+  const int cols = (elu_hi ? elu_cols : 0) > (raw_hi ? raw_cols : 0) ? elu_cols : raw_cols;
+  const long total = (long)B * (prefix + T) * (cols >> 2);
+  hipLaunchKernelGGL(seanet_prep2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, in_prefix, B, T, C, prefix, eo, ro,
+                     cols >> 2, fmt);
+  return hipGetLastError();
+}
+
 hipError_t launch_seanet_unpad(const float* src, long ld_src, int prefix, float* dst, long ld_dst, int B, long T, int C, hipStream_t s) {
   const long n = (long)B * T * C;
   hipLaunchKernelGGL(seanet_unpad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld_src, prefix, dst, ld_dst, B, T, C);

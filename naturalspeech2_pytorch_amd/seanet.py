@@ -29,7 +29,7 @@ from ._lib import check
 from .model import _PRECISIONS
 
 
-_FUSED_ELU = os.environ.get("NS2_SEANET_FUSED_ELU", "0") == "1"
+_FUSED_RESBLOCK = os.environ.get("NS2_SEANET_FUSED_RESBLOCK", "1") != "0"    # 0: conv1, shortcut, conv2 as three GEMMs (A/B, tests)
 
 
 def _stream():
@@ -43,6 +43,19 @@ def _prep(x, B, T, C, *, in_prefix=0, elu=False, prefix=0, im2col_k=0, add=None,
     check(_lib.load().ns2_seanet_prep(x.data_ptr(), x.shape[-1], in_prefix, ops._p(add), add.shape[-1] if add is not None else 0, B, T,
                                       C, int(elu), prefix, im2col_k, out.hi, out.lo, ldo, precision, _stream()), "ns2_seanet_prep")
     return out
+
+
+def _prep2(x, B, T, C, *, in_prefix=0, prefix=0, elu_out=None, raw_out=None, precision=3):
+    """one pass over fp32 rows [B, in_prefix + T, C]: ELU(x) and / or x into column windows (planes, col0, cols) of plane buffers
+    with `prefix` mirrored rows per utterance (ns2_seanet_prep2)"""
+    def win(o):
+        if o is None:
+            return None, None, 0, 0, 0
+        pl, col0, cols = o
+        assert pl.rows == B * (prefix + T) and pl.precision == precision
+        return pl.hi, pl.lo, pl.ld, col0, cols
+    check(_lib.load().ns2_seanet_prep2(x.data_ptr(), x.shape[-1], in_prefix, B, T, C, prefix, *win(elu_out), *win(raw_out), precision,
+                                       _stream()), "ns2_seanet_prep2")
 
 
 def _unpad(x, B, T, C, prefix):
@@ -117,7 +130,21 @@ class _SEANetHIP(nn.Module):
     def _pack_resblock(self, m):
         convs = [l for l in m.block if not isinstance(l, nn.ELU)]
         assert len(convs) == 2 and not isinstance(m.shortcut, nn.Identity), "EnCodec 24 kHz: two convolutions + conv shortcut"
-        return dict(kind="res", c1=self._pack_conv(convs[0]), c2=self._pack_conv(convs[1]), sc=self._pack_conv(m.shortcut))
+        p = dict(kind="res", c1=self._pack_conv(convs[0]), c2=self._pack_conv(convs[1]), sc=self._pack_conv(m.shortcut))
+        c1, c2, sc = p["c1"], p["c2"], p["sc"]
+        if c1["kind"] == c2["kind"] == sc["kind"] == "conv" and c2["k"] == 1 and sc["k"] == 1:
+            # conv2(elu(h)) + shortcut(x) = [W_c2 | W_sc] [elu(h) ; x]: one GEMM over the concatenated K, the two operands side by
+            # side in one plane buffer (32-column blocks: h in [0, hs), x in [hs, hs + xs))
+            (w2, b2), (ws, bs) = self._w(convs[1]), self._w(m.shortcut)
+            co, ch, cx = w2.shape[0], w2.shape[1], ws.shape[1]
+            hs, xs = ops.round_up(ch, 32), ops.round_up(cx, 32)
+            wcat = torch.zeros(co, hs + xs, dtype=torch.float32, device=w2.device)
+            wcat[:, :ch] = w2[:, :, 0]
+            wcat[:, hs:hs + cx] = ws[:, :, 0]
+            zero = torch.zeros(co, dtype=torch.float32, device=w2.device)
+            p["cat"] = dict(w=ops.PackedWeight(wcat, precision=_PRECISIONS[self.precision]), hs=hs, xs=xs, co=co,
+                            b=(b2 if b2 is not None else zero) + (bs if bs is not None else zero))
+        return p
 
     def _pack_lstm(self, m):
         prec = _PRECISIONS[self.precision]
@@ -187,31 +214,29 @@ class _SEANetHIP(nn.Module):
         raise NotImplementedError(p["kind"])
 
     def _resblock(self, a: _Act, p):
-        """EncodecResnetBlock (HFENC:268-301): conv2(elu(conv1(elu(x)))) + shortcut(x).  All three GEMMs run on the row layout of
-        conv1 -- `prefix` reflected rows in front of every utterance, whose outputs are not data and are skipped by whoever reads
-        the result -- so neither the input nor the hidden activation is ever copied just to drop prefix rows.
-        NS2_SEANET_FUSED_ELU=1: conv1's epilogue applies the second ELU and writes conv2's operand planes itself (act = 2); it
-        saves the fp32 round trip of the hidden activation but leaves through the generic plane epilogue, which measured slower
-        than fp32 epilogue + prep pass on the decoder (tools/gpu_r3_k.sh: encode 26.9 / decode 27.0 ms against 27.7 / 26.4)."""
+        """EncodecResnetBlock (HFENC:268-301): conv2(elu(conv1(elu(x)))) + shortcut(x) as TWO GEMMs: conv1, then conv2 and the
+        shortcut together over the concatenated K (their operands elu(h) | x side by side in one plane buffer, written by two
+        passes that also do the ELUs: ns2_seanet_prep2).  Everything runs on the row layout of conv1 -- `prefix` reflected rows
+        in front of every utterance, whose outputs are not data and are skipped by whoever reads the result -- so nothing is
+        ever copied just to drop prefix rows, and the shortcut's output never exists in memory."""
         prec = _PRECISIONS[self.precision]
-        c1, c2, sc = p["c1"], p["c2"], p["sc"]
-        if not (c1["kind"] == "conv" and c2["kind"] == "conv" and sc["kind"] == "conv" and c2["k"] == 1 and sc["k"] == 1):
+        c1, c2, sc, cat = p["c1"], p["c2"], p["sc"], p.get("cat")
+        if cat is None or not _FUSED_RESBLOCK:
             a = a.clean() if a.prefix else a                      # any other block shape: layer by layer
             h = self._conv(a, c1, elu=True)
             s = self._conv(a, sc, elu=False)
             return self._conv(h, c2, elu=True, resid=s.x)
         B, T, P = a.B, a.T, c1["prefix"]
-        xe = _prep(a.x, B, T, a.C, in_prefix=a.prefix, elu=True, prefix=P, precision=prec)
+        rows = B * (P + T)
+        xe = ops._out_planes(rows, cat["xs"], a.x.device, prec)                                   # elu(x): conv1's operand
+        both = ops._out_planes(rows, cat["hs"] + cat["xs"], a.x.device, prec)                     # [elu(h) | x]
+        _prep2(a.x, B, T, a.C, in_prefix=a.prefix, prefix=P, elu_out=(xe, 0, cat["xs"]), raw_out=(both, cat["hs"], cat["xs"]),
+               precision=prec)
         kw = dict(conv_taps=c1["k"], dilation=c1["dil"], seq_len=P + T) if c1["k"] > 1 else {}
-        if _FUSED_ELU:
-            h = ops.linear_split(c1["w"], xe, bias=c1["b"], precision=prec, act=2, **kw)
-        else:
-            hf = ops.linear_f32(c1["w"], xe, bias=c1["b"], precision=prec, **kw)                         # [B (P + T), co]
-            h = _prep(hf, B, P + T, c1["co"], elu=True, precision=prec)
-        xs = _prep(a.x, B, T, a.C, in_prefix=a.prefix, elu=False, prefix=P, precision=prec)
-        s = ops.linear_f32(sc["w"], xs, bias=sc["b"], precision=prec)
-        y = ops.linear_f32(c2["w"], h, bias=c2["b"], resid=s, precision=prec)
-        return _Act(y, B, T, c2["co"], P)
+        hf = ops.linear_f32(c1["w"], xe, bias=c1["b"], precision=prec, **kw)                      # [B (P + T), C / 2]
+        _prep2(hf, B, P + T, c1["co"], elu_out=(both, 0, cat["hs"]), precision=prec)
+        y = ops.linear_f32(cat["w"], both, bias=cat["b"], precision=prec)
+        return _Act(y, B, T, cat["co"], P)
 
     def _lstm(self, a: _Act, p):
         prec = _PRECISIONS[self.precision]

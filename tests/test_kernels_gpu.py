@@ -168,6 +168,25 @@ def test_conv_elu_epilogue(M, Cin, Cout, k, gemm_kernel):
     assert ops.join(ys)[:, Cout:].abs().sum().item() == 0.0
 
 
+@pytest.mark.parametrize("prec", [3, 4, 2])
+@pytest.mark.parametrize("B,T,C,P,inp", [(2, 50, 16, 2, 0), (3, 33, 32, 2, 2), (1, 20, 70, 0, 1)])
+def test_seanet_prep2_windows(B, T, C, P, inp, prec):
+    """ns2_seanet_prep2: ELU(x) and x of one fp32 activation (garbage prefix rows skipped on the way in, mirrored prefix rows on
+    the way out) into column windows of two plane buffers; columns outside the windows are left alone, padding columns are zeros"""
+    from naturalspeech2_pytorch_amd.seanet import _prep2
+    x = rnd(B * (inp + T), C, seed=300 + C, scale=2.0)
+    cs = ops.round_up(C, 32)
+    e = ops._out_planes(B * (P + T), cs, DEV, prec)
+    both = ops._out_planes(B * (P + T), 32 + cs, DEV, prec, zero=True)
+    _prep2(x, B, T, C, in_prefix=inp, prefix=P, elu_out=(e, 0, cs), raw_out=(both, 32, cs), precision=prec)
+    xv = x.reshape(B, inp + T, C)[:, inp:]
+    ref = torch.cat([xv[:, 1:P + 1].flip(1), xv], dim=1).reshape(B * (P + T), C)          # reflect: row -j = row j
+    tol = {3: 2e-5, 4: 3e-4, 2: 1e-3}[prec]                      # the formats' own rounding: bf16 hi + lo, half + e5m2 residual, half
+    je, jb = ops.join(e), ops.join(both)
+    assert rel(je[:, :C], F.elu(ref)) < tol and rel(jb[:, 32:32 + C], ref) < tol
+    assert je[:, C:].abs().sum().item() == 0.0 and jb[:, 32 + C:].abs().sum().item() == 0.0 and jb[:, :32].abs().sum().item() == 0.0
+
+
 def test_embedding_padding_ids():
     table = rnd(11, 32, seed=93)
     ids = torch.tensor([[0, 5, -1, 9], [-3, 10, 2, 2]], device=DEV)
