@@ -412,14 +412,15 @@ def main():
                 encode_ms=round(1e3 * t_enc, 2), decode_ms=round(1e3 * t_dec, 2),
                 encode_x_realtime=round(secs / t_enc, 1), decode_x_realtime=round(secs / t_dec, 1),
                 parity=dict(frames_checked=2 * nf, frames_with_codes_differing_from_hf=ndiff, decode_rel_err_vs_hf=dec_err),
-                roofline=dict(bound="latency (2 x 1024 dependent LSTM steps) + hbm (activation passes of the wide early layers)",
+                roofline=dict(bound="latency (1024 dependent frame pairs of the 2-layer LSTM) + hbm (activation passes of the wide early layers)",
                               algorithmic_gflop_per_encode=round(fl_enc / 1e9, 1), algorithmic_mb_per_encode=round(by_enc / 1e6, 1),
                               achieved=round(fl_enc / t_enc / 1e12, 2), unit="TFLOP/s", peak=PEAK_16BIT_TFLOPS,
                               frac=round(fl_enc / t_enc / 1e12 / PEAK_16BIT_TFLOPS, 5),
                               mfma_floor_ms=round(3.0 * fl_enc / (PEAK_16BIT_TFLOPS * 1e12) * 1e3, 3),
                               hbm_floor_ms=round(by_enc / 8e12 * 1e3, 4)),
-                note="the 2-layer LSTM recurrence is one persistent launch per layer, the batch in independent 8-row groups side by "
-                     "side, each with its own device-wide barrier per frame; kernel breakdown: profiles/r03_codec_kernel_stats.csv")
+                note="median of 3 calls; both LSTM layers in ONE launch (layer 2 a frame behind layer 1, frames synchronised through "
+                     "tagged values, the batch in independent 8-row groups side by side); residual blocks as two GEMMs (conv2 + shortcut "
+                     "over the concatenated K); kernel breakdown: profiles/r03_codec_kernel_stats.csv, profiles/r03_codec_timeline.txt")
             del hf, codec, wav, emb_c, codes_c, rec
         except Exception as e:                                        # transformers missing / API drift: report, do not fail the line
             side["codec_seanet_rvq"] = dict(skipped=f"{type(e).__name__}: {e}")
