@@ -128,7 +128,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
   // 32-column sub-tiles of this wave that hold real output columns (wave-uniform): the SEANet codec's 1 ... 32-channel
   // convolutions over 10 M rows would otherwise spend 4 x their MFMA time on columns nobody stores
+#ifndef NS2_GEMM_NO_NSKIP                        // A/B switch of experiment builds
   const int nv = g.N - col_base > 32 ? 2 : (g.N - col_base > 0 ? 1 : 0);
+#else
+  constexpr int nv = 2;
+#endif
 
   const int a_frag_off = (wm * 64 + l31) * ROWB + hi * 16;
   const int w_frag_off = (wn * 64 + l31) * ROWB + hi * 16;
