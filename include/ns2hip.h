@@ -155,6 +155,13 @@ int ns2_seanet_prep(const float* x, int ldx, int in_prefix, const float* add, in
 int ns2_seanet_prep2(const float* x, int ldx, int in_prefix, int B, int64_t T, int C, int prefix, uint16_t* elu_hi, uint16_t* elu_lo,
                      int elu_ld, int elu_col0, int elu_cols, uint16_t* raw_hi, uint16_t* raw_lo, int raw_ld, int raw_col0, int raw_cols,
                      int precision, void* stream);
+/* ns2_seanet_conv_narrow: the two ends of the SEANet stacks as what they are -- the encoder's first convolution (ci = 1 -> co
+ *   channels, HFENC:304-327) and the decoder's last (ci -> co = 1, HFENC:330-358): causal, reflect padded (HFENC:142-175), k = 7,
+ *   fp32 on the vector ALUs in one pass over the wide side.  x fp32 [B, in_prefix + T, ci] (row stride ldx), optional ELU on the
+ *   input, w [co, ci, k] as nn.Conv1d holds it, out fp32 [B * T, co] (row stride ldo).  Returns NS2_UNAVAILABLE (nothing launched)
+ *   for any other shape: the caller takes the GEMM path. */
+int ns2_seanet_conv_narrow(const float* x, int64_t ldx, int in_prefix, int B, int64_t T, int ci, int co, int k, int elu, const float* w,
+                           const float* bias, float* out, int64_t ldo, void* stream);
 int ns2_seanet_unpad(const float* src, int64_t ld_src, int prefix, float* dst, int64_t ld_dst, int B, int64_t T, int C, void* stream);
 int64_t ns2_lstm_state_floats(int B, int H);
 int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_hh, const float* b_hh, float* state, int64_t state_floats,

@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 108; }   // 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 109; }   // 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 2, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
   force_gemm_kernel(kernel);
@@ -233,6 +233,15 @@ extern "C" int ns2_seanet_prep2(const float* x, int ldx, int in_prefix, int B, i
   ARGCHK(x && (elu_hi || raw_hi) && prec_ok(precision), "ns2_seanet_prep2: bad arguments");
   HIPRET(launch_seanet_prep2(x, ldx, in_prefix, B, (long)T, C, prefix, elu_hi, elu_lo, elu_ld, elu_col0, elu_cols, raw_hi, raw_lo, raw_ld,
                              raw_col0, raw_cols, op_fmt(precision), (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_seanet_conv_narrow(const float* x, int64_t ldx, int in_prefix, int B, int64_t T, int ci, int co, int k, int elu,
+                                      const float* w, const float* bias, float* out, int64_t ldo, void* stream) {
+  ARGCHK(x && w && out && B > 0 && T > 0 && ci > 0 && co > 0 && k > 0 && in_prefix >= 0, "ns2_seanet_conv_narrow: bad arguments");
+  const hipError_t e = launch_seanet_conv_narrow(x, (long)ldx, in_prefix, B, (long)T, ci, co, k, elu, w, bias, out, (long)ldo,
+                                                 (hipStream_t)stream);
+  if (e == hipErrorNotReady) return NS2_UNAVAILABLE;
+  HIPRET(e);
   return NS2_OK;
 }
 extern "C" int ns2_seanet_unpad(const float* src, int64_t ld_src, int prefix, float* dst, int64_t ld_dst, int B, int64_t T, int C,

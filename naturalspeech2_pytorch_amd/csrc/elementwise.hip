@@ -636,6 +636,103 @@ hipError_t launch_seanet_prep2(const float* x, int ldx, int in_prefix, int B, lo
   return hipGetLastError();
 }
 
+// ---- the two ends of the SEANet stacks: 1 -> co channels (the encoder's first convolution) and ci -> 1 (the decoder's last).
+// As GEMMs they padded a K of 7 to 32 (plus an im2col pass) and an N of 1 to a 64-column wave tile with the operand re-read once
+// per tap; here they are what they are -- 7 x co and 7 x ci multiply-adds per sample in fp32 on the vector ALUs, one pass over the
+// wide side of the layer, causal with EnCodec's reflect padding (HFENC:142-175), optional ELU on the input (HFENC:285-347).
+template <int K>
+__global__ __launch_bounds__(256) void seanet_conv_in_kernel(const float* x, long ldx, int in_prefix, int B, long T, int co, int elu,
+                                                             const float* w, const float* bias, float* out, long ldo, int iters) {
+  const int cg = co >> 2;                          // threads per output row, 4 channels each: whole 16-byte stores, 128 B per row at co = 32
+  const int c4 = (threadIdx.x % cg) * 4, rslot = threadIdx.x / cg, rpb = 256 / cg;
+  float wr[4][K], b4[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    b4[e] = bias ? bias[c4 + e] : 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) wr[e][j] = w[(c4 + e) * K + j];
+  }
+  for (int it = 0; it < iters; ++it) {
+    const long row = ((long)blockIdx.x * iters + it) * rpb + rslot;
+    if (row >= (long)B * T) break;
+    const long b = row / T, t = row - b * T;
+    const float* xb = x + (b * (in_prefix + T) + in_prefix) * ldx;
+    float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      long tt = t - (K - 1) + j;
+      if (tt < 0) tt = -tt;                        // reflection: x[-t] = x[t]
+      float v = xb[tt * ldx];
+      if (elu) v = eluf(v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(wr[e][j], v, acc[e]);
+    }
+    *reinterpret_cast<float4*>(out + row * ldo + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+template <int K>
+__global__ __launch_bounds__(256) void seanet_conv_out_kernel(const float* x, long ldx, int in_prefix, int B, long T, int ci, int elu,
+                                                              const float* w, const float* bias, float* out, long ldo, int R) {
+  const int cg = ci >> 2;                          // lanes per row (a power of two): 16 bytes each, whole 128-B rows at ci = 32
+  const int c4 = (threadIdx.x % cg) * 4;
+  const long grp = ((long)blockIdx.x * 256 + threadIdx.x) / cg;     // a run of R consecutive rows of one utterance
+  const long gpu = (T + R - 1) / R;
+  const long b = grp / gpu;
+  if (b >= B) return;                              // whole groups leave together
+  const long t0 = (grp - b * gpu) * R;
+  const float* xb = x + (b * (in_prefix + T) + in_prefix) * ldx + c4;
+  float wv[4][K];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int j = 0; j < K; ++j) wv[e][j] = w[(c4 + e) * K + j];
+  const float b0 = bias ? bias[0] : 0.f;
+  auto load = [&](long tt) {
+    if (tt < 0) tt = -tt;
+    float4 v = *reinterpret_cast<const float4*>(xb + tt * ldx);
+    if (elu) { v.x = eluf(v.x); v.y = eluf(v.y); v.z = eluf(v.z); v.w = eluf(v.w); }
+    return v;
+  };
+  float4 win[K];                                   // rows t - (K - 1) .. t of this lane's 4 channels, after the ELU
+#pragma unroll
+  for (int j = 0; j + 1 < K; ++j) win[j] = load(t0 - (K - 1) + j);
+  for (int r = 0; r < R && t0 + r < T; ++r) {
+    win[K - 1] = load(t0 + r);
+    float p = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      p = fmaf(wv[0][j], win[j].x, p); p = fmaf(wv[1][j], win[j].y, p); p = fmaf(wv[2][j], win[j].z, p); p = fmaf(wv[3][j], win[j].w, p);
+    }
+    for (int m = cg >> 1; m > 0; m >>= 1) p += __shfl_xor(p, m, 64);
+    if (c4 == 0) out[(b * T + t0 + r) * ldo] = p + b0;
+#pragma unroll
+    for (int j = 0; j + 1 < K; ++j) win[j] = win[j + 1];
+  }
+}
+// hipErrorNotReady: not one of the two shapes (the caller takes the GEMM path)
+hipError_t launch_seanet_conv_narrow(const float* x, long ldx, int in_prefix, int B, long T, int ci, int co, int k, int elu, const float* w,
+                                     const float* bias, float* out, long ldo, hipStream_t s) {
+  if (B <= 0 || T <= 0 || ci <= 0 || co <= 0 || in_prefix < 0 || !x || !w || !out) return hipErrorInvalidValue;
+  if (k != 7 || T < k) return hipErrorNotReady;
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  if (ci == 1 && (co & 3) == 0 && pow2(co >> 2) && co <= 256 && (ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const int rpb = 256 / (co >> 2), iters = 8;
+    const long blocks = ((long)B * T + (long)rpb * iters - 1) / ((long)rpb * iters);
+    hipLaunchKernelGGL(seanet_conv_in_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, in_prefix, B, T, co, elu, w, bias, out, ldo,
+                       iters);
+    return hipGetLastError();
+  }
+  if (co == 1 && (ci & 3) == 0 && pow2(ci >> 2) && ci <= 256 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const int R = 32, cg = ci >> 2;
+    const long groups = (long)B * ((T + R - 1) / R);
+    const long blocks = (groups * cg + 255) / 256;
+    hipLaunchKernelGGL(seanet_conv_out_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, in_prefix, B, T, ci, elu, w, bias, out, ldo,
+                       R);
+    return hipGetLastError();
+  }
+  return hipErrorNotReady;
+}
+
 hipError_t launch_seanet_unpad(const float* src, long ld_src, int prefix, float* dst, long ld_dst, int B, long T, int C, hipStream_t s) {
   const long n = (long)B * T * C;
   hipLaunchKernelGGL(seanet_unpad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld_src, prefix, dst, ld_dst, B, T, C);

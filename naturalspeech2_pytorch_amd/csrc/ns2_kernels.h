@@ -170,6 +170,8 @@ hipError_t launch_seanet_prep(const float* x, int ldx, int in_prefix, const floa
 hipError_t launch_seanet_prep2(const float* x, int ldx, int in_prefix, int B, long T, int C, int prefix, bf16_t* elu_hi, bf16_t* elu_lo,
                                int elu_ld, int elu_col0, int elu_cols, bf16_t* raw_hi, bf16_t* raw_lo, int raw_ld, int raw_col0,
                                int raw_cols, int fmt, hipStream_t s);
+hipError_t launch_seanet_conv_narrow(const float* x, long ldx, int in_prefix, int B, long T, int ci, int co, int k, int elu, const float* w,
+                                     const float* bias, float* out, long ldo, hipStream_t s);
 hipError_t launch_seanet_unpad(const float* src, long ld_src, int prefix, float* dst, long ld_dst, int B, long T, int C, hipStream_t s);
 long lstm_state_floats(int B, int H);     // caller scratch of launch_lstm_layer (h exchange, cell state / barrier counter)
 hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, const float* b_hh, float* h_a, float* h_b,

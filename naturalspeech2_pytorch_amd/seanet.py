@@ -29,6 +29,7 @@ from ._lib import check
 from .model import _PRECISIONS
 
 
+_NARROW_CONV = os.environ.get("NS2_SEANET_NARROW_CONV", "1") != "0"          # 0: the two 1-channel ends as GEMMs (A/B, tests)
 _FUSED_RESBLOCK = os.environ.get("NS2_SEANET_FUSED_RESBLOCK", "1") != "0"    # 0: conv1, shortcut, conv2 as three GEMMs (A/B, tests)
 
 
@@ -104,8 +105,10 @@ class _SEANetHIP(nn.Module):
             "the HIP SEANet implements EnCodec's 24 kHz configuration: causal convolutions, reflect padding, weight norm"
         if stride == 1:
             if ci == 1:                                         # first encoder conv: k taps of one channel as a K = k Linear
-                return dict(w=ops.PackedWeight(w.reshape(co, k).contiguous(), precision=prec), b=b, kind="im2col", k=k, co=co)
-            return dict(w=ops.PackedWeight(w, precision=prec), b=b, kind="conv", k=k, dil=dil, co=co, ci=ci, prefix=(k - 1) * dil)
+                return dict(w=ops.PackedWeight(w.reshape(co, k).contiguous(), precision=prec), b=b, kind="im2col", k=k, co=co, ci=1,
+                            w_f32=w)                             # w_f32: the fp32 vector-ALU path of the two 1-channel ends
+            return dict(w=ops.PackedWeight(w, precision=prec), b=b, kind="conv", k=k, dil=dil, co=co, ci=ci, prefix=(k - 1) * dil,
+                        w_f32=w if (co == 1 and dil == 1) else None)
         assert k == 2 * stride and dil == 1
         # rows regrouped `stride` at a time: W'[co][a][i * ci + c] = W[co][c][a * stride + i]
         w2 = w.reshape(co, ci, 2, stride).permute(0, 2, 3, 1).reshape(co, 2, stride * ci).permute(0, 2, 1).contiguous()
@@ -185,6 +188,14 @@ class _SEANetHIP(nn.Module):
     def _conv(self, a: _Act, p, elu, resid=None):
         prec = _PRECISIONS[self.precision]
         B, T = a.B, a.T
+        if p.get("w_f32") is not None and resid is None and _NARROW_CONV:
+            # 1 -> co / ci -> 1 channels, k = 7: fp32 on the vector ALUs, one pass (ns2_seanet_conv_narrow); other shapes: below
+            y = torch.empty(B * T, p["co"], dtype=torch.float32, device=a.x.device)
+            rc = _lib.load().ns2_seanet_conv_narrow(a.x.data_ptr(), a.x.shape[-1], a.prefix, B, T, p["ci"], p["co"], p["k"], int(elu),
+                                                    p["w_f32"].data_ptr(), ops._p(p["b"]), y.data_ptr(), p["co"], _stream())
+            if rc != _lib.NS2_UNAVAILABLE:
+                check(rc, "ns2_seanet_conv_narrow")
+                return _Act(y, B, T, p["co"], 0)
         if p["kind"] == "im2col":
             pl = _prep(a.x, B, T, 1, in_prefix=a.prefix, elu=elu, im2col_k=p["k"], precision=prec)
             y = ops.linear_f32(p["w"], pl, bias=p["b"], precision=prec)

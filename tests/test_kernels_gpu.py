@@ -187,6 +187,28 @@ def test_seanet_prep2_windows(B, T, C, P, inp, prec):
     assert je[:, C:].abs().sum().item() == 0.0 and jb[:, 32 + C:].abs().sum().item() == 0.0 and jb[:, :32].abs().sum().item() == 0.0
 
 
+@pytest.mark.parametrize("B,T,ci,co,inp,elu", [(2, 300, 1, 32, 0, False), (3, 77, 1, 16, 0, True), (2, 300, 32, 1, 2, True),
+                                                (1, 45, 64, 1, 0, False), (2, 7, 16, 1, 1, True)])
+def test_seanet_conv_narrow(B, T, ci, co, inp, elu):
+    """ns2_seanet_conv_narrow: the 1 -> co and ci -> 1 channel k = 7 causal convolutions with reflect padding (and ELU on the
+    input) in fp32 against torch's conv1d on the reflect-padded signal; an unsupported shape reports NS2_UNAVAILABLE"""
+    from naturalspeech2_pytorch_amd import _lib
+    lib = _lib.load()
+    k = 7
+    x = rnd(B * (inp + T), ci, seed=400 + ci + co, scale=1.5)
+    w = rnd(co, ci, k, seed=401, scale=1 / math.sqrt(k * ci))
+    b = rnd(co, seed=402)
+    y = torch.full((B * T, co), float("nan"), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.ns2_seanet_conv_narrow(x.data_ptr(), ci, inp, B, T, ci, co, k, int(elu), w.data_ptr(), b.data_ptr(), y.data_ptr(), co, st)
+    assert rc == 0, rc
+    xv = x.reshape(B, inp + T, ci)[:, inp:].double()
+    xv = F.elu(xv) if elu else xv
+    ref = F.conv1d(F.pad(xv.transpose(1, 2), (k - 1, 0), mode="reflect"), w.double(), b.double()).transpose(1, 2).reshape(B * T, co)
+    assert rel(y, ref) < 2e-6
+    assert lib.ns2_seanet_conv_narrow(x.data_ptr(), ci, inp, B, T, ci, co, 5, 0, w.data_ptr(), b.data_ptr(), y.data_ptr(), co, st) == _lib.NS2_UNAVAILABLE
+
+
 def test_embedding_padding_ids():
     table = rnd(11, 32, seed=93)
     ids = torch.tensor([[0, 5, -1, 9], [-3, 10, 2, 2]], device=DEV)
