@@ -183,6 +183,8 @@ int ns2_lstm2(const float* xproj1, int64_t ld_x, const float* w_hh1, const float
  * and counts the launch here instead of trapping.  Synchronises; call it after a codec run.  NS2_LSTM_PERSISTENT=0 forces the
  * per-step kernel. */
 int ns2_lstm_abort_count(int reset, int64_t* count);
+/* test hook: set that counter, as if n launches had given up (exercises the caller's fallback from the one-launch recurrences) */
+int ns2_debug_lstm_inject_abort(int n);
 
 /* Range guard of precisions 2 and 4 (IEEE-half operands stop at 65504 / 57344; beyond, values are clamped: finite but
  * wrong).  Counts, on the CURRENT device, the conversions that met an out-of-range (or NaN) value since the last reset.

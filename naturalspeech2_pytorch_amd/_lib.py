@@ -59,6 +59,7 @@ SIGNATURES = {
     "ns2_lstm2_state_floats": (L, []),
     "ns2_lstm2": (I, [P, L, P, P, P, P, P, P, P, L, P, L, P, L, I, L, P]),
     "ns2_lstm_abort_count": (I, [I, POINTER(c_int64)]),
+    "ns2_debug_lstm_inject_abort": (I, [I]),
     "ns2_saturation_count": (I, [I, POINTER(c_int64)]),
     "ns2_saturation_peek_async": (I, [P, P]),
     "ns2_rvq_prepare": (I, [P, P, I, I, I, P]),

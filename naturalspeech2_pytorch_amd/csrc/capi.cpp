@@ -292,6 +292,12 @@ extern "C" int ns2_saturation_count(int reset, int64_t* count) {
   return NS2_OK;
 }
 
+extern "C" int ns2_debug_lstm_inject_abort(int n) {
+  ARGCHK(n >= 0, "ns2_debug_lstm_inject_abort: negative count");
+  HIPRET(hipDeviceSynchronize());
+  HIPRET(lstm_abort_inject((unsigned int)n));
+  return NS2_OK;
+}
 extern "C" int ns2_lstm_abort_count(int reset, int64_t* count) {
   ARGCHK(count != nullptr, "ns2_lstm_abort_count: null pointer");
   HIPRET(hipDeviceSynchronize());

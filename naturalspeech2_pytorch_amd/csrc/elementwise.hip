@@ -1214,6 +1214,9 @@ hipError_t launch_lstm2(const float* xproj, long ld_x, const float* w_hh1, const
   return hipGetLastError();
 }
 
+hipError_t lstm_abort_inject(unsigned int n) {         // test hook: pretend n launches gave up (the host's fallback chain)
+  return hipMemcpyToSymbol(HIP_SYMBOL(ns2_lstm_aborts), &n, sizeof n);
+}
 unsigned int lstm_abort_read(bool reset) {
   unsigned int v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(ns2_lstm_aborts), sizeof v) != hipSuccess) return ~0u;

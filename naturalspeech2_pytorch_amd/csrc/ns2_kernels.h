@@ -185,6 +185,7 @@ hipError_t launch_lstm2(const float* xproj, long ld_x, const float* w_hh1, const
                         const float* w_hh2, const float* b_hh2, float* state, long state_floats, const float* resid, long ld_r, float* out,
                         long ld_o, int B, long T, hipStream_t s);
 
+hipError_t lstm_abort_inject(unsigned int n);   // test hook
 unsigned int lstm_abort_read(bool reset);   // persistent-LSTM launches that gave up at their step barrier since the last reset (synchronising)
 
 // values that left the IEEE-half range in this translation unit's kernels since the last reset (synchronising reads)

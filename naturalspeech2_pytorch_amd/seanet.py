@@ -250,49 +250,61 @@ class _SEANetHIP(nn.Module):
         return _Act(y, B, T, cat["co"], P)
 
     def _lstm(self, a: _Act, p):
+        """EncodecLSTM (HFENC:253-266): lstm(x) + x.  Three ways to run the recurrence, fastest first: both layers in one launch
+        (ns2_lstm2), one launch per layer, one launch per frame.  The first two need all their workgroups resident at once; the
+        launchers check that (NS2_UNAVAILABLE / an internal fallback), and a launch that still had to give up -- a device shared
+        with other work -- is reported by ns2_lstm_abort_count: its output is discarded and the next way is taken."""
+        import ctypes
+        import warnings
         prec = _PRECISIONS[self.precision]
         a = a.clean()
         B, T, H = a.B, a.T, p["H"]
         lib = _lib.load()
-        x = a.x
         layers = p["layers"]
-        out = None
-        if len(layers) == 2 and H == 512:
-            # both layers in one launch, layer 2 one frame behind layer 1 (ns2_lstm2); NS2_UNAVAILABLE -> layer by layer below
+        dev = a.x.device
+        xproj1 = ops.linear_f32(layers[0]["w_ih"], _prep(a.x, B, T, H, precision=prec), bias=layers[0]["b_ih"], precision=prec)   # [B T, 4H]
+
+        def fused():
             l1, l2 = layers
-            xproj = ops.linear_f32(l1["w_ih"], _prep(x, B, T, H, precision=prec), bias=l1["b_ih"], precision=prec)   # [B T, 4H]
             nstate = int(lib.ns2_lstm2_state_floats())
-            state = torch.empty(nstate, dtype=torch.float32, device=x.device)
-            out = torch.empty(B * T, H, dtype=torch.float32, device=x.device)
-            rc = lib.ns2_lstm2(xproj.data_ptr(), 4 * H, l1["w_hh"].data_ptr(), l1["b_hh"].data_ptr(), l2["w_ih_f32"].data_ptr(),
+            state = torch.empty(nstate, dtype=torch.float32, device=dev)
+            out = torch.empty(B * T, H, dtype=torch.float32, device=dev)
+            rc = lib.ns2_lstm2(xproj1.data_ptr(), 4 * H, l1["w_hh"].data_ptr(), l1["b_hh"].data_ptr(), l2["w_ih_f32"].data_ptr(),
                                l2["b_ih"].data_ptr(), l2["w_hh"].data_ptr(), l2["b_hh"].data_ptr(), state.data_ptr(), nstate,
-                               a.x.data_ptr(), H, out.data_ptr(), H, B, T, _stream())                      # HFENC:264: lstm(x) + x
+                               a.x.data_ptr(), H, out.data_ptr(), H, B, T, _stream())
             if rc == _lib.NS2_UNAVAILABLE:
-                out = None
-            else:
-                check(rc, "ns2_lstm2")
-        if out is None:
-            nstate = int(lib.ns2_lstm_state_floats(B, H))
-            state = torch.empty(nstate, dtype=torch.float32, device=x.device)
-            xproj = None
+                return None
+            check(rc, "ns2_lstm2")
+            return out
+
+        def layer_by_layer(per_frame):
+            # the entry point runs one launch per frame when it gets only the minimal scratch (include/ns2hip.h)
+            nstate = 3 * B * H if per_frame else int(lib.ns2_lstm_state_floats(B, H))
+            state = torch.empty(nstate, dtype=torch.float32, device=dev)
+            x, out = a.x, None
             for i, l in enumerate(layers):
-                if not (i == 0 and xproj is not None):
-                    xproj = ops.linear_f32(l["w_ih"], _prep(x, B, T, H, precision=prec), bias=l["b_ih"], precision=prec)
-                out = torch.empty(B * T, H, dtype=torch.float32, device=x.device)
-                last = i + 1 == len(layers)
-                resid = a.x if last else None                                                             # HFENC:264: lstm(x) + x
+                xproj = xproj1 if i == 0 else ops.linear_f32(l["w_ih"], _prep(x, B, T, H, precision=prec), bias=l["b_ih"], precision=prec)
+                out = torch.empty(B * T, H, dtype=torch.float32, device=dev)
+                resid = a.x if i + 1 == len(layers) else None
                 check(lib.ns2_lstm_layer(xproj.data_ptr(), 4 * H, l["w_hh"].data_ptr(), l["b_hh"].data_ptr(), state.data_ptr(), nstate,
                                          ops._p(resid), H, out.data_ptr(), H, B, T, H, _stream()), "ns2_lstm_layer")
-                x, xproj = out, None
-        import ctypes
-        n = ctypes.c_int64(0)
-        check(lib.ns2_lstm_abort_count(1, ctypes.byref(n)), "ns2_lstm_abort_count")       # one synchronisation per codec run
-        if n.value:
-            raise _lib.Ns2Error(
-                f"the one-launch LSTM recurrence gave up waiting for a frame in {n.value} launch(es): not all of its workgroups were "
-                f"resident (CU masking / a device shared with other work).  Set NS2_LSTM_FUSED=0 (one launch per layer) or "
-                f"NS2_LSTM_PERSISTENT=0 (one launch per frame).")
-        return _Act(out, B, T, H, 0)
+                x = out
+            return out
+
+        ways = ([("both layers in one launch", fused)] if len(layers) == 2 and H == 512 else []) + \
+               [("one launch per layer", lambda: layer_by_layer(False)), ("one launch per frame", lambda: layer_by_layer(True))]
+        for name, run in ways:
+            out = run()
+            if out is None:
+                continue
+            n = ctypes.c_int64(0)
+            check(lib.ns2_lstm_abort_count(1, ctypes.byref(n)), "ns2_lstm_abort_count")   # one synchronisation per codec run
+            if n.value == 0:
+                return _Act(out, B, T, H, 0)
+            warnings.warn(f"LSTM recurrence ({name}) gave up waiting for a frame: not all of its workgroups were resident (CU masking / "
+                          f"a device shared with other work); running it the next way.  NS2_LSTM_FUSED=0 / NS2_LSTM_PERSISTENT=0 skip "
+                          f"the one-launch paths altogether.")
+        raise _lib.Ns2Error("the LSTM recurrence could not complete on this device")
 
     def algorithmic_work(self, B, T, C):
         """(FLOPs, compulsory bytes) of one pass over B utterances of T rows x C channels, counted from the layer shapes:

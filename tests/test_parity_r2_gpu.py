@@ -563,6 +563,27 @@ def test_lstm2_both_layers_in_one_launch(B, T):
     assert n.value == 0
 
 
+def test_seanet_lstm_falls_back_when_a_launch_gave_up():
+    """a one-launch recurrence that could not get all its workgroups resident is reported by ns2_lstm_abort_count; seanet.py then
+    discards its output and runs the recurrence the next way (one launch per layer, then per frame).  The give-up is injected
+    through the test hook; the encoder output must not change"""
+    from naturalspeech2_pytorch_amd import _lib
+    from naturalspeech2_pytorch_amd.seanet import SEANetEncoderHIP
+    hf = _hf_encodec()
+    enc = SEANetEncoderHIP(hf.encoder).to(DEV).eval()
+    wav = make_input("wavfb", (3, 1, 320 * 40), seed=97).to(DEV)
+    with torch.no_grad():
+        ref = enc(wav)
+        _lib.check(_lib.load().ns2_debug_lstm_inject_abort(1), "inject")
+        with pytest.warns(UserWarning, match="gave up waiting for a frame"):
+            out = enc(wav)
+    assert rel(out, ref) < 1e-5
+    import ctypes
+    n = ctypes.c_int64(-1)
+    _lib.check(_lib.load().ns2_lstm_abort_count(0, ctypes.byref(n)), "count")
+    assert n.value == 0
+
+
 def test_encodec_wrapper_with_hf_seanet():
     """the boundary class `codec(x, return_encoded=True)` on raw audio (BASELINE configs 1 / 4 input shape randn(4, 327680)):
     HF EnCodec's SEANet encoder injected, RVQ in HIP, against HF's own quantizer on the same encoder output"""
