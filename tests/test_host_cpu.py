@@ -363,3 +363,96 @@ def test_gradient_allreduce_world2_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "OK 2" in r.stdout
+
+
+class _FakeLstmLib:
+    """stands in for libns2hip in the host-logic test of seanet._lstm: records which recurrence entry points ran, reports the
+    scripted availability / give-up outcomes, and writes a marker into `out` so the caller's choice is visible"""
+
+    def __init__(self, fused_rc, aborts):
+        self.fused_rc, self.aborts, self.calls = fused_rc, list(aborts), []
+
+    def ns2_lstm2_state_floats(self):
+        return 16
+
+    def ns2_lstm_state_floats(self, B, H):
+        return 10 ** 6
+
+    def ns2_lstm2(self, *a):
+        self.calls.append("fused")
+        return self.fused_rc
+
+    def ns2_lstm_layer(self, xproj, ldx, whh, bhh, state, nstate, *rest):
+        self.calls.append("frame" if nstate < 10 ** 6 else "layer")
+        return 0
+
+    def ns2_lstm_abort_count(self, reset, ref):
+        ref._obj.value = self.aborts.pop(0)
+        return 0
+
+    def ns2_last_error(self):
+        return b""
+
+
+@pytest.mark.parametrize("fused_rc,aborts,expect", [
+    (0, [0], ["fused"]),                                           # the normal case: one launch, nothing gave up
+    (1, [0], ["fused", "layer", "layer"]),                         # NS2_UNAVAILABLE (nothing launched): one launch per layer
+    (0, [1, 0], ["fused", "layer", "layer"]),                      # the two-layer launch gave up: its output is discarded
+    (0, [1, 2, 0], ["fused", "layer", "layer", "frame", "frame"]),  # ... and so did a per-layer launch: one launch per frame
+])
+def test_seanet_lstm_fallback_chain_host_logic(monkeypatch, fused_rc, aborts, expect):
+    """seanet._lstm without a GPU: both layers in one launch -> one launch per layer -> one launch per frame, moving on when the
+    entry point reports NS2_UNAVAILABLE or ns2_lstm_abort_count says a launch gave up (its output must not be used)"""
+    import warnings
+    from naturalspeech2_pytorch_amd import seanet, ops
+    fake = _FakeLstmLib(fused_rc, aborts)
+    monkeypatch.setattr(seanet._lib, "load", lambda: fake)
+    monkeypatch.setattr(seanet, "_prep", lambda x, B, T, C, **kw: x)
+    monkeypatch.setattr(seanet, "_stream", lambda: 0)
+    monkeypatch.setattr(ops, "linear_f32", lambda w, a, **kw: torch.zeros(a.shape[0], 2048))
+    B, T, H = 2, 5, 512
+    z = torch.zeros(1)
+    layers = [dict(w_ih=None, b_ih=z, w_hh=z, b_hh=z, w_ih_f32=z) for _ in range(2)]
+    net = seanet._SEANetHIP.__new__(seanet._SEANetHIP)
+    torch.nn.Module.__init__(net)
+    net.precision = "exact"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        act = net._lstm(seanet._Act(torch.zeros(B * T, H), B, T, H, 0), dict(layers=layers, H=H))
+    assert fake.calls == expect and fake.aborts == []
+    assert len([x for x in w if "gave up waiting" in str(x.message)]) == len(aborts) - 1
+    assert (act.B, act.T, act.C, act.prefix) == (B, T, H, 0) and act.x.shape == (B * T, H)
+
+
+def test_seanet_resblock_concatenated_weight(monkeypatch):
+    """_pack_resblock: conv2(elu(h)) + shortcut(x) as ONE matrix over [elu(h) | x] in 32-column blocks (HFENC:268-301) -- the
+    packed matrix applied to the concatenated operand equals the two convolutions of HF's block"""
+    tf = pytest.importorskip("transformers")
+    from transformers.models.encodec.modeling_encodec import EncodecResnetBlock
+    from naturalspeech2_pytorch_amd import seanet, ops
+    held = {}
+
+    class Holder:                                                   # keeps the fp32 matrix a PackedWeight would pack
+        def __init__(self, w, precision=3):
+            self.w = w
+            self.rows, self.cols = w.shape[0], w.shape[1]
+    monkeypatch.setattr(ops, "PackedWeight", Holder)
+    torch.manual_seed(0)
+    cfg = tf.EncodecConfig()
+    blk = EncodecResnetBlock(cfg, dim=48, dilations=[1, 1]).eval()
+    net = seanet._SEANetHIP.__new__(seanet._SEANetHIP)
+    torch.nn.Module.__init__(net)
+    net.precision = "exact"
+    p = net._pack_resblock(blk)
+    cat = p["cat"]
+    assert (cat["hs"], cat["xs"], cat["co"]) == (32, 64, 48)
+    x = torch.randn(48, 30)
+    with torch.no_grad():
+        convs = [l for l in blk.block if not isinstance(l, torch.nn.ELU)]
+        h = convs[0](torch.nn.functional.elu(x[None]))              # [1, 24, 30]
+        ref = blk(x[None])[0].t()                                   # [30, 48]
+        both = torch.zeros(30, cat["hs"] + cat["xs"])
+        both[:, :24] = torch.nn.functional.elu(h[0]).t()
+        both[:, cat["hs"]:cat["hs"] + 48] = x.t()
+        got = both @ cat["w"].w.t() + cat["b"]
+    assert torch.allclose(got, ref, atol=1e-5), (got - ref).abs().max()
