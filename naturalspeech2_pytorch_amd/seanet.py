@@ -264,30 +264,41 @@ class _SEANetHIP(nn.Module):
         dev = a.x.device
         xproj1 = ops.linear_f32(layers[0]["w_ih"], _prep(a.x, B, T, H, precision=prec), bias=layers[0]["b_ih"], precision=prec)   # [B T, 4H]
 
+        CH = 32                                    # batch rows per one-launch recurrence (rows are independent: larger batches in chunks)
+        chunks = [(b0, min(CH, B - b0)) for b0 in range(0, B, CH)]
+
+        def rows(t, b0, nb):                       # rows b0 T .. (b0 + nb) T of a [B T, *] tensor (a view)
+            return t[b0 * T:(b0 + nb) * T]
+
         def fused():
             l1, l2 = layers
             nstate = int(lib.ns2_lstm2_state_floats())
             state = torch.empty(nstate, dtype=torch.float32, device=dev)
             out = torch.empty(B * T, H, dtype=torch.float32, device=dev)
-            rc = lib.ns2_lstm2(xproj1.data_ptr(), 4 * H, l1["w_hh"].data_ptr(), l1["b_hh"].data_ptr(), l2["w_ih_f32"].data_ptr(),
-                               l2["b_ih"].data_ptr(), l2["w_hh"].data_ptr(), l2["b_hh"].data_ptr(), state.data_ptr(), nstate,
-                               a.x.data_ptr(), H, out.data_ptr(), H, B, T, _stream())
-            if rc == _lib.NS2_UNAVAILABLE:
-                return None
-            check(rc, "ns2_lstm2")
+            for b0, nb in chunks:
+                rc = lib.ns2_lstm2(rows(xproj1, b0, nb).data_ptr(), 4 * H, l1["w_hh"].data_ptr(), l1["b_hh"].data_ptr(),
+                                   l2["w_ih_f32"].data_ptr(), l2["b_ih"].data_ptr(), l2["w_hh"].data_ptr(), l2["b_hh"].data_ptr(),
+                                   state.data_ptr(), nstate, rows(a.x, b0, nb).data_ptr(), H, rows(out, b0, nb).data_ptr(), H, nb, T,
+                                   _stream())
+                if rc == _lib.NS2_UNAVAILABLE:
+                    assert b0 == 0, "availability is a property of the device, not of the chunk"
+                    return None
+                check(rc, "ns2_lstm2")
             return out
 
         def layer_by_layer(per_frame):
             # the entry point runs one launch per frame when it gets only the minimal scratch (include/ns2hip.h)
-            nstate = 3 * B * H if per_frame else int(lib.ns2_lstm_state_floats(B, H))
-            state = torch.empty(nstate, dtype=torch.float32, device=dev)
             x, out = a.x, None
             for i, l in enumerate(layers):
                 xproj = xproj1 if i == 0 else ops.linear_f32(l["w_ih"], _prep(x, B, T, H, precision=prec), bias=l["b_ih"], precision=prec)
                 out = torch.empty(B * T, H, dtype=torch.float32, device=dev)
                 resid = a.x if i + 1 == len(layers) else None
-                check(lib.ns2_lstm_layer(xproj.data_ptr(), 4 * H, l["w_hh"].data_ptr(), l["b_hh"].data_ptr(), state.data_ptr(), nstate,
-                                         ops._p(resid), H, out.data_ptr(), H, B, T, H, _stream()), "ns2_lstm_layer")
+                for b0, nb in ([(0, B)] if per_frame else chunks):
+                    nstate = 3 * nb * H if per_frame else int(lib.ns2_lstm_state_floats(nb, H))
+                    state = torch.empty(nstate, dtype=torch.float32, device=dev)
+                    check(lib.ns2_lstm_layer(rows(xproj, b0, nb).data_ptr(), 4 * H, l["w_hh"].data_ptr(), l["b_hh"].data_ptr(),
+                                             state.data_ptr(), nstate, ops._p(rows(resid, b0, nb) if resid is not None else None), H,
+                                             rows(out, b0, nb).data_ptr(), H, nb, T, H, _stream()), "ns2_lstm_layer")
                 x = out
             return out
 

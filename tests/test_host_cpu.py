@@ -370,7 +370,7 @@ class _FakeLstmLib:
     scripted availability / give-up outcomes, and writes a marker into `out` so the caller's choice is visible"""
 
     def __init__(self, fused_rc, aborts):
-        self.fused_rc, self.aborts, self.calls = fused_rc, list(aborts), []
+        self.fused_rc, self.aborts, self.calls, self.rows = fused_rc, list(aborts), [], []
 
     def ns2_lstm2_state_floats(self):
         return 16
@@ -380,10 +380,12 @@ class _FakeLstmLib:
 
     def ns2_lstm2(self, *a):
         self.calls.append("fused")
+        self.rows.append(a[-3])                                      # B of this launch
         return self.fused_rc
 
     def ns2_lstm_layer(self, xproj, ldx, whh, bhh, state, nstate, *rest):
         self.calls.append("frame" if nstate < 10 ** 6 else "layer")
+        self.rows.append(rest[-4])
         return 0
 
     def ns2_lstm_abort_count(self, reset, ref):
@@ -422,6 +424,26 @@ def test_seanet_lstm_fallback_chain_host_logic(monkeypatch, fused_rc, aborts, ex
     assert fake.calls == expect and fake.aborts == []
     assert len([x for x in w if "gave up waiting" in str(x.message)]) == len(aborts) - 1
     assert (act.B, act.T, act.C, act.prefix) == (B, T, H, 0) and act.x.shape == (B * T, H)
+
+
+def test_seanet_lstm_chunks_large_batches(monkeypatch):
+    """more than 32 utterances: the one-launch recurrences run per chunk of 32 batch rows, the per-frame form takes them all"""
+    from naturalspeech2_pytorch_amd import seanet, ops
+    fake = _FakeLstmLib(0, [1, 1, 0])
+    monkeypatch.setattr(seanet._lib, "load", lambda: fake)
+    monkeypatch.setattr(seanet, "_prep", lambda x, B, T, C, **kw: x)
+    monkeypatch.setattr(seanet, "_stream", lambda: 0)
+    monkeypatch.setattr(ops, "linear_f32", lambda w, a, **kw: torch.zeros(a.shape[0], 2048))
+    B, T, H = 70, 3, 512
+    z = torch.zeros(1)
+    layers = [dict(w_ih=None, b_ih=z, w_hh=z, b_hh=z, w_ih_f32=z) for _ in range(2)]
+    net = seanet._SEANetHIP.__new__(seanet._SEANetHIP)
+    torch.nn.Module.__init__(net)
+    net.precision = "exact"
+    with pytest.warns(UserWarning):
+        net._lstm(seanet._Act(torch.zeros(B * T, H), B, T, H, 0), dict(layers=layers, H=H))
+    assert fake.calls == ["fused"] * 3 + ["layer"] * 6 + ["frame"] * 2
+    assert fake.rows == [32, 32, 6] + [32, 32, 6] * 2 + [70, 70]
 
 
 def test_seanet_resblock_concatenated_weight(monkeypatch):

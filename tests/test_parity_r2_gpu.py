@@ -477,6 +477,19 @@ def test_seanet_encoder_decoder_match_hf(precision, tol):
     assert e_enc < tol and e_dec < tol, (e_enc, e_dec)
 
 
+def test_seanet_encoder_batch_beyond_one_lstm_launch():
+    """40 utterances: the one-launch LSTM recurrences take at most 32 batch rows, larger batches go through them in chunks (rows are
+    independent through the recurrence) -- against HF's encoder"""
+    from naturalspeech2_pytorch_amd import SEANetEncoderHIP
+    hf = _hf_encodec()
+    wav = make_input("wav40", (40, 1, 320 * 12), seed=98).to(DEV)
+    with torch.no_grad():
+        ref_lat = hf.encoder(wav)
+        lat = SEANetEncoderHIP(hf.encoder)(wav)
+    assert lat.shape == ref_lat.shape == (40, 128, 12)
+    assert rel(lat, ref_lat) < 2e-4 and rel(lat[32:], ref_lat[32:]) < 2e-4
+
+
 def test_seanet_pieces():
     """the pieces around the GEMMs: reflect prefix + ELU + im2col (ns2_seanet_prep), and one LSTM layer vs torch.nn.LSTM"""
     from naturalspeech2_pytorch_amd import seanet as S
