@@ -17,9 +17,11 @@
  *     4 = "mixed": the IEEE-half product plus BOTH first-order correction terms (a_hi.w_lo + a_lo.w_hi) evaluated in one
  *         block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, e5m2 operands) per 32-deep k block: 4e-5-class accuracy
  *         at two thirds of the MFMA work of precision 3.
- *   - the library keeps no mutable host state and never allocates on a launch path: scratch is caller-owned
+ *   - the library keeps no mutable host state on a launch path and never allocates there: scratch is caller-owned
  *     (ns2_*_workspace_bytes), constants live in per-device __device__ storage, so one host thread per device (or one
- *     process per device) may drive several devices concurrently, also under stream capture.
+ *     process per device) may drive several devices concurrently, also under stream capture.  What it does keep, all of it
+ *     write-once or atomic: per-device "attribute raised" / occupancy answers, the environment switches NS2_GEMM,
+ *     NS2_LSTM_PERSISTENT and NS2_LSTM_FUSED (read once per process), and the test hooks ns2_debug_*.
  *   - layout of a split-plane matrix (x_hi, x_lo, ld): `ld` is the LOGICAL column count, a multiple of 32.
  *     x_lo != NULL: ONE bf16 buffer [rows, 2*ld]; every 32 logical columns occupy a 128-byte line [hi(32) | lo(32)],
  *       i.e. element (r, c) has hi at r*2*ld + ((c & ~31) << 1) + (c & 31) and lo 32 elements further; the caller
