@@ -236,6 +236,19 @@ int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_prompt, cons
  * n_cond = the n_cond the cond_state was prepared with */
 int ns2_model_forward(ns2_model* m, const float* x, const float* times, const void* cond_state, int n_cond, float* out, int B,
                       int N, void* workspace, int64_t workspace_bytes, void* stream);
+/* Step-invariant TIME conditioning.  A sampler knows its times up front and they are shared by the batch
+ * (get_sampling_timesteps, NS2:1303-1308), so every time-conditioning projection of the run (to_time_cond NS2:839-843 + the FiLM /
+ * adaptive-norm Linears NS2:623, 744) is ONE table: ns2_model_time_table fills table[T, ns2_model_table_cols(m)] for times[T]
+ * (device), and ns2_model_forward_row runs Model.forward for the step whose conditioning is `cond_row` = table + i * cols -- no
+ * projection is launched inside the step.  Rows are computed with the K split of a batch of plan_B rows (pass the run's batch size):
+ * for an unconditional model the step is then BIT-IDENTICAL to ns2_model_forward(times = t_i for every utterance); a conditioned
+ * model adds the per-utterance prompt half kept in its cond_state (sum order differs: equal to fp32 rounding). */
+int ns2_model_table_cols(const ns2_model* m);
+int64_t ns2_model_time_table_workspace_bytes(const ns2_model* m, int plan_B);
+int ns2_model_time_table(ns2_model* m, const float* times, int T, int plan_B, float* table, void* workspace, int64_t workspace_bytes,
+                         void* stream);
+int ns2_model_forward_row(ns2_model* m, const float* x, const float* cond_row, const void* cond_state, int n_cond, float* out, int B, int N,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 /* optional intermediate taps for parity tests (fp32 copies made during forward / prepare_cond): "t", "c",
  * "wavenet.init", "wavenet.stack<s>", "wavenet.out", "layer<i>.attn", "layer<i>"; dst = null unregisters */
 int ns2_model_debug_tap(ns2_model* m, const char* name, float* dst, int64_t dst_elems);
@@ -245,6 +258,89 @@ int ns2_model_debug_tap(ns2_model* m, const char* name, float* dst, int64_t dst_
 int ns2_model_profile_begin(ns2_model* m, unsigned category_mask);
 int ns2_model_profile_end(ns2_model* m, double* total_ms, int64_t* launches);
 void ns2_model_destroy(ns2_model* m);
+
+/* ------------------------------------------------------------------ training: the backward pass
+ * What `loss.backward()` runs for the denoiser (NS2:1635 `pred = self.model(...)` under autograd, NS2:1637-1666 the loss,
+ * NS2:1886 `accelerator.backward`).  All operand planes of this section are precision 3 (bf16 hi / lo, interleaved lines).
+ * The contractions reuse the forward GEMM family:
+ *   dgrad  dX = dY W   : ns2_linear_f32 on a SECOND pack of the weight -- ns2_weight_pack of W^T ([in, out, taps] with the taps
+ *                        flipped), conv_taps as in the forward, pad_left = 0 (the gradient of a causal conv looks ahead);
+ *   wgrad  dW = dY^T X : ns2_wgrad on TRANSPOSED planes (contraction over the tokens), split over fixed slots + fixed-order sum.
+ * Every reduction of this section is slot based and summed in a fixed order: gradients are deterministic, no atomics. */
+
+/* re-pack a weight IN PLACE from new fp32 values (same shape / flags as the ns2_weight_pack call that made it): stream-ordered,
+ * no allocation, no synchronisation -- the per-step refresh of an optimizer's weights */
+int ns2_weight_update(ns2_weight* w, const float* w_src, const float* extra1x1, void* stream);
+
+/* fp32 gradient x [M, C] (row stride ldx) -> any of
+ *   row planes [M, ld_row] (zero beyond C)                                  -- the A operand of the dgrad GEMM;
+ *   transposed planes T[c][m] with ld_t token columns (ld_t a multiple of 32, zero beyond M) and t_rows rows (zero beyond C; a
+ *     W operand of ns2_wgrad needs its rows padded to a multiple of 256)    -- the operands of ns2_wgrad;
+ *     per_batch != 0: T[b * t_rows + c][n] per utterance of seq_len tokens   -- the transposed operands of ns2_attention_bwd;
+ *     shift: T[c][m] = x[m - shift][c] if m - shift lies in the utterance of m (seq_len tokens each), else 0;
+ *   colsum_partial [ns2_grad_prep_slices(M, ld_t)][C]: column sums of 64-row tiles (sum the slots with ns2_reduce_slices:
+ *     the bias gradient). */
+int64_t ns2_grad_prep_slices(int M, int64_t ld_t);
+int ns2_grad_prep(const float* x, int64_t ldx, int M, int C, int seq_len, int shift, uint16_t* row_hi, uint16_t* row_lo, int ld_row,
+                  uint16_t* t_hi, uint16_t* t_lo, int64_t ld_t, int t_rows, int per_batch, float* colsum_partial, void* stream);
+/* the same transposition for an activation that already exists as operand planes (columns [in_col0, in_col0 + C) of [M, ld_in]):
+ * tap t of a causal conv (NS2:583-595) contributes x[n - (k - 1 - t) * dilation], i.e. shift = (k - 1 - t) * dilation */
+int ns2_planes_transpose(const uint16_t* in_hi, const uint16_t* in_lo, int ld_in, int in_col0, int M, int C, int seq_len, int shift,
+                         uint16_t* t_hi, uint16_t* t_lo, int64_t ld_t, int t_rows, int per_batch, void* stream);
+/* out[o * inner + j] (+)= sum_s partial[(o * S + s) * inner + j], s in increasing order */
+int ns2_reduce_slices(const float* partial, int64_t outer, int S, int64_t inner, float* out, int accumulate, void* stream);
+/* weight gradient of nn.Linear / CausalConv1d (NS2:583-595, 1021-1024, 1051-1069): dw[r, k, t] = sum_m dY[m, r] * X_t[m, k].
+ * dyt: transposed planes of dY, R rows; xt: transposed planes of the T (shifted) inputs stacked along the rows, tap t at rows
+ * [t * Kp, t * Kp + K), allocated (zeros) up to the next multiple of 256 rows; both with ld_t token columns.  dw [R, K, T] fp32
+ * (the nn.Conv1d layout; T = 1: nn.Linear).  workspace = ns2_wgrad_workspace_bytes(R, T * Kp, ld_t) bytes of caller scratch. */
+int64_t ns2_wgrad_workspace_bytes(int R, int ncols, int64_t ld_t);
+int ns2_wgrad(const uint16_t* dyt_hi, const uint16_t* dyt_lo, const uint16_t* xt_hi, const uint16_t* xt_lo, int64_t ld_t, int R, int T,
+              int Kp, int K, float* dw, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* WavenetResBlock's FiLM + gate (NS2:629-636) for the unfused training forward: out = tanh(z) * sigmoid(z), z = h * gamma_b + beta_b,
+ * film[b] = [gamma (d) | beta (d)]; and its backward: dh = dg g'(z) gamma, partial[(b * slices + s)] = [sum dg g'(z) h | sum dg g'(z)]
+ * over the s-th group of tokens of utterance b (ns2_film_gate_slices(seq_len) groups; ns2_reduce_slices gives d film [B, 2 d]) */
+int ns2_film_gate_fwd(const float* h, int64_t ldh, const float* film, int film_ld, int seq_len, int64_t M, int d, float* out, int64_t ldo,
+                      void* stream);
+int ns2_film_gate_slices(int seq_len);
+int ns2_film_gate_bwd(const float* dg, int64_t lddg, const float* h, int64_t ldh, const float* film, int film_ld, int B, int seq_len, int d,
+                      float* dh, int64_t lddh, float* partial, void* stream);
+/* GEGLU (NS2:1004-1007) on the saved pre-activation pre [M, ldp] = [x (f) | gate (f)]: planes of gelu(gate) * x, and the backward */
+int ns2_geglu_fwd(const float* pre, int64_t ldp, int64_t M, int f, uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream);
+int ns2_geglu_bwd(const float* dh, int64_t lddh, const float* pre, int64_t ldp, int64_t M, int f, float* dpre, int64_t lddp, void* stream);
+/* RMSNorm backward (NS2:727-746): dx = (dx_add ? dx_add : 0) + dL/dx (dx may alias dx_add: the residual stream's gradient);
+ * cond_partial [B * slices][2 d] -> the adaptive (gamma_c, beta_c) gradients, gamma_partial [B * slices][d] -> the learned gamma's */
+int ns2_rmsnorm_bwd_slices(int seq_len);
+int ns2_rmsnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma, const float* cond, int cond_ld, int B,
+                    int seq_len, int d, const float* dx_add, float* dx, int64_t lddx, float* cond_partial, float* gamma_partial, void* stream);
+
+/* ns2_attention that also returns lse [B, H, Nq] = log2 of the softmax denominator of the scaled scores (m + log2 l): what the
+ * backward recomputes P from (ATT:77-155; no key-padding mask on this path: Model never passes one) */
+int ns2_attention_lse(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi, const uint16_t* k_lo, int ldk,
+                      int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld, uint16_t* o_hi, uint16_t* o_lo, int ldo, int B,
+                      int H, int Nq, int Nk, float scale, float* lse, int precision, void* stream);
+/* delta[b, h, q] = sum_d dO[q, 64 h + d] * O[q, 64 h + d] (O from its operand planes) */
+int ns2_attention_delta(const float* d_out, int64_t ld_dout, const uint16_t* o_hi, const uint16_t* o_lo, int ldo, int B, int H, int Nq,
+                        float* delta, void* stream);
+/* flash-attention backward, head dim 64: dq = scale * dS k, dk = scale * dS^T q, dv = P^T dO with P recomputed from lse and
+ * dS = P (dO v^T - delta).  q / k / v / d_out: row-major planes (head h at columns col0 + 64 h); kt / qt / dot: per-utterance
+ * transposed planes [B][H * 64][ld] (ns2_planes_transpose / ns2_grad_prep with per_batch = 1).  dq == NULL or dk == dv == NULL
+ * skips that half (cross-attention to a context that needs no gradient). */
+typedef struct {
+  const uint16_t* q_hi; const uint16_t* q_lo; int ldq, q_col0;
+  const uint16_t* k_hi; const uint16_t* k_lo; int ldk, k_col0;
+  const uint16_t* v_hi; const uint16_t* v_lo; int ldv, v_col0;
+  const uint16_t* do_hi; const uint16_t* do_lo; int lddo;
+  const uint16_t* kt_hi; const uint16_t* kt_lo; int kt_ld;
+  const uint16_t* qt_hi; const uint16_t* qt_lo; int qt_ld;
+  const uint16_t* dot_hi; const uint16_t* dot_lo; int dot_ld;
+  const float* lse; const float* delta;
+  float* dq; int lddq, dq_col0;
+  float* dk; int lddk, dk_col0;
+  float* dv; int lddv, dv_col0;
+  int B, H, Nq, Nk; float scale;
+} ns2_attn_bwd_args;
+int ns2_attention_bwd(const ns2_attn_bwd_args* args, void* stream);
 
 #ifdef __cplusplus
 }

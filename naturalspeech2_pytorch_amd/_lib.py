@@ -26,6 +26,23 @@ I = c_int
 F = c_float
 L = c_int64
 
+
+class AttnBwdArgs(ctypes.Structure):
+    """ns2_attn_bwd_args (include/ns2hip.h), field for field"""
+    _fields_ = [("q_hi", P), ("q_lo", P), ("ldq", I), ("q_col0", I),
+                ("k_hi", P), ("k_lo", P), ("ldk", I), ("k_col0", I),
+                ("v_hi", P), ("v_lo", P), ("ldv", I), ("v_col0", I),
+                ("do_hi", P), ("do_lo", P), ("lddo", I),
+                ("kt_hi", P), ("kt_lo", P), ("kt_ld", I),
+                ("qt_hi", P), ("qt_lo", P), ("qt_ld", I),
+                ("dot_hi", P), ("dot_lo", P), ("dot_ld", I),
+                ("lse", P), ("delta", P),
+                ("dq", P), ("lddq", I), ("dq_col0", I),
+                ("dk", P), ("lddk", I), ("dk_col0", I),
+                ("dv", P), ("lddv", I), ("dv_col0", I),
+                ("B", I), ("H", I), ("Nq", I), ("Nk", I), ("scale", F)]
+
+
 # name -> (restype, argtypes); mirrors include/ns2hip.h line by line
 SIGNATURES = {
     "ns2_last_error": (c_char_p, []),
@@ -72,10 +89,32 @@ SIGNATURES = {
     "ns2_model_cond_bytes": (L, [P, I, I, I, I]),
     "ns2_model_prepare_cond": (I, [P, P, I, P, I, I, I, I, P, P, L, P]),
     "ns2_model_forward": (I, [P, P, P, P, I, P, I, I, P, L, P]),
+    "ns2_model_table_cols": (I, [P]),
+    "ns2_model_time_table_workspace_bytes": (L, [P, I]),
+    "ns2_model_time_table": (I, [P, P, I, I, P, P, L, P]),
+    "ns2_model_forward_row": (I, [P, P, P, P, I, P, I, I, P, L, P]),
     "ns2_model_debug_tap": (I, [P, c_char_p, P, L]),
     "ns2_model_profile_begin": (I, [P, ctypes.c_uint]),
     "ns2_model_profile_end": (I, [P, POINTER(ctypes.c_double), POINTER(c_int64)]),
     "ns2_model_destroy": (None, [P]),
+    # ---- training: the backward pass
+    "ns2_weight_update": (I, [P, P, P, P]),
+    "ns2_grad_prep_slices": (L, [I, L]),
+    "ns2_grad_prep": (I, [P, L, I, I, I, I, P, P, I, P, P, L, I, I, P, P]),
+    "ns2_planes_transpose": (I, [P, P, I, I, I, I, I, I, P, P, L, I, I, P]),
+    "ns2_reduce_slices": (I, [P, L, I, L, P, I, P]),
+    "ns2_wgrad_workspace_bytes": (L, [I, I, L]),
+    "ns2_wgrad": (I, [P, P, P, P, L, I, I, I, I, P, P, L, P]),
+    "ns2_film_gate_fwd": (I, [P, L, P, I, I, L, I, P, L, P]),
+    "ns2_film_gate_slices": (I, [I]),
+    "ns2_film_gate_bwd": (I, [P, L, P, L, P, I, I, I, I, P, L, P, P]),
+    "ns2_geglu_fwd": (I, [P, L, L, I, P, P, I, P]),
+    "ns2_geglu_bwd": (I, [P, L, P, L, L, I, P, L, P]),
+    "ns2_rmsnorm_bwd_slices": (I, [I]),
+    "ns2_rmsnorm_bwd": (I, [P, L, P, L, P, P, I, I, I, I, P, P, L, P, P, P]),
+    "ns2_attention_lse": (I, [P, P, I, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, F, P, I, P]),
+    "ns2_attention_delta": (I, [P, L, P, P, I, I, I, I, P, P]),
+    "ns2_attention_bwd": (I, [POINTER(AttnBwdArgs), P]),
 }
 
 NS2_UNAVAILABLE = 1          # include/ns2hip.h: "this fast path does not apply here" (not an error)

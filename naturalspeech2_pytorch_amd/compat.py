@@ -26,14 +26,22 @@ def hip_backed_model_class(reference_model_cls):
     defaults = {k: v.default for k, v in sig.parameters.items() if v.default is not inspect.Parameter.empty}
 
     class HipBackedModel(HipDenoiserMixin, reference_model_cls):
-        def __init__(self, dim, *args, precision="exact", **kwargs):
+        def __init__(self, dim, *args, precision="exact", train_backend="reference", **kwargs):
             reference_model_cls.__init__(self, dim, *args, **kwargs)
             bound = sig.bind(self, dim, *args, **kwargs)
             cfg = dict(defaults)
             cfg.update({k: v for k, v in bound.arguments.items() if k != "self"})
             self._hip_init({k: cfg[k] for k in _CFG_KEYS}, precision)
+            assert train_backend in ("reference", "hip")
+            self.train_backend = train_backend
 
         def _forward_autograd(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None):
+            """train_backend="reference" (default): the reference's own forward under torch autograd -- the loss is upstream's bit for
+            bit.  "hip": forward AND backward in libns2hip (training.py), through the reference's own parameters; the unmodified
+            reference `Trainer` / `NaturalSpeech2.forward` (NS2:1635, 1886) then trains on the HIP kernels."""
+            if self.train_backend == "hip" and x.is_cuda:
+                from .training import model_forward_train
+                return model_forward_train(self, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)
             return reference_model_cls.forward(self, x, times, prompt=prompt, prompt_mask=prompt_mask, cond=cond,
                                                cond_drop_prob=cond_drop_prob)
 

@@ -43,7 +43,9 @@ NS2_DEVINL uint4 mask_chunk(uint4 v, int nvalid) {
 // for three (one 4-byte spill outside the loop) it runs 9.5 % faster at the headline shape (0.1439 -> 0.1302 ms, 478 -> 528 TF):
 // the loop is VALU-bound (softmax) and lock-stepped by one barrier per tile, so a third wave per SIMD is what overlaps one
 // wave's exp / max / convert work with another's MFMAs.  Four waves (<= 128 VGPRs) spills 60+ registers.
-template <int NSPLIT, bool F16, int NW>
+// WLSE: also write the log-sum-exp the backward kernels recompute P from (training); a separate instantiation, so the inference
+// kernels keep their register allocation (three waves per SIMD is a one-register margin, see above)
+template <int NSPLIT, bool F16, int NW, bool WLSE>
 __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(const AttnArgs a) {
   constexpr int NP = (NSPLIT == 3) ? 2 : 1;
   constexpr int QB = 32 * NW;                        // query rows per workgroup
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(co
   // ---- normalise and write O[q][h*64 + d]: lane holds d = 32dt + 8g + 4hi + e for its query
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
+  if constexpr (WLSE) if (q_ok && hi == 0) a.lse[((long)b * a.H + h) * a.Nq + qrow] = m_run + log2f(l_tot);   // training: P is recomputed from this
   if (q_ok) {
     bf16_t* orow = a.o_hi + ((long)b * a.Nq + qrow) * pld(a.ldo, oil);
 #pragma unroll
@@ -263,20 +266,24 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(co
   }
 }
 
-template <int NSPLIT, bool F16, int NW>
+template <int NSPLIT, bool F16, int NW, bool WLSE>
 static hipError_t launch_attn_w(const AttnArgs& a, hipStream_t s) {
   const size_t lds = 2 * 2 * (NSPLIT == 3 ? 2 : 1) * AT_PLANE;
   static DynLdsAttr attr;
   {
-    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attn_kernel<NSPLIT, F16, NW>), (int)lds);
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attn_kernel<NSPLIT, F16, NW, WLSE>), (int)lds);
     if (e != hipSuccess) return e;
   }
   dim3 grid(((a.Nq + 32 * NW - 1) / (32 * NW)) * a.H * a.B);
-  hipLaunchKernelGGL((attn_kernel<NSPLIT, F16, NW>), grid, dim3(64 * NW), lds, s, a);
+  hipLaunchKernelGGL((attn_kernel<NSPLIT, F16, NW, WLSE>), grid, dim3(64 * NW), lds, s, a);
   return hipGetLastError();
 }
 template <int NSPLIT, bool F16>
-static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) { return launch_attn_w<NSPLIT, F16, 4>(a, s); }
+static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
+  if constexpr (NSPLIT == 3) { if (a.lse) return launch_attn_w<NSPLIT, F16, 4, true>(a, s); }   // training runs in precision 3
+  else if (a.lse) return hipErrorInvalidValue;
+  return launch_attn_w<NSPLIT, F16, 4, false>(a, s);
+}
 
 hipError_t launch_attention(const AttnArgs& a_in, int nsplit, hipStream_t s) {
   AttnArgs a = a_in;

@@ -1,0 +1,702 @@
+// Backward (training) kernels of the NaturalSpeech2 denoiser on gfx950 -- SURVEY §8f-4: the arithmetic behind
+// `loss.backward()` of NS2:1635-1666, 1886.
+//
+// How the backward pass maps onto the machine:
+//   * every contraction of the backward pass is a call of the FORWARD GEMM family (gemm.hip / gemm2.hip):
+//       dgrad  dX = dY W          -> the same kernel on a second pack of the weight (transposed, taps flipped), pad_left = 0
+//       wgrad  dW = dY^T X        -> the same kernel on TRANSPOSED operand planes (contraction over the M = B*N tokens),
+//                                    split-K over grid-z into fixed slots, summed in a fixed order (deterministic, no atomics)
+//     so what this file adds around them is data movement and pointwise calculus:
+//   * tplanes_kernel: fp32 gradient (or operand planes) -> row planes + transposed planes (+ column sums = bias gradients) in
+//     one pass; the transposed copy optionally row-shifted per utterance (tap t of a causal conv reads x[n - (k-1-t) dil]);
+//   * the pointwise derivatives: FiLM + tanh*sigmoid gate (NS2:629-636), GEGLU (NS2:1004-1007), RMSNorm (NS2:727-746) with
+//     the per-utterance reductions for the conditioning gradients left in fixed slots;
+//   * flash-attention backward (ATT:77-155): P is recomputed from the forward's log-sum-exp; one kernel template, two roles
+//     (dQ: a workgroup owns 128 queries and walks the keys; dK/dV: owns 128 keys and walks the queries), the same swapped
+//     MFMA products and LDS tile shapes as attention.hip.
+// Arithmetic: bf16 hi/lo planes, hi*hi + hi*lo + lo*hi (precision 3, "exact"): gradients are fp32-class like the forward.
+#include "ns2_common.h"
+#include "ns2_kernels.h"
+
+namespace ns2 {
+
+// ================================================================================================ tplanes
+// One 64 x 64 tile per workgroup: load (fp32 -> split, or planes), optional row-plane store, transpose through LDS, store
+// transposed interleaved lines [hi32 | lo32] along the token axis.
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void tplanes_kernel(const TPlanesArgs a) {
+  __shared__ uint16_t th[64][66], tl[64][66];
+  __shared__ float cs[16][64];
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.x * 64;
+  // rows of this tile: per_batch -> utterance b, positions n0 .. n0 + 63; else global rows m0 .. m0 + 63
+  int b = 0;
+  long n0;
+  if (a.per_batch) {
+    const int ntn = (int)((a.ld_t + 63) / 64);
+    b = blockIdx.y / ntn;
+    n0 = (long)(blockIdx.y % ntn) * 64;
+  } else {
+    n0 = (long)blockIdx.y * 64;
+  }
+  // source row of tile row i (or -1): the output position takes input row (m - shift) of the same utterance
+  auto src_row = [&](int i) -> long {
+    long m, n;
+    if (a.per_batch) { n = n0 + i; if (n >= a.seq_len) return -1; m = (long)b * a.seq_len + n; }
+    else { m = n0 + i; if (m >= a.M) return -1; n = a.seq_len > 0 ? m % a.seq_len : m; }
+    const long ns = n - a.shift;
+    if (a.seq_len > 0 ? (ns < 0 || ns >= a.seq_len) : (m - a.shift < 0 || m - a.shift >= a.M)) return -1;
+    return m - a.shift;
+  };
+
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (IN_F32) {
+    const int ch = tid & 15;                    // 4 columns c0 + 4 ch ..
+    const bool vec = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.xf) & 15) == 0);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int i = (tid >> 4) + 16 * pass;
+      const long sr = src_row(i);
+      const int c = c0 + 4 * ch;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (sr >= 0 && c < a.C) {
+        if (vec && c + 3 < a.C) {
+          const float4 t = *reinterpret_cast<const float4*>(a.xf + sr * a.ldx + c);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (c + e < a.C) v[e] = a.xf[sr * a.ldx + c + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bf16_t h, l;
+        split_bf16(v[e], h, l);
+        th[i][4 * ch + e] = h; tl[i][4 * ch + e] = l;
+        csum[e] += v[e];
+      }
+      // row planes of the UNSHIFTED rows (shift must be 0 when they are requested; checked by the launcher)
+      if (a.row_hi) {
+        const long m = a.per_batch ? (long)b * a.seq_len + n0 + i : n0 + i;
+        const bool rok = a.per_batch ? (n0 + i < a.seq_len) : (m < a.M);
+        if (rok && c < a.ld_row) store_cols4(a.row_hi + m * 2L * a.ld_row, c, v[0], v[1], v[2], v[3], FMT_BF16, true);
+      }
+    }
+    if (a.colsum_partial) {                     // fixed-order column sums of this 64-row tile (bias gradients)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cs[tid >> 4][4 * ch + e] = csum[e];
+    }
+  } else {
+    const int ch = tid & 15;                    // 16-B chunk of the two 128-B lines covering columns c0 .. c0 + 63
+    const int line = ch >> 3, q = ch & 7, plane = q >> 2, kc = q & 3;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int i = (tid >> 4) + 16 * pass;
+      const long sr = src_row(i);
+      const int c = c0 + 32 * line + 8 * kc;    // first of 8 logical columns
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (sr >= 0 && c < a.C) {                  // C is a multiple of 8 for plane inputs (checked by the launcher)
+        const bf16_t* p = a.in_hi + sr * 2L * a.ld_in + pcol(a.in_col0 + c, true) + 32 * plane;
+        v = *reinterpret_cast<const uint4*>(p);
+      }
+      uint16_t* dst = (plane ? &tl[i][0] : &th[i][0]) + 32 * line + 8 * kc;
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dst[2 * e] = (uint16_t)(w[e] & 0xffffu); dst[2 * e + 1] = (uint16_t)(w[e] >> 16); }
+    }
+  }
+  __syncthreads();
+  if (IN_F32 && a.colsum_partial && tid < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += cs[r][tid];
+    if (c0 + tid < a.C) a.colsum_partial[(long)blockIdx.y * a.C + c0 + tid] = s;
+  }
+  if (!a.t_hi) return;
+  // ---- transposed store: output row = column c of the tile, 64 token positions = two interleaved lines
+  const int ch = tid & 15;
+  const int line = ch >> 3, q = ch & 7, plane = q >> 2, mc = q & 3;
+  const int rows_out = a.per_batch ? a.t_rows_per_batch : a.t_rows;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int cr = (tid >> 4) + 16 * pass;
+    const int c = c0 + cr;
+    const long col = n0 + 32 * line;            // first token position of this output line
+    if (c >= rows_out || col >= a.ld_t) continue;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i0 = 32 * line + 8 * mc + 2 * e;
+      const uint16_t lo16 = plane ? tl[i0][cr] : th[i0][cr], hi16 = plane ? tl[i0 + 1][cr] : th[i0 + 1][cr];
+      w[e] = (uint32_t)lo16 | ((uint32_t)hi16 << 16);
+    }
+    const long orow = a.per_batch ? (long)b * a.t_rows_per_batch + c : c;
+    bf16_t* dst = a.t_hi + orow * 2L * a.ld_t + 2L * col + 32 * plane + 8 * mc;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+hipError_t launch_tplanes(const TPlanesArgs& a, hipStream_t s) {
+  if (a.M <= 0 || a.C <= 0) return hipErrorInvalidValue;
+  const bool in_f32 = a.xf != nullptr;
+  if (in_f32 == (a.in_hi != nullptr)) return hipErrorInvalidValue;                 // exactly one input form
+  if (!in_f32 && (!planes_ok(a.in_hi, a.in_lo) || !a.in_lo || (a.C & 7) || (a.in_col0 & 31) || (a.ld_in & 31))) return hipErrorInvalidValue;
+  if (a.row_hi && (!in_f32 || a.shift != 0 || !a.row_lo || a.row_lo != a.row_hi + 32 || (a.ld_row & 31) || a.ld_row < a.C))
+    return hipErrorInvalidValue;
+  if (a.t_hi && (!a.t_lo || a.t_lo != a.t_hi + 32 || (a.ld_t & 31))) return hipErrorInvalidValue;
+  if (a.colsum_partial && (!in_f32 || a.per_batch || a.shift != 0)) return hipErrorInvalidValue;
+  if (a.per_batch && (a.seq_len <= 0 || a.M % a.seq_len || a.ld_t < a.seq_len || a.t_rows_per_batch < a.C)) return hipErrorInvalidValue;
+  if (!a.per_batch && a.t_hi && (a.ld_t < a.M || a.t_rows < a.C)) return hipErrorInvalidValue;
+  if (a.seq_len > 0 && a.M % a.seq_len) return hipErrorInvalidValue;
+  int ccover = a.C;
+  if (a.t_hi) ccover = max(ccover, a.per_batch ? a.t_rows_per_batch : a.t_rows);
+  if (a.row_hi) ccover = max(ccover, a.ld_row);
+  long ntile_m;
+  if (a.per_batch) ntile_m = (long)(a.M / a.seq_len) * ((a.ld_t + 63) / 64);
+  else ntile_m = tplanes_slices(a.M, a.t_hi ? a.ld_t : 0);
+  const dim3 grid((ccover + 63) / 64, (unsigned)ntile_m);
+  if (in_f32) hipLaunchKernelGGL(tplanes_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(tplanes_kernel<false>, grid, dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+long tplanes_slices(int M, long ld_t) { return (max((long)M, ld_t) + 63) / 64; }
+
+// ================================================================================================ fixed-order reductions
+// out[o * inner + j] (+)= sum_s partial[(o * S + s) * inner + j]
+__global__ void reduce_slices_kernel(const float* partial, long outer, int S, long inner, float* out, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= outer * inner) return;
+  const long o = i / inner, j = i - o * inner;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += partial[(o * S + s) * inner + j];
+  out[i] = accumulate ? out[i] + v : v;
+}
+hipError_t launch_reduce_slices(const float* partial, long outer, int S, long inner, float* out, int accumulate, hipStream_t s) {
+  if (outer <= 0 || S <= 0 || inner <= 0) return hipErrorInvalidValue;
+  const long n = outer * inner;
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partial, outer, S, inner, out, accumulate);
+  return hipGetLastError();
+}
+// weight gradient from the split-K slots of the wgrad GEMM: partial [S][R][ldp], column t * Kp + k  ->  out [R, K, T] (the
+// nn.Conv1d / nn.Linear weight layout), summed over s in a fixed order
+__global__ void wgrad_reduce_kernel(const float* partial, int S, int R, long ldp, int T, int Kp, int K, float* out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long n = (long)R * K * T;
+  if (i >= n) return;
+  const int t = (int)(i % T);
+  const long rk = i / T;
+  const int k = (int)(rk % K);
+  const long r = rk / K;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += partial[((long)s * R + r) * ldp + (long)t * Kp + k];
+  out[i] = v;
+}
+hipError_t launch_wgrad_reduce(const float* partial, int S, int R, long ldp, int T, int Kp, int K, float* out, hipStream_t s) {
+  if (S <= 0 || R <= 0 || T <= 0 || K <= 0 || Kp < K || ldp < (long)T * Kp) return hipErrorInvalidValue;
+  const long n = (long)R * K * T;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partial, S, R, ldp, T, Kp, K, out);
+  return hipGetLastError();
+}
+
+// ================================================================================================ FiLM + gate (NS2:629-636)
+// z = h * gamma_b + beta_b ; g = tanh(z) * sigmoid(z)
+NS2_DEVINL float gate_fn(float z) {
+  const float u = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(z));
+  const float t = (1.f - u) * (z < 0.f ? u : 1.f) * __builtin_amdgcn_rcpf(1.f + u * u);      // the forward's formula (gemm_epi.h)
+  return copysignf(t, z);
+}
+NS2_DEVINL float gate_grad(float z) {            // d/dz tanh(z) sigmoid(z) = (1 - tanh^2) sig + tanh sig (1 - sig)
+  const float sg = 1.0f / (1.0f + expf(-z));
+  const float th = tanhf(z);
+  return (1.f - th * th) * sg + th * sg * (1.f - sg);
+}
+__global__ __launch_bounds__(256) void film_gate_fwd_kernel(const float* h, long ldh, const float* film, int film_ld, int seq_len,
+                                                            long M, int d, float* out, long ldo) {
+  const int chunks = d >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * chunks) return;
+  const long row = idx / chunks;
+  const int c = (int)(idx - row * chunks) * 4;
+  const float* fb = film + (row / seq_len) * film_ld;
+  const float4 hv = *reinterpret_cast<const float4*>(h + row * ldh + c);
+  const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = gate_fn(hh[e] * fb[c + e] + fb[d + c + e]);
+  *reinterpret_cast<float4*>(out + row * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+}
+hipError_t launch_film_gate_fwd(const float* h, long ldh, const float* film, int film_ld, int seq_len, long M, int d, float* out,
+                                long ldo, hipStream_t s) {
+  if (M <= 0 || d <= 0 || (d & 3) || (ldh & 3) || (ldo & 3) || seq_len <= 0) return hipErrorInvalidValue;
+  const long n = M * (d >> 2);
+  hipLaunchKernelGGL(film_gate_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h, ldh, film, film_ld, seq_len, M, d, out, ldo);
+  return hipGetLastError();
+}
+// backward: dh = dg * g'(z) * gamma ; dgamma[b, c] = sum_n dg g'(z) h ; dbeta[b, c] = sum_n dg g'(z).  A workgroup owns 64 columns
+// x FG_ROWS positions of ONE utterance and leaves its two column sums in slot (b * nchunk + chunk) of `partial` ([.., 2 d]).
+constexpr int FG_ROWS = 256;
+__global__ __launch_bounds__(256) void film_gate_bwd_kernel(const float* dg, long lddg, const float* h, long ldh, const float* film,
+                                                            int film_ld, int seq_len, int d, float* dh, long lddh, float* partial) {
+  __shared__ float red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int nchunk = (seq_len + FG_ROWS - 1) / FG_ROWS;
+  const int b = blockIdx.y / nchunk, chunk = blockIdx.y % nchunk;
+  const float* fb = film + (long)b * film_ld;
+  float sg = 0.f, sb = 0.f;
+  if (c < d) {
+    const float gam = fb[c], bet = fb[d + c];
+    for (int i = ty; i < FG_ROWS; i += 4) {
+      const int n = chunk * FG_ROWS + i;
+      if (n >= seq_len) break;
+      const long row = (long)b * seq_len + n;
+      const float hv = h[row * ldh + c];
+      const float dz = dg[row * lddg + c] * gate_grad(hv * gam + bet);
+      dh[row * lddh + c] = dz * gam;
+      sg += dz * hv;
+      sb += dz;
+    }
+  }
+  red[0][ty][tx] = sg; red[1][ty][tx] = sb;
+  __syncthreads();
+  if (ty == 0 && c < d) {
+    float* slot = partial + (long)blockIdx.y * 2 * d;
+    slot[c] = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+    slot[d + c] = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+  }
+}
+int film_gate_slices(int seq_len) { return (seq_len + FG_ROWS - 1) / FG_ROWS; }
+hipError_t launch_film_gate_bwd(const float* dg, long lddg, const float* h, long ldh, const float* film, int film_ld, int B, int seq_len,
+                                int d, float* dh, long lddh, float* partial, hipStream_t s) {
+  if (B <= 0 || seq_len <= 0 || d <= 0 || !partial) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(film_gate_bwd_kernel, dim3((d + 63) / 64, B * film_gate_slices(seq_len)), dim3(256), 0, s, dg, lddg, h, ldh, film,
+                     film_ld, seq_len, d, dh, lddh, partial);
+  return hipGetLastError();
+}
+
+// ================================================================================================ GEGLU (NS2:1004-1007)
+// pre [M, ldp] = [x (f) | gate (f)] -> h = gelu(gate) * x as operand planes [M, ldo] (zero beyond f)
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* pre, long ldp, long M, int f, bf16_t* out_hi, bf16_t* out_lo, int ldo) {
+  const int chunks = ldo >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * chunks) return;
+  const long row = idx / chunks;
+  const int c = (int)(idx - row * chunks) * 4;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* p = pre + row * ldp;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (c + e < f) o[e] = gelu_erf(p[f + c + e]) * p[c + e];
+  store_cols4(out_hi + row * 2L * ldo, c, o[0], o[1], o[2], o[3], FMT_BF16, out_lo != nullptr);
+}
+hipError_t launch_geglu_fwd(const float* pre, long ldp, long M, int f, bf16_t* out_hi, bf16_t* out_lo, int ldo, hipStream_t s) {
+  if (M <= 0 || f <= 0 || ldp < 2L * f || (ldo & 31) || ldo < f || !out_lo || out_lo != out_hi + 32) return hipErrorInvalidValue;
+  const long n = M * (ldo >> 2);
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, ldp, M, f, out_hi, out_lo, ldo);
+  return hipGetLastError();
+}
+// dpre[:, c] = dh * gelu(gate) ; dpre[:, f + c] = dh * x * (Phi(gate) + gate * phi(gate))
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* dh, long lddh, const float* pre, long ldp, long M, int f, float* dpre,
+                                                        long lddp) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * f) return;
+  const long row = idx / f;
+  const int c = (int)(idx - row * f);
+  const float x = pre[row * ldp + c], g = pre[row * ldp + f + c], dy = dh[row * lddh + c];
+  const float Phi = 0.5f * erfc_fast(-0.70710678118654752440f * g);
+  const float phi = 0.39894228040143267794f * __expf(-0.5f * g * g);
+  dpre[row * lddp + c] = dy * g * Phi;
+  dpre[row * lddp + f + c] = dy * x * (Phi + g * phi);
+}
+hipError_t launch_geglu_bwd(const float* dh, long lddh, const float* pre, long ldp, long M, int f, float* dpre, long lddp, hipStream_t s) {
+  if (M <= 0 || f <= 0 || ldp < 2L * f || lddp < 2L * f || lddh < f) return hipErrorInvalidValue;
+  const long n = M * f;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dh, lddh, pre, ldp, M, f, dpre, lddp);
+  return hipGetLastError();
+}
+
+// ================================================================================================ RMSNorm backward (NS2:727-746)
+// y = nh * gp * gc + bc,  nh = x * r,  r = sqrt(d) / max(|x|, eps)   (gp = learned gamma or 1, gc / bc = adaptive or 1 / 0)
+//   dx = r * (dn - nh * (nh . dn) / d),  dn = dy * gc * gp
+//   dgc[b, c] = sum_n dy nh gp ; dbc[b, c] = sum_n dy ; dgp[c] = sum_m dy gc nh
+// One wave per row; a workgroup walks NB_ROWS rows of one utterance and leaves its column sums in its slot.
+constexpr int NB_ROWS = 64;
+template <int CH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const NormBwdArgs a) {
+  extern __shared__ float red[];                  // [3][4][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = (a.seq_len + NB_ROWS - 1) / NB_ROWS;
+  const int b = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+  const float* gc = a.cond ? a.cond + (long)b * a.cond_ld : nullptr;
+  float gm[CH][4], gg[CH][4];
+  float agc[CH][4], abc[CH][4], agp[CH][4];
+#pragma unroll
+  for (int j = 0; j < CH; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = lane * 4 + 256 * j + e;
+      gm[j][e] = (a.gamma && c < a.d) ? a.gamma[c] : 1.f;
+      gg[j][e] = (gc && c < a.d) ? gc[c] : 1.f;
+      agc[j][e] = abc[j][e] = agp[j][e] = 0.f;
+    }
+  const float scale = sqrtf((float)a.d), invd = 1.0f / (float)a.d;
+  for (int i = wave; i < NB_ROWS; i += 4) {
+    const int n = chunk * NB_ROWS + i;
+    if (n >= a.seq_len) break;
+    const long row = (long)b * a.seq_len + n;
+    float4 xv[CH], dv[CH];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int c = lane * 4 + 256 * j;
+      const bool ok = c < a.d;
+      xv[j] = ok ? *reinterpret_cast<const float4*>(a.x + row * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dv[j] = ok ? *reinterpret_cast<const float4*>(a.dy + row * a.lddy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ss += xv[j].x * xv[j].x + xv[j].y * xv[j].y + xv[j].z * xv[j].z + xv[j].w * xv[j].w;
+    }
+    ss = wave_sum(ss);
+    const float r = scale / fmaxf(sqrtf(ss), 1e-12f);
+    float dot = 0.f;
+    float nh[CH][4], dn[CH][4];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const float xx[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, dd[4] = {dv[j].x, dv[j].y, dv[j].z, dv[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        nh[j][e] = xx[e] * r;
+        dn[j][e] = dd[e] * gg[j][e] * gm[j][e];
+        dot += nh[j][e] * dn[j][e];
+        agc[j][e] += dd[e] * nh[j][e] * gm[j][e];
+        abc[j][e] += dd[e];
+        agp[j][e] += dd[e] * gg[j][e] * nh[j][e];
+      }
+    }
+    dot = wave_sum(dot) * invd;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int c = lane * 4 + 256 * j;
+      if (c >= a.d) continue;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = r * (dn[j][e] - nh[j][e] * dot);
+      if (a.dx_add) {
+        const float4 t = *reinterpret_cast<const float4*>(a.dx_add + row * a.lddx + c);
+        o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+      }
+      *reinterpret_cast<float4*>(a.dx + row * a.lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  // column sums of this workgroup's rows: waves -> LDS -> slot
+  float* r0 = red, *r1 = red + 4 * a.d, *r2 = red + 8 * a.d;
+#pragma unroll
+  for (int j = 0; j < CH; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = lane * 4 + 256 * j + e;
+      if (c < a.d) { r0[wave * a.d + c] = agc[j][e]; r1[wave * a.d + c] = abc[j][e]; r2[wave * a.d + c] = agp[j][e]; }
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.d; c += 256) {
+    if (a.cond_partial) {
+      float* slot = a.cond_partial + (long)blockIdx.x * 2 * a.d;
+      slot[c] = r0[c] + r0[a.d + c] + r0[2 * a.d + c] + r0[3 * a.d + c];
+      slot[a.d + c] = r1[c] + r1[a.d + c] + r1[2 * a.d + c] + r1[3 * a.d + c];
+    }
+    if (a.gamma_partial) a.gamma_partial[(long)blockIdx.x * a.d + c] = r2[c] + r2[a.d + c] + r2[2 * a.d + c] + r2[3 * a.d + c];
+  }
+}
+int rmsnorm_bwd_slices(int seq_len) { return (seq_len + NB_ROWS - 1) / NB_ROWS; }
+hipError_t launch_rmsnorm_bwd(const NormBwdArgs& a, hipStream_t s) {
+  if (a.B <= 0 || a.seq_len <= 0 || a.d <= 0 || (a.d & 3) || a.d > 2048 || (a.ldx & 3) || (a.lddy & 3) || (a.lddx & 3)) return hipErrorInvalidValue;
+  if (a.cond && !a.cond_partial) return hipErrorInvalidValue;
+  const dim3 grid(a.B * rmsnorm_bwd_slices(a.seq_len));
+  const size_t lds = (size_t)12 * a.d * sizeof(float);
+  if (a.d <= 256) hipLaunchKernelGGL(rmsnorm_bwd_kernel<1>, grid, dim3(256), lds, s, a);
+  else if (a.d <= 512) hipLaunchKernelGGL(rmsnorm_bwd_kernel<2>, grid, dim3(256), lds, s, a);
+  else if (a.d <= 1024) hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+// ================================================================================================ attention backward (ATT:77-155)
+// delta[b, h, q] = sum_d dO[q, 64 h + d] * O[q, 64 h + d]   (O from its operand planes, hi + lo)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* dO, long lddo, const bf16_t* o_hi, int ldo, int B, int H, int Nq,
+                                                         float* delta) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long tot = (long)B * Nq * H;
+  if (idx >= tot) return;
+  const int h = (int)(idx % H);
+  const long m = idx / H;
+  const float* g = dO + m * lddo + 64 * h;
+  float s = 0.f;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const bf16_t* line = o_hi + m * 2L * ldo + pcol(64 * h + 32 * blk, true);
+#pragma unroll 8
+    for (int e = 0; e < 32; ++e) s += g[32 * blk + e] * (bf2f(line[e]) + bf2f(line[32 + e]));
+  }
+  const long b = m / Nq, q = m - b * Nq;
+  delta[(b * H + h) * Nq + q] = s;
+}
+hipError_t launch_attn_delta(const float* dO, long lddo, const bf16_t* o_hi, const bf16_t* o_lo, int ldo, int B, int H, int Nq, float* delta,
+                             hipStream_t s) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || !o_lo || o_lo != o_hi + 32 || (ldo & 31) || ldo < 64 * H) return hipErrorInvalidValue;
+  const long n = (long)B * Nq * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dO, lddo, o_hi, ldo, B, H, Nq, delta);
+  return hipGetLastError();
+}
+
+// Flash backward.  ROLE 0 (dQ): the workgroup OWNS 128 queries (4 waves x 32), walks 64-key tiles:
+//     S^T = K Q^T ; dP^T = V dO^T ; P = exp2(S sl2 - lse) ; dS = P (dP - delta) ; dQ^T += K^T dS^T
+//   ROLE 1 (dK, dV): owns 128 keys, walks 64-query tiles:
+//     S = Q K^T ; dP = dO V^T ; P, dS as above with lse / delta per query (per register) ; dV^T += dO^T P ; dK^T += Q^T dS
+// In both roles the first two products put the OWN row in the lane (col = lane & 31 of the MFMA C tile) and 16 walked rows in
+// the registers -- the layout of attention.hip -- so P / dS feed the second pair of products as B operands straight from the
+// registers, against tiles of the TRANSPOSED planes (K^T, Q^T, dO^T: [64 d][64 walked rows]) read from LDS.
+constexpr int AB_ROWB = 144;
+constexpr int AB_PLANE = 64 * AB_ROWB;
+template <int ROLE>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnBwdArgs a) {
+  constexpr int NT = ROLE == 0 ? 3 : 4;            // LDS tiles: [Y, Yg, Y1T (, Y2T)], 2 planes each
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_lse = reinterpret_cast<float*>(smem + NT * 2 * AB_PLANE);
+  float* s_del = s_lse + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int Nown = ROLE == 0 ? a.Nq : a.Nk, Nwalk = ROLE == 0 ? a.Nk : a.Nq;
+  const int nown_t = (Nown + 127) / 128;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ot = bid % nown_t;
+  bid /= nown_t;
+  const int h = bid % a.H, b = bid / a.H;
+  const int orow = ot * 128 + wave * 32 + l31;
+  const bool own_ok = orow < Nown;
+
+  // own-side fragments (B operands): X = Q (role 0) / K (role 1); G = dO (role 0) / V (role 1)
+  const bf16_t* xb = ROLE == 0 ? a.q_hi : a.k_hi;
+  const int ldx = ROLE == 0 ? a.ldq : a.ldk, xcol = ROLE == 0 ? a.q_col0 : a.k_col0;
+  const bf16_t* gb = ROLE == 0 ? a.do_hi : a.v_hi;
+  const int ldg = ROLE == 0 ? a.lddo : a.ldv, gcol = ROLE == 0 ? 0 : a.v_col0;
+  bf16x8 xf[2][4], gf[2][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint4 vx = make_uint4(0u, 0u, 0u, 0u), vg = make_uint4(0u, 0u, 0u, 0u);
+      if (own_ok) {
+        vx = *reinterpret_cast<const uint4*>(xb + ((long)b * Nown + orow) * 2L * ldx + pcol(xcol + h * 64 + 16 * c + 8 * hi, true) + 32 * p);
+        vg = *reinterpret_cast<const uint4*>(gb + ((long)b * Nown + orow) * 2L * ldg + pcol(gcol + h * 64 + 16 * c + 8 * hi, true) + 32 * p);
+      }
+      xf[p][c] = *reinterpret_cast<bf16x8*>(&vx);
+      gf[p][c] = *reinterpret_cast<bf16x8*>(&vg);
+    }
+  float lse_own = INFINITY, del_own = 0.f;        // role 0: per-lane statistics of the own query
+  if (ROLE == 0 && own_ok) {
+    lse_own = a.lse[((long)b * a.H + h) * a.Nq + orow];
+    del_own = a.delta[((long)b * a.H + h) * a.Nq + orow];
+  }
+
+  // walked-side sources
+  const bf16_t* yb = ROLE == 0 ? a.k_hi : a.q_hi;      // row-major, scores
+  const int ldy = ROLE == 0 ? a.ldk : a.ldq, ycol = ROLE == 0 ? a.k_col0 : a.q_col0;
+  const bf16_t* ygb = ROLE == 0 ? a.v_hi : a.do_hi;    // row-major, dP
+  const int ldyg = ROLE == 0 ? a.ldv : a.lddo, ygcol = ROLE == 0 ? a.v_col0 : 0;
+  const bf16_t* t1b = ROLE == 0 ? a.kt_hi : a.qt_hi;   // transposed [B][H*64][ld]
+  const int ldt1 = ROLE == 0 ? a.kt_ld : a.qt_ld;
+  const bf16_t* t2b = a.dot_hi;                        // role 1 only
+  const int ldt2 = a.dot_ld;
+
+  const int pi_row = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+  const int y_frag_off = pi_row * AB_ROWB + hi * 16;
+  const int t_frag_off = l31 * AB_ROWB + hi * 16;
+
+  f32x16 acc1[2], acc2[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc1[dt][r] = 0.f; acc2[dt][r] = 0.f; }
+  const float sl2 = a.scale * 1.4426950408889634f;
+  const int ntiles = (Nwalk + 63) / 64;
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int r0 = t * 64;
+    __syncthreads();                                   // the previous tile's reads are done
+    // ---- stage the tile: 2 chunks of 16 B per plane per thread and matrix
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int cidx = tid + 256 * i;
+      const int srow = cidx >> 3, sch = cidx & 7;
+      const int off = srow * AB_ROWB + sch * 16;
+      {                                                // row-major tiles: row = walked row r0 + srow, chunk = d 8 sch ..
+        const int wr = r0 + srow;
+        const bool ok = wr < Nwalk;
+        const long base_y = ((long)b * Nwalk + wr) * 2L * ldy + pcol(ycol + h * 64 + sch * 8, true);
+        const long base_g = ((long)b * Nwalk + wr) * 2L * ldyg + pcol(ygcol + h * 64 + sch * 8, true);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+          *reinterpret_cast<uint4*>(smem + (0 * 2 + p) * AB_PLANE + off) = ok ? *reinterpret_cast<const uint4*>(yb + base_y + 32 * p) : z4;
+          *reinterpret_cast<uint4*>(smem + (1 * 2 + p) * AB_PLANE + off) = ok ? *reinterpret_cast<const uint4*>(ygb + base_g + 32 * p) : z4;
+        }
+      }
+      {                                                // transposed tiles: row = d srow, chunk = walked rows r0 + 8 sch ..
+        const int wc = r0 + sch * 8;
+        const bool ok = wc < Nwalk;                      // the transposed planes are zero beyond Nwalk up to their ld (tplanes)
+        const long base1 = ((long)(b * a.H + h) * 64 + srow) * 2L * ldt1 + pcol(wc, true);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+          *reinterpret_cast<uint4*>(smem + (2 * 2 + p) * AB_PLANE + off) = ok ? *reinterpret_cast<const uint4*>(t1b + base1 + 32 * p) : z4;
+          if constexpr (ROLE == 1) {
+            const long base2 = ((long)(b * a.H + h) * 64 + srow) * 2L * ldt2 + pcol(wc, true);
+            *reinterpret_cast<uint4*>(smem + (3 * 2 + p) * AB_PLANE + off) = ok ? *reinterpret_cast<const uint4*>(t2b + base2 + 32 * p) : z4;
+          }
+        }
+      }
+    }
+    if (ROLE == 1 && tid < 64) {
+      const int q = r0 + tid;
+      s_lse[tid] = q < a.Nq ? a.lse[((long)b * a.H + h) * a.Nq + q] : INFINITY;      // exp2(-inf) = 0: rows beyond Nq contribute nothing
+      s_del[tid] = q < a.Nq ? a.delta[((long)b * a.H + h) * a.Nq + q] : 0.f;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int js = 0; js < 2; ++js) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x8 yf[2], ygf[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          yf[p] = *reinterpret_cast<const bf16x8*>(smem + (0 * 2 + p) * AB_PLANE + y_frag_off + js * 32 * AB_ROWB + c * 32);
+          ygf[p] = *reinterpret_cast<const bf16x8*>(smem + (1 * 2 + p) * AB_PLANE + y_frag_off + js * 32 * AB_ROWB + c * 32);
+        }
+        st = mma16<false>(yf[1], xf[0][c], st);
+        st = mma16<false>(yf[0], xf[1][c], st);
+        st = mma16<false>(yf[0], xf[0][c], st);
+        dp = mma16<false>(ygf[1], gf[0][c], dp);
+        dp = mma16<false>(ygf[0], gf[1][c], dp);
+        dp = mma16<false>(ygf[0], gf[0][c], dp);
+      }
+      // ---- P and dS for (own row = lane, walked row = register): register r <-> walked row r0 + 32 js + 16 (r >> 3) + 8 hi + (r & 7)
+      float pv[16], dsv[16];
+#pragma unroll
+      for (int g1 = 0; g1 < 2; ++g1) {
+        float ls[8], dl[8];
+        if constexpr (ROLE == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ls[e] = lse_own; dl[e] = del_own; }
+        } else {
+          const int w0 = 32 * js + 16 * g1 + 8 * hi;
+          const float4 l0 = *reinterpret_cast<const float4*>(s_lse + w0), l1 = *reinterpret_cast<const float4*>(s_lse + w0 + 4);
+          const float4 d0 = *reinterpret_cast<const float4*>(s_del + w0), d1 = *reinterpret_cast<const float4*>(s_del + w0 + 4);
+          ls[0] = l0.x; ls[1] = l0.y; ls[2] = l0.z; ls[3] = l0.w; ls[4] = l1.x; ls[5] = l1.y; ls[6] = l1.z; ls[7] = l1.w;
+          dl[0] = d0.x; dl[1] = d0.y; dl[2] = d0.z; dl[3] = d0.w; dl[4] = d1.x; dl[5] = d1.y; dl[6] = d1.z; dl[7] = d1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = 8 * g1 + e;
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sl2, -ls[e]));
+          if (ROLE == 0 && r0 + 32 * js + 16 * g1 + 8 * hi + e >= Nwalk) p = 0.f;      // keys beyond Nk (role 1: lse = +inf did it)
+          pv[r] = p;
+          dsv[r] = p * (dp[r] - dl[e]);
+        }
+      }
+      // ---- accumulate: acc1 += Y1T dS^T (dQ^T or dK^T), acc2 += Y2T P^T (dV^T, role 1)
+#pragma unroll
+      for (int g1 = 0; g1 < 2; ++g1) {
+        bf16x8 dsf[2], pf[2];
+        {
+          uint32_t ph[4], pl[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2(dsv[8 * g1 + 2 * e], dsv[8 * g1 + 2 * e + 1], ph[e], pl[e]);
+          const uint4 uh = make_uint4(ph[0], ph[1], ph[2], ph[3]), ul = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+          dsf[0] = *reinterpret_cast<const bf16x8*>(&uh);
+          dsf[1] = *reinterpret_cast<const bf16x8*>(&ul);
+        }
+        if constexpr (ROLE == 1) {
+          uint32_t ph[4], pl[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2(pv[8 * g1 + 2 * e], pv[8 * g1 + 2 * e + 1], ph[e], pl[e]);
+          const uint4 uh = make_uint4(ph[0], ph[1], ph[2], ph[3]), ul = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+          pf[0] = *reinterpret_cast<const bf16x8*>(&uh);
+          pf[1] = *reinterpret_cast<const bf16x8*>(&ul);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          bf16x8 t1f[2];
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            t1f[p] = *reinterpret_cast<const bf16x8*>(smem + (2 * 2 + p) * AB_PLANE + t_frag_off + dt * 32 * AB_ROWB + js * 64 + g1 * 32);
+          acc1[dt] = mma16<false>(t1f[1], dsf[0], acc1[dt]);
+          acc1[dt] = mma16<false>(t1f[0], dsf[1], acc1[dt]);
+          acc1[dt] = mma16<false>(t1f[0], dsf[0], acc1[dt]);
+          if constexpr (ROLE == 1) {
+            bf16x8 t2f[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              t2f[p] = *reinterpret_cast<const bf16x8*>(smem + (3 * 2 + p) * AB_PLANE + t_frag_off + dt * 32 * AB_ROWB + js * 64 + g1 * 32);
+            acc2[dt] = mma16<false>(t2f[1], pf[0], acc2[dt]);
+            acc2[dt] = mma16<false>(t2f[0], pf[1], acc2[dt]);
+            acc2[dt] = mma16<false>(t2f[0], pf[0], acc2[dt]);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- store: lane holds d = 32 dt + 8 gq + 4 hi + e of its own row
+  if (!own_ok) return;
+  float* o1 = ROLE == 0 ? a.dq + ((long)b * a.Nq + orow) * a.lddq + a.dq_col0 + h * 64
+                        : a.dk + ((long)b * a.Nk + orow) * a.lddk + a.dk_col0 + h * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int dcol = 32 * dt + 8 * gq + 4 * hi;
+      *reinterpret_cast<float4*>(o1 + dcol) = make_float4(acc1[dt][4 * gq] * a.scale, acc1[dt][4 * gq + 1] * a.scale,
+                                                          acc1[dt][4 * gq + 2] * a.scale, acc1[dt][4 * gq + 3] * a.scale);
+      if constexpr (ROLE == 1) {
+        float* o2 = a.dv + ((long)b * a.Nk + orow) * a.lddv + a.dv_col0 + h * 64;
+        *reinterpret_cast<float4*>(o2 + dcol) = make_float4(acc2[dt][4 * gq], acc2[dt][4 * gq + 1], acc2[dt][4 * gq + 2], acc2[dt][4 * gq + 3]);
+      }
+    }
+}
+
+template <int ROLE>
+static hipError_t launch_attn_bwd_role(const AttnBwdArgs& a, hipStream_t s) {
+  const size_t lds = (ROLE == 0 ? 3 : 4) * 2 * AB_PLANE + 128 * sizeof(float);
+  static DynLdsAttr attr;
+  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attn_bwd_kernel<ROLE>), (int)lds);
+  if (e != hipSuccess) return e;
+  const int nown = ROLE == 0 ? a.Nq : a.Nk;
+  dim3 grid(((nown + 127) / 128) * a.H * a.B);
+  hipLaunchKernelGGL((attn_bwd_kernel<ROLE>), grid, dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
+  if (a.B <= 0 || a.H <= 0 || a.Nq <= 0 || a.Nk <= 0 || !a.lse || !a.delta) return hipErrorInvalidValue;
+  auto il = [](const bf16_t* hi_, const bf16_t* lo_) { return hi_ && lo_ == hi_ + 32; };
+  if (!il(a.q_hi, a.q_lo) || !il(a.k_hi, a.k_lo) || !il(a.v_hi, a.v_lo) || !il(a.do_hi, a.do_lo)) return hipErrorInvalidValue;
+  if (((a.ldq | a.ldk | a.ldv | a.lddo) & 31) || ((a.q_col0 | a.k_col0 | a.v_col0) & 31)) return hipErrorInvalidValue;
+  const bool want_q = a.dq != nullptr, want_kv = a.dk != nullptr || a.dv != nullptr;
+  if (!want_q && !want_kv) return hipErrorInvalidValue;
+  if (want_q) {
+    if (!il(a.kt_hi, a.kt_lo) || (a.kt_ld & 31) || a.kt_ld < a.Nk || (a.lddq & 3) || (a.dq_col0 & 3)) return hipErrorInvalidValue;
+    hipError_t e = launch_attn_bwd_role<0>(a, s);
+    if (e != hipSuccess) return e;
+  }
+  if (want_kv) {
+    if (!a.dk || !a.dv || !il(a.qt_hi, a.qt_lo) || !il(a.dot_hi, a.dot_lo) || ((a.qt_ld | a.dot_ld) & 31) || a.qt_ld < a.Nq || a.dot_ld < a.Nq ||
+        ((a.lddk | a.lddv | a.dk_col0 | a.dv_col0) & 3))
+      return hipErrorInvalidValue;
+    hipError_t e = launch_attn_bwd_role<1>(a, s);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+}  // namespace ns2

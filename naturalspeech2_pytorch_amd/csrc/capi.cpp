@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 109; }   // 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 110; }   // 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 2, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
   force_gemm_kernel(kernel);
@@ -58,6 +58,21 @@ extern "C" int ns2_weight_pack(const float* w, int rows, int cols, int taps, int
   h->taps = taps; h->geglu = geglu; h->has_extra = extra1x1 != nullptr; h->cols_p = (cols + 31) / 32 * 32;
   int r = pack_weight_public(w, rows, cols, taps, geglu, extra1x1, precision, &h->w, &h->owned, (hipStream_t)stream);
   if (r != NS2_OK) { ns2_weight_free(h); return r; }
+  {   // keep the row map on the device: ns2_weight_update (training: the weights change every step) re-packs without allocating
+    h->cols = cols;
+    const std::vector<int> m = geglu ? geglu_row_map(rows / 2, h->w.rows_p) : [&] {
+      std::vector<int> id(h->w.rows_p, -1);
+      for (int i = 0; i < rows && i < h->w.rows_p; ++i) id[i] = i;
+      return id;
+    }();
+    if (hipMalloc((void**)&h->d_map, m.size() * sizeof(int)) != hipSuccess ||
+        hipMemcpy(h->d_map, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("ns2_weight_pack: could not keep the row map");
+      ns2_weight_free(h);
+      return NS2_ERR_HIP;
+    }
+    h->owned.push_back(h->d_map);
+  }
   *out = h;
   return NS2_OK;
 }
@@ -155,6 +170,7 @@ extern "C" int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq
                              const uint8_t* key_mask, int precision, void* stream) {
   ARGCHK(q_hi && k_hi && vt_hi && o_hi && prec_ok(precision), "ns2_attention: bad arguments");
   AttnArgs a;
+  a.lse = nullptr;
   a.q_hi = q_hi; a.q_lo = q_lo; a.ldq = ldq; a.q_col0 = q_col0;
   a.k_hi = k_hi; a.k_lo = k_lo; a.ldk = ldk; a.k_col0 = k_col0;
   a.vt_hi = vt_hi; a.vt_lo = vt_lo; a.vt_ld = vt_ld;

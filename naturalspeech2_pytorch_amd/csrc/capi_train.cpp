@@ -1,0 +1,184 @@
+// extern "C" surface of the backward (training) pass: declared in include/ns2hip.h under "training".  Kernels: backward.hip; the
+// contractions are calls of the forward GEMM family (gemm.hip / gemm2.hip) on re-packed weights / transposed operand planes.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "ns2_host.h"
+
+using namespace ns2;
+
+#define HIPRET(expr)                                                                 \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return NS2_ERR_HIP;                                                            \
+    }                                                                                \
+  } while (0)
+#define ARGCHK(cond, msg)            \
+  do {                               \
+    if (!(cond)) {                   \
+      set_error("%s", msg);          \
+      return NS2_ERR_ARG;            \
+    }                                \
+  } while (0)
+
+extern "C" int ns2_weight_update(ns2_weight* w, const float* w_src, const float* extra1x1, void* stream) {
+  ARGCHK(w && w_src && w->d_map, "ns2_weight_update: null weight / source");
+  ARGCHK((extra1x1 != nullptr) == (w->has_extra != 0), "ns2_weight_update: extra1x1 must be given iff the weight was packed with one");
+  hipStream_t s = (hipStream_t)stream;
+  // same kernel and row map as ns2_weight_pack, in place: stream-ordered, no allocation, no synchronisation
+  HIPRET(launch_pack_weight(w_src, w->cols, w->taps, w->cols_p, w->d_map, w->w.rows_p, w->w.hi, w->w.lo, w->w.ldk, 0, s, w->w.fmt));
+  if (extra1x1)
+    HIPRET(launch_pack_weight(extra1x1, w->cols, 1, w->cols_p, w->d_map, w->w.rows_p, w->w.hi, w->w.lo, w->w.ldk, w->taps * w->cols_p, s,
+                              w->w.fmt));
+  return NS2_OK;
+}
+
+extern "C" int64_t ns2_grad_prep_slices(int M, int64_t ld_t) { return M > 0 ? (int64_t)tplanes_slices(M, (long)ld_t) : 0; }
+
+extern "C" int ns2_grad_prep(const float* x, int64_t ldx, int M, int C, int seq_len, int shift, uint16_t* row_hi, uint16_t* row_lo,
+                             int ld_row, uint16_t* t_hi, uint16_t* t_lo, int64_t ld_t, int t_rows, int per_batch, float* colsum_partial,
+                             void* stream) {
+  ARGCHK(x && (row_hi || t_hi || colsum_partial), "ns2_grad_prep: nothing to do");
+  TPlanesArgs a;
+  memset(&a, 0, sizeof a);
+  a.xf = x; a.ldx = (long)ldx; a.M = M; a.C = C; a.seq_len = seq_len; a.shift = shift;
+  a.row_hi = row_hi; a.row_lo = row_lo; a.ld_row = ld_row;
+  a.t_hi = t_hi; a.t_lo = t_lo; a.ld_t = (long)ld_t; a.per_batch = per_batch; a.t_rows_per_batch = t_rows; a.t_rows = t_rows;
+  a.colsum_partial = colsum_partial;
+  HIPRET(launch_tplanes(a, (hipStream_t)stream));
+  return NS2_OK;
+}
+
+extern "C" int ns2_planes_transpose(const uint16_t* in_hi, const uint16_t* in_lo, int ld_in, int in_col0, int M, int C, int seq_len,
+                                    int shift, uint16_t* t_hi, uint16_t* t_lo, int64_t ld_t, int t_rows, int per_batch, void* stream) {
+  ARGCHK(in_hi && in_lo && t_hi && t_lo, "ns2_planes_transpose: null pointer (operands are bf16 hi/lo planes)");
+  TPlanesArgs a;
+  memset(&a, 0, sizeof a);
+  a.in_hi = in_hi; a.in_lo = in_lo; a.ld_in = ld_in; a.in_col0 = in_col0; a.M = M; a.C = C; a.seq_len = seq_len; a.shift = shift;
+  a.t_hi = t_hi; a.t_lo = t_lo; a.ld_t = (long)ld_t; a.per_batch = per_batch; a.t_rows_per_batch = t_rows; a.t_rows = t_rows;
+  HIPRET(launch_tplanes(a, (hipStream_t)stream));
+  return NS2_OK;
+}
+
+extern "C" int ns2_reduce_slices(const float* partial, int64_t outer, int S, int64_t inner, float* out, int accumulate, void* stream) {
+  ARGCHK(partial && out, "ns2_reduce_slices: null pointer");
+  HIPRET(launch_reduce_slices(partial, (long)outer, S, (long)inner, out, accumulate, (hipStream_t)stream));
+  return NS2_OK;
+}
+
+// ---- weight gradient: dW[r, k, t] = sum_m dY[m, r] * X_t[m, k]  as ONE GEMM over transposed planes, split-K into fixed slots
+static int wgrad_split(int R, int ncols, int64_t ld_t) {
+  const int nkt = (int)(ld_t / 32);
+  const long tiles = ncols > 128 ? (long)((R + 255) / 256) * ((ncols + 255) / 256) : (long)((R + 127) / 128);
+  long want = (640 + tiles - 1) / tiles;                 // >= ~2.5 workgroups per CU in flight
+  want = std::min<long>(want, std::max(1, nkt / 8));     // ... of at least 8 K tiles each
+  int S = 1;
+  for (int d = 1; d <= nkt && d <= want; ++d)
+    if (nkt % d == 0) S = d;                             // slices must cover whole K tiles evenly
+  return S;
+}
+extern "C" int64_t ns2_wgrad_workspace_bytes(int R, int ncols, int64_t ld_t) {
+  if (R <= 0 || ncols <= 0 || ld_t <= 0 || (ld_t & 31)) return 0;
+  return (int64_t)wgrad_split(R, ncols, ld_t) * R * ncols * (int64_t)sizeof(float);
+}
+extern "C" int ns2_wgrad(const uint16_t* dyt_hi, const uint16_t* dyt_lo, const uint16_t* xt_hi, const uint16_t* xt_lo, int64_t ld_t, int R,
+                         int T, int Kp, int K, float* dw, void* workspace, int64_t workspace_bytes, void* stream) {
+  ARGCHK(dyt_hi && dyt_lo == dyt_hi + 32 && xt_hi && xt_lo == xt_hi + 32 && dw && workspace, "ns2_wgrad: null pointer / operands must be bf16 hi/lo planes");
+  ARGCHK(R > 0 && T > 0 && K > 0 && Kp >= K && (Kp & 3) == 0 && ld_t > 0 && (ld_t & 31) == 0 && ld_t < (1LL << 30), "ns2_wgrad: bad shapes");
+  const int ncols = T * Kp;
+  const int S = wgrad_split(R, ncols, ld_t);
+  ARGCHK(workspace_bytes >= (int64_t)S * R * ncols * (int64_t)sizeof(float), "ns2_wgrad: workspace too small (ns2_wgrad_workspace_bytes)");
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  const int nkt = (int)(ld_t / 32) / S;
+  g.a_hi = dyt_hi; g.a_lo = dyt_lo; g.lda = (int)ld_t;
+  g.w_hi = xt_hi; g.w_lo = xt_lo; g.ldw = (int)ld_t;        // rows of X^T beyond T * Kp up to the next multiple of 256 must exist (zeros)
+  g.M = R; g.N = ncols; g.nkt = nkt; g.kt_per_tap = nkt; g.conv_taps = 0; g.dil = 1; g.mid_kt = -1;
+  g.nz = S; g.a_zs = (long)nkt * 32; g.w_zs = (long)nkt * 32; g.out_f_zs = (long)R * ncols;
+  g.pad_left = -1; g.out_fmt = -1; g.vt_fmt = -1;
+  g.epi = EPI_F32; g.out_f = (float*)workspace; g.ldo_f = ncols;
+  HIPRET(launch_gemm(g, 3, (hipStream_t)stream));
+  HIPRET(launch_wgrad_reduce((const float*)workspace, S, R, ncols, T, Kp, K, dw, (hipStream_t)stream));
+  return NS2_OK;
+}
+
+extern "C" int ns2_film_gate_fwd(const float* h, int64_t ldh, const float* film, int film_ld, int seq_len, int64_t M, int d, float* out,
+                                 int64_t ldo, void* stream) {
+  ARGCHK(h && film && out, "ns2_film_gate_fwd: null pointer");
+  HIPRET(launch_film_gate_fwd(h, (long)ldh, film, film_ld, seq_len, (long)M, d, out, (long)ldo, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_film_gate_slices(int seq_len) { return seq_len > 0 ? film_gate_slices(seq_len) : 0; }
+extern "C" int ns2_film_gate_bwd(const float* dg, int64_t lddg, const float* h, int64_t ldh, const float* film, int film_ld, int B,
+                                 int seq_len, int d, float* dh, int64_t lddh, float* partial, void* stream) {
+  ARGCHK(dg && h && film && dh && partial, "ns2_film_gate_bwd: null pointer");
+  HIPRET(launch_film_gate_bwd(dg, (long)lddg, h, (long)ldh, film, film_ld, B, seq_len, d, dh, (long)lddh, partial, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_geglu_fwd(const float* pre, int64_t ldp, int64_t M, int f, uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream) {
+  ARGCHK(pre && out_hi && out_lo, "ns2_geglu_fwd: null pointer");
+  HIPRET(launch_geglu_fwd(pre, (long)ldp, (long)M, f, out_hi, out_lo, ldo, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_geglu_bwd(const float* dh, int64_t lddh, const float* pre, int64_t ldp, int64_t M, int f, float* dpre, int64_t lddp,
+                             void* stream) {
+  ARGCHK(dh && pre && dpre, "ns2_geglu_bwd: null pointer");
+  HIPRET(launch_geglu_bwd(dh, (long)lddh, pre, (long)ldp, (long)M, f, dpre, (long)lddp, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_rmsnorm_bwd_slices(int seq_len) { return seq_len > 0 ? rmsnorm_bwd_slices(seq_len) : 0; }
+extern "C" int ns2_rmsnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma, const float* cond,
+                               int cond_ld, int B, int seq_len, int d, const float* dx_add, float* dx, int64_t lddx, float* cond_partial,
+                               float* gamma_partial, void* stream) {
+  ARGCHK(x && dy && dx, "ns2_rmsnorm_bwd: null pointer");
+  NormBwdArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.ldx = (long)ldx; a.dy = dy; a.lddy = (long)lddy; a.gamma = gamma; a.cond = cond; a.cond_ld = cond_ld;
+  a.dx_add = dx_add; a.dx = dx; a.lddx = (long)lddx; a.cond_partial = cond_partial; a.gamma_partial = gamma_partial;
+  a.B = B; a.seq_len = seq_len; a.d = d;
+  HIPRET(launch_rmsnorm_bwd(a, (hipStream_t)stream));
+  return NS2_OK;
+}
+
+extern "C" int ns2_attention_lse(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi, const uint16_t* k_lo,
+                                 int ldk, int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld, uint16_t* o_hi, uint16_t* o_lo,
+                                 int ldo, int B, int H, int Nq, int Nk, float scale, float* lse, int precision, void* stream) {
+  ARGCHK(q_hi && k_hi && vt_hi && o_hi && lse && precision >= 1 && precision <= 4, "ns2_attention_lse: bad arguments");
+  AttnArgs a;
+  a.q_hi = q_hi; a.q_lo = q_lo; a.ldq = ldq; a.q_col0 = q_col0;
+  a.k_hi = k_hi; a.k_lo = k_lo; a.ldk = ldk; a.k_col0 = k_col0;
+  a.vt_hi = vt_hi; a.vt_lo = vt_lo; a.vt_ld = vt_ld;
+  a.o_hi = o_hi; a.o_lo = o_lo; a.ldo = ldo; a.o_fmt = -1;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale; a.kmask = nullptr; a.lse = lse;
+  HIPRET(launch_attention(a, precision, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_attention_delta(const float* d_out, int64_t ld_dout, const uint16_t* o_hi, const uint16_t* o_lo, int ldo, int B, int H,
+                                   int Nq, float* delta, void* stream) {
+  ARGCHK(d_out && o_hi && delta, "ns2_attention_delta: null pointer");
+  HIPRET(launch_attn_delta(d_out, (long)ld_dout, o_hi, o_lo, ldo, B, H, Nq, delta, (hipStream_t)stream));
+  return NS2_OK;
+}
+extern "C" int ns2_attention_bwd(const ns2_attn_bwd_args* p, void* stream) {
+  ARGCHK(p != nullptr, "ns2_attention_bwd: null argument block");
+  AttnBwdArgs a;
+  memset(&a, 0, sizeof a);
+  a.q_hi = p->q_hi; a.q_lo = p->q_lo; a.ldq = p->ldq; a.q_col0 = p->q_col0;
+  a.k_hi = p->k_hi; a.k_lo = p->k_lo; a.ldk = p->ldk; a.k_col0 = p->k_col0;
+  a.v_hi = p->v_hi; a.v_lo = p->v_lo; a.ldv = p->ldv; a.v_col0 = p->v_col0;
+  a.do_hi = p->do_hi; a.do_lo = p->do_lo; a.lddo = p->lddo;
+  a.kt_hi = p->kt_hi; a.kt_lo = p->kt_lo; a.kt_ld = p->kt_ld;
+  a.qt_hi = p->qt_hi; a.qt_lo = p->qt_lo; a.qt_ld = p->qt_ld;
+  a.dot_hi = p->dot_hi; a.dot_lo = p->dot_lo; a.dot_ld = p->dot_ld;
+  a.lse = p->lse; a.delta = p->delta;
+  a.dq = p->dq; a.lddq = p->lddq; a.dq_col0 = p->dq_col0;
+  a.dk = p->dk; a.lddk = p->lddk; a.dk_col0 = p->dk_col0;
+  a.dv = p->dv; a.lddv = p->lddv; a.dv_col0 = p->dv_col0;
+  a.B = p->B; a.H = p->H; a.Nq = p->Nq; a.Nk = p->Nk; a.scale = p->scale;
+  HIPRET(launch_attention_bwd(a, (hipStream_t)stream));
+  return NS2_OK;
+}

@@ -251,8 +251,11 @@ __global__ void skinny_reduce_kernel(const float* partial, int nsplit, const flo
 }
 
 // K split: enough blocks to keep ~2 per CU streaming, in whole SK_KC chunks
-static void skinny_plan(int B, int K, int J, int* nsplit, int* kps) {
-  const long blocks = (long)((J + SK_COLS - 1) / SK_COLS) * ((B + 31) / 32);
+// plan_B (> 0): take the K split a batch of plan_B rows would get.  The split fixes the order of the partial sums, so a table of
+// conditioning rows built ahead of a sampling run in 32-row chunks is bit-identical to what each step's own launch (batch = plan_B
+// identical rows) would have produced (ns2_model_time_table).
+static void skinny_plan(int B, int K, int J, int* nsplit, int* kps, int plan_B = 0) {
+  const long blocks = (long)((J + SK_COLS - 1) / SK_COLS) * (((plan_B > 0 ? plan_B : B) + 31) / 32);
   int want = (int)((512 + blocks - 1) / blocks);
   const int max_split = (K + SK_KC - 1) / SK_KC;
   if (want > max_split) want = max_split;
@@ -260,18 +263,19 @@ static void skinny_plan(int B, int K, int J, int* nsplit, int* kps) {
   *kps = ((K + want - 1) / want + SK_KC - 1) / SK_KC * SK_KC;
   *nsplit = (K + *kps - 1) / *kps;
 }
-size_t skinny_linear_workspace_bytes(int B, int K, int J) {
+size_t skinny_linear_workspace_bytes(int B, int K, int J, int plan_B) {
   if (B <= 0 || K <= 0 || J <= 0) return 0;
   int nsplit, kps;
-  skinny_plan(B, K, J, &nsplit, &kps);
+  skinny_plan(B, K, J, &nsplit, &kps, plan_B);
   return nsplit > 1 ? (size_t)nsplit * B * J * sizeof(float) : 0;
 }
 
 hipError_t launch_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out,
-                                int B, int K, int J, int act, float* ws, size_t ws_bytes, hipStream_t s) {
+                                int B, int K, int J, int act, float* ws, size_t ws_bytes, hipStream_t s, int plan_B) {
   if (B <= 0 || K <= 0 || J <= 0) return hipErrorInvalidValue;
   int nsplit, kps;
-  skinny_plan(B, K, J, &nsplit, &kps);
+  skinny_plan(B, K, J, &nsplit, &kps, plan_B);
+  if (plan_B > 0 && nsplit > 1 && (!ws || ws_bytes < (size_t)nsplit * B * J * sizeof(float))) return hipErrorInvalidValue;   // a planned split must not degrade silently
   if (nsplit > 1 && (!ws || ws_bytes < (size_t)nsplit * B * J * sizeof(float))) { nsplit = 1; kps = (K + SK_KC - 1) / SK_KC * SK_KC; }
   float* partial = nsplit > 1 ? ws : nullptr;               // no scratch -> one pass over the whole K (slower, still correct)
   hipLaunchKernelGGL(skinny_linear_kernel, dim3((J + SK_COLS - 1) / SK_COLS, (B + 31) / 32, nsplit), dim3(256), 0, s, in, ld_in,
@@ -302,12 +306,12 @@ __global__ void time_feat_kernel(const float* times, const float* freqs, float* 
 }
 
 hipError_t launch_time_embed(const float* times, const float* freqs, const float* wt, const float* bias, float* feat_ws,
-                             float* out, int ld_out, int B, int dim, int dt, float* ws, size_t ws_bytes, hipStream_t s) {
+                             float* out, int ld_out, int B, int dim, int dt, float* ws, size_t ws_bytes, hipStream_t s, int plan_B) {
   const int K = dim + 1;
   hipLaunchKernelGGL(time_feat_kernel, dim3((B * K + 255) / 256), dim3(256), 0, s, times, freqs, feat_ws, B, dim);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return launch_skinny_linear(feat_ws, K, wt, bias, out, ld_out, B, K, dt, /*act=*/1, ws, ws_bytes, s);
+  return launch_skinny_linear(feat_ws, K, wt, bias, out, ld_out, B, K, dt, /*act=*/1, ws, ws_bytes, s, plan_B);
 }
 
 // ---------------------------------------------------------------- small data movers
@@ -340,6 +344,19 @@ __global__ void mean_rows_kernel(const float* in, int n, int d, float* out) {
 }
 hipError_t launch_mean_rows(const float* in, int B, int n, int d, float* out, hipStream_t s) {
   hipLaunchKernelGGL(mean_rows_kernel, dim3((d + 255) / 256, B), dim3(256), 0, s, in, n, d, out);
+  return hipGetLastError();
+}
+
+// out[b, j] = row[j] + add[b, j]: the step's conditioning of a CONDITIONED model from the hoisted time table row and the
+// per-utterance prompt part (ns2_model_forward_row)
+__global__ void add_row_kernel(const float* row, const float* add, float* out, long J, long n_total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_total) return;
+  out[i] = row[i % J] + add[i];
+}
+hipError_t launch_add_row(const float* row, const float* add, float* out, int B, long J, hipStream_t s) {
+  const long n = (long)B * J;
+  hipLaunchKernelGGL(add_row_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, row, add, out, J, n);
   return hipGetLastError();
 }
 

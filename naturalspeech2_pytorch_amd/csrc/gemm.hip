@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
           const float4 rr = *reinterpret_cast<const float4*>(g.resid + row * g.ldr + col_base + ch * 4);
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
-        *reinterpret_cast<float4*>(g.out_f + row * g.ldo_f + col_base + ch * 4) = v;
+        *reinterpret_cast<float4*>(g.out_f + z * g.out_f_zs + row * g.ldo_f + col_base + ch * 4) = v;
       }
       return;
     }

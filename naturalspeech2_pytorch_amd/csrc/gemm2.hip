@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const bool a_wave = wave < 4;
   const int lrow = lane / CPR, pchunk = lane % CPR;
   const bf16_t* src[8];        // per-instruction source ROW pointer at K offset 0 (A: unshifted row), without the chunk offset
-  int nseq[8];                 // A only: position inside the utterance (for the causal zero fill); -1 = row >= M
+  int nseq[8];                 // A only: position inside the utterance (for the causal zero fill); -2^30 = row >= M (no tap shift brings it back into range)
   int ldst[8];                 // LDS byte offset inside a stage (wave-uniform)
   // logical 16-B chunk this lane fetches: pchunk ^ swizzle(row); row = 8 rg + lrow and rg = 8 (wave & 3) + i, so the
   // swizzle (row >> 1) & 7 = 4 (i & 1) + (lrow >> 1) takes two values per lane, for even and odd i
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     if (a_wave) {
       const long m = (long)tm * G2_BM + row;
       src[i] = g.a_hi + pcol((int)(z * g.a_zs), ail) + m * a_rs;
-      nseq[i] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -1;
+      nseq[i] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -0x40000000;
     } else {
       src[i] = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN + row) * w_rs;
       nseq[i] = 0;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       const long off = pcol(it * BK, ail) - (long)shift * a_rs;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const bool ok = ((unsigned)(nseq[i] - shift) < slim) && !(half && chi[i & 1]);   // nseq = -1 marks rows >= M
+        const bool ok = ((unsigned)(nseq[i] - shift) < slim) && !(half && chi[i & 1]);   // nseq = -2^30 marks rows >= M
         const bf16_t* p = ok ? (src[i] + off + coff[i & 1]) : zero_page;
         glds16(p, sbase + ldst[i]);
       }
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   // its last read (the reads have retired at the lgkmcnt before that phase's MFMAs, again two barriers earlier).
   // Accumulation order per accumulator is unchanged: results are bit-identical to run_k.
   const bf16_t* psrc[4][2];      // [A0, A1, B0, B1][piece]: source row pointer at K offset 0
-  int pnseq[2][2];               // A pieces: position inside the utterance (-1 = row >= M)
+  int pnseq[2][2];               // A pieces: position inside the utterance (-2^30 = row >= M)
   int pldst[4][2];               // LDS byte offset inside a stage (wave-uniform)
 #pragma unroll
   for (int h = 0; h < 4; ++h)
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       if (h < 2) {
         const long m = (long)tm * G2_BM + row;
         psrc[h][e] = g.a_hi + pcol((int)(z * g.a_zs), ail) + m * a_rs;
-        pnseq[h][e] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -1;
+        pnseq[h][e] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -0x40000000;
       } else {
         psrc[h][e] = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN + row) * w_rs;
       }
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       if constexpr (EPI == EPI_F32) {
         if (col_base + 64 <= g.N && g.act == 0 && (g.ldo_f & 3) == 0 && (reinterpret_cast<uintptr_t>(g.out_f) & 15) == 0 &&
             (!g.resid || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.resid) & 15) == 0))) {
-          epi_f32_fast(acc, g, row_base, col_base, lane, wbuf);
+          epi_f32_fast(acc, g, z, row_base, col_base, lane, wbuf);
           done = true;
         }
       } else if constexpr (EPI == EPI_GEGLU) {

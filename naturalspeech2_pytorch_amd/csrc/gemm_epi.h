@@ -73,7 +73,7 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
           float v = acc[mi][ni][r] + bc;
           if (g.act) v = apply_act(v, g.act);
           if (g.resid) v += g.resid[(long)row * g.ldr + col];
-          g.out_f[(long)row * g.ldo_f + col] = v;
+          g.out_f[z * g.out_f_zs + (long)row * g.ldo_f + col] = v;
         }
       }
   } else if constexpr (EPI == EPI_GEGLU) {
@@ -229,14 +229,14 @@ NS2_DEVINL void gemm_epilogue_lds(f32x16 (&acc)[4][NIT], const GemmArgs& g, int 
               const float4 rr = *reinterpret_cast<const float4*>(g.resid + (long)row * g.ldr + col);
               o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w;
             }
-            *reinterpret_cast<float4*>(g.out_f + (long)row * g.ldo_f + col) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(g.out_f + z * g.out_f_zs + (long)row * g.ldo_f + col) = make_float4(o[0], o[1], o[2], o[3]);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (col + e < g.N) {
                 float t = o[e];
                 if (g.resid) t += g.resid[(long)row * g.ldr + col + e];
-                g.out_f[(long)row * g.ldo_f + col + e] = t;
+                g.out_f[z * g.out_f_zs + (long)row * g.ldo_f + col + e] = t;
               }
           }
         }

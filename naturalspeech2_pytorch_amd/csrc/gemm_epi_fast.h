@@ -211,7 +211,7 @@ NS2_DEVINL void epi_geglu_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_b
 }
 
 // ---- fp32 (+ bias, residual; calls with an activation keep the generic path): two passes of 64 rows x 64 columns through LDS, float4 loads / stores
-NS2_DEVINL void epi_f32_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_base, int col_base, int lane, unsigned char* wbuf) {
+NS2_DEVINL void epi_f32_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int z, int row_base, int col_base, int lane, unsigned char* wbuf) {
   constexpr int RS = 272;
   const int l31 = lane & 31, hi = lane >> 5;
   const float bc0 = g.bias ? g.bias[col_base + l31] : 0.f, bc1 = g.bias ? g.bias[col_base + 32 + l31] : 0.f;
@@ -235,7 +235,7 @@ NS2_DEVINL void epi_f32_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_bas
           *reinterpret_cast<float*>(wbuf + lr * RS + (ni * 32 + l31) * 4) = acc[pass * 2 + mh][ni][r] + (ni ? bc1 : bc0);
         }
     __builtin_amdgcn_wave_barrier();
-    float* obase = g.out_f + (long)(row_base + pass * 64 + lr0) * g.ldo_f + col_base + ch * 4;
+    float* obase = g.out_f + z * g.out_f_zs + (long)(row_base + pass * 64 + lr0) * g.ldo_f + col_base + ch * 4;
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       float4 v = *reinterpret_cast<const float4*>(wbuf + (it * 4 + lr0) * RS + ch * 16);

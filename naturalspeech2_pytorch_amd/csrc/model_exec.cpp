@@ -538,7 +538,7 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
   w->tfeat = c.take<float>((int64_t)B * (dim + 1));
   w->t = c.take<float>((int64_t)B * m->Tc);
   w->condall = c.take<float>((int64_t)B * m->Jtot);
-  w->skinny_ws_bytes = std::max(skinny_linear_workspace_bytes(B, m->Tc, m->Jtot),
+  w->skinny_ws_bytes = std::max(std::max(skinny_linear_workspace_bytes(B, m->Tc, m->Jtot), skinny_linear_workspace_bytes(B, m->dt, m->Jtot)),
                                 std::max(skinny_linear_workspace_bytes(B, dim + 1, m->dt),
                                          skinny_linear_workspace_bytes(B, std::max(m->cfg.dim_prompt, 1), m->dt)));
   w->skinny_ws = c.take<float>((int64_t)(w->skinny_ws_bytes / sizeof(float)));
@@ -581,6 +581,8 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
 
 struct CondState {       // lives in the caller-owned cond_state blob
   float* prompt_cond;    // [B, dt]
+  float* pbias;          // [B, Jtot]: W[:, dt:] prompt_cond[b] + bias of every conditioning projection (the step-invariant half of
+                         // NS2:623 / 744 for a conditioned model; ns2_model_forward_row adds the hoisted time half)
   float* condadd;        // [B, n_cond, dim]
   std::vector<Planes> ck, cvt;   // per layer: K planes [B*Lm, a], V^T planes [B][a][Lmp]
   int n_cond_valid; int Lmp;
@@ -589,6 +591,7 @@ static int64_t carve_cond(const ns2_model* m, CondState* cs, void* base, int64_t
   Carver c(base, cap);
   c.take<int64_t>(4);                              // header: {magic, B, N, n_cond_valid}
   cs->prompt_cond = c.take<float>((int64_t)B * m->dt);
+  cs->pbias = c.take<float>((int64_t)B * m->Jtot);
   cs->condadd = c.take<float>((int64_t)B * n_cond * m->dim);
   const Fmts F = fmts_for(op_precision(m->cfg.precision));
   const bool il = F.xatt_il;                        // the cached cross-attention keys / values are attention operands
@@ -640,6 +643,7 @@ static int attention_call(const bf16_t* q_hi, const bf16_t* q_lo, int ldq, int q
                           int ldk, int k_col0, Planes vt, int vt_ld, Planes o, int ldo, int B, int H, int Nq, int Nk, int prec,
                           hipStream_t s) {
   AttnArgs a;
+  a.lse = nullptr;
   a.q_hi = q_hi; a.q_lo = q_lo; a.ldq = ldq; a.q_col0 = q_col0;
   a.k_hi = k_hi; a.k_lo = k_lo; a.ldk = ldk; a.k_col0 = k_col0;
   a.vt_hi = vt.hi; a.vt_lo = vt.lo; a.vt_ld = vt_ld;
@@ -728,6 +732,9 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
     NSCHK(gemm_f32(m->w_cond2model, w.ctxp.hi, w.ctxp.lo, dpp, B * n_cond, 0, 1, 0, m->b_cond2model, nullptr, 0, cs.condadd, dim, prec, s));
   }
   NSCHK(tap_f32(m, "c", ctok, (int64_t)B * Lm * dim, s));
+  // the prompt half of every conditioning projection of the step: rows dt .. 2 dt of the K-major weight (t = cat(time, prompt_cond), NS2:960)
+  HIPCHK(launch_skinny_linear(cs.prompt_cond, m->dt, m->wt_cond + (size_t)m->dt * m->Jtot, m->b_cond, cs.pbias, m->Jtot, B, m->dt, m->Jtot, 0,
+                              w.skinny_ws, w.skinny_ws_bytes, s));
   // per-layer cross-attention keys / values of the (step-invariant) context (NS2:1063 with context = c)
   for (int l = 0; l < m->cfg.depth; ++l)
     NSCHK(gemm_qkv(m->layers[l].ckv, w.cpl.hi, w.cpl.lo, dp, B * Lm, Lm, a, cs.ck[l].hi, cs.ck[l].lo, a, cs.cvt[l].hi, cs.cvt[l].lo,
@@ -783,10 +790,12 @@ extern "C" int ns2_model_profile_end(ns2_model* m, double* total_ms, int64_t* la
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* times, const void* cond_state, int n_cond, float* out,
-                                 int B, int N, void* workspace, int64_t workspace_bytes, void* stream) {
+// cond_row != null: the step's time conditioning comes from a row of the table ns2_model_time_table built ahead of the run
+// (the sampler's times are known up front and shared by the batch, NS2:1303-1308): no projection is launched in the step
+static int forward_impl(ns2_model* m, const float* x, const float* times, const float* cond_row, const void* cond_state, int n_cond, float* out,
+                        int B, int N, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!m || !m->finalized) { set_error("model not finalized"); return NS2_ERR_STATE; }
-  if (!x || !times || !out || B <= 0 || N <= 0) { set_error("bad forward arguments"); return NS2_ERR_ARG; }
+  if (!x || (!times && !cond_row) || !out || B <= 0 || N <= 0) { set_error("bad forward arguments"); return NS2_ERR_ARG; }
   const bool cond = m->cfg.condition_on_prompt;
   if (cond != (cond_state != nullptr)) {
     set_error(cond ? "conditional model needs a cond_state (ns2_model_prepare_cond)" : "unconditional model got a cond_state");
@@ -804,12 +813,19 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
   char name[64];
 
   // ---- t = to_time_cond(times) [, prompt_cond]  (NS2:944-960), then every conditioning projection of the step at once
-  HIPCHK(launch_time_embed(times, m->freqs, m->wt_time, m->b_time, w.tfeat, w.t, m->Tc, B, dim, m->dt, w.skinny_ws, w.skinny_ws_bytes, s));
-  if (cond)
-    HIPCHK(hipMemcpy2DAsync(w.t + m->dt, (size_t)m->Tc * 4, cs.prompt_cond, (size_t)m->dt * 4, (size_t)m->dt * 4, B,
-                            hipMemcpyDeviceToDevice, s));
-  NSCHK(tap_f32(m, "t", w.t, (int64_t)B * m->Tc, s));
-  HIPCHK(launch_skinny_linear(w.t, m->Tc, m->wt_cond, m->b_cond, w.condall, Jtot, B, m->Tc, Jtot, 0, w.skinny_ws, w.skinny_ws_bytes, s));
+  const float* call = w.condall;     // [gamma | beta] blocks of all FiLM / adaptive-norm projections; row b at call + b * cld
+  int cld = Jtot;
+  if (cond_row) {
+    if (cond) HIPCHK(launch_add_row(cond_row, cs.pbias, w.condall, B, Jtot, s));     // time half (hoisted) + prompt half (per utterance)
+    else { call = cond_row; cld = 0; }                                                // every utterance reads the same row
+  } else {
+    HIPCHK(launch_time_embed(times, m->freqs, m->wt_time, m->b_time, w.tfeat, w.t, m->Tc, B, dim, m->dt, w.skinny_ws, w.skinny_ws_bytes, s));
+    if (cond)
+      HIPCHK(hipMemcpy2DAsync(w.t + m->dt, (size_t)m->Tc * 4, cs.prompt_cond, (size_t)m->dt * 4, (size_t)m->dt * 4, B,
+                              hipMemcpyDeviceToDevice, s));
+    NSCHK(tap_f32(m, "t", w.t, (int64_t)B * m->Tc, s));
+    HIPCHK(launch_skinny_linear(w.t, m->Tc, m->wt_cond, m->b_cond, w.condall, Jtot, B, m->Tc, Jtot, 0, w.skinny_ws, w.skinny_ws_bytes, s));
+  }
 
   // ---- x (+ aligned conditioning, NS2:976-992) -> split planes
   HIPCHK(launch_split(x, dim, cond ? cs.condadd : nullptr, dim, n_cond, cond ? cs.n_cond_valid : 0, w.xs.hi, w.xs.lo, dp, M, dim, N, s, w.xs.fmt));
@@ -824,7 +840,7 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
     const int lda = (st == 0) ? dp : L * dp;
     const long a_zs = (st == 0) ? 0 : dp;
     PROF(PC_GEMM_WAVENET, gemm_wavenet(m->w_wn[st], a_hi, a_lo, lda, a_zs, M, N, /*dil=*/1, /*dil_z=*/1, /*nz=*/L, m->b_wn_conv[st], m->b_wn_res[st],
-                       dim, w.condall + (size_t)st * L * 2 * dim, Jtot, 2 * dim, cur.hi, cur.lo, L * dp, dp, dp, prec, s,
+                       dim, call + (size_t)st * L * 2 * dim, cld, 2 * dim, cur.hi, cur.lo, L * dp, dp, dp, prec, s,
                        /*p1_half=*/hybrid_plan(m->cfg.precision) ? 1 : 0));
     snprintf(name, sizeof name, "wavenet.stack%d", st);
     NSCHK(tap_planes(m, name, cur, L * dp, M, L * dp, s));
@@ -836,25 +852,25 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
   NSCHK(tap_f32(m, "wavenet.out", w.xres, (int64_t)M * dim, s));
 
   // ---- transformer (NS2:786-809)
-  const float* cbase = w.condall + (size_t)S * L * 2 * dim;
+  const float* cbase = call + (size_t)S * L * 2 * dim;
   for (int l = 0; l < m->cfg.depth; ++l) {
     const ns2_model::Layer& ly = m->layers[l];
     const float* cn = cbase + (size_t)l * m->nnorm * 2 * dim;
     // self attention
-    PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn, Jtot, w.xn, dp, nullptr, 0, s));
+    PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn, cld, w.xn, dp, nullptr, 0, s));
     PROF(PC_GEMM_QKV, gemm_qkv(ly.qkv, w.xn.hi, w.xn.lo, dp, M, N, 2 * a, w.qk.hi, w.qk.lo, 2 * a, w.vt.hi, w.vt.lo, w.Nkp, prec, s));
     PROF(PC_ATTENTION, attention_call(w.qk.hi, w.qk.lo, 2 * a, 0, w.qk.hi, w.qk.lo, 2 * a, a, w.vt, w.Nkp, w.o, a, B, H, N, N, prec, s));
     PROF(PC_GEMM_F32, gemm_f32(ly.out, w.o.hi, w.o.lo, a, M, 0, 1, 0, nullptr, w.xres, dim, w.xres, dim, prec, s));
     snprintf(name, sizeof name, "layer%d.attn", l);
     NSCHK(tap_f32(m, name, w.xres, (int64_t)M * dim, s));
     if (cond) {   // cross attention to the resampled prompt tokens (NS2:799-803)
-      PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + 2 * dim, Jtot, w.xn, dp, nullptr, 0, s));
+      PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + 2 * dim, cld, w.xn, dp, nullptr, 0, s));
       PROF(PC_GEMM_SPLIT, gemm_split(ly.cq, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, w.xq.hi, w.xq.lo, a, prec, s, -1, 0, w.xq.fmt));
       PROF(PC_ATTENTION, attention_call(w.xq.hi, w.xq.lo, a, 0, cs.ck[l].hi, cs.ck[l].lo, a, 0, cs.cvt[l], cs.Lmp, w.o, a, B, H, N, Lm, xprec, s));
       PROF(PC_GEMM_F32, gemm_f32(ly.cout, w.o.hi, w.o.lo, a, M, 0, 1, 0, nullptr, w.xres, dim, w.xres, dim, prec, s));
     }
     // feedforward: Linear -> GEGLU -> causal conv k3 -> Linear (NS2:1009-1025)
-    PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + (size_t)(m->nnorm - 1) * 2 * dim, Jtot, w.xn, dp, nullptr, 0, s));
+    PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + (size_t)(m->nnorm - 1) * 2 * dim, cld, w.xn, dp, nullptr, 0, s));
     PROF(PC_GEMM_GEGLU, gemm_geglu(ly.ffin, w.xn.hi, w.xn.lo, dp, M, ly.b_ffin, w.ffh_conv.hi, w.ffh_conv.lo, fp, prec, s, w.ffh_conv.fmt));
     PROF(PC_GEMM_FFCONV, gemm_split(ly.conv, w.ffh_conv.hi, w.ffh_conv.lo, fp, M, 3, 1, N, ly.b_conv, w.ffc.hi, w.ffc.lo, fp,
                                     conv_prec, s, -1, 0, w.ffc.fmt));
@@ -865,5 +881,53 @@ extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* time
   // to_pred: RMSNorm -> Linear (NS2:781-784)
   PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, m->g_pred, nullptr, 0, w.xn, dp, nullptr, 0, s));
   PROF(PC_GEMM_F32, gemm_f32(m->w_pred, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, nullptr, 0, out, dim, prec, s));
+  return NS2_OK;
+}
+
+extern "C" int ns2_model_forward(ns2_model* m, const float* x, const float* times, const void* cond_state, int n_cond, float* out,
+                                 int B, int N, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!times) { set_error("bad forward arguments"); return NS2_ERR_ARG; }
+  return forward_impl(m, x, times, nullptr, cond_state, n_cond, out, B, N, workspace, workspace_bytes, stream);
+}
+extern "C" int ns2_model_forward_row(ns2_model* m, const float* x, const float* cond_row, const void* cond_state, int n_cond, float* out,
+                                     int B, int N, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!cond_row) { set_error("ns2_model_forward_row: null conditioning row"); return NS2_ERR_ARG; }
+  return forward_impl(m, x, nullptr, cond_row, cond_state, n_cond, out, B, N, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ hoisted time conditioning
+// "all time-conditioning projections" are step-invariant work once the schedule is known: the sampler's times are
+// linspace(1, 0, T + 1) and identical across the batch (NS2:1303-1308), so the 56-68 Linears of NS2:623 / 744 for the WHOLE run are
+// this one table [T, Jtot] (229 MB at T = 1000, d512/L12) and a step reads row i.  Rows are produced 32 at a time by the very
+// kernels a step would launch, with the K split of a batch of `plan_B` rows (the run's batch size): every row is bit-identical
+// to what the step's own launches compute for a batch of that size.  Unconditional model: row = the complete projections (with
+// bias); conditioned: the time half W[:, :dt] t (the prompt half + bias sits in the cond_state, ns2_model_prepare_cond).
+extern "C" int ns2_model_table_cols(const ns2_model* m) { return m ? m->Jtot : 0; }
+extern "C" int64_t ns2_model_time_table_workspace_bytes(const ns2_model* m, int plan_B) {
+  if (!m) return 0;
+  const int kt = m->cfg.condition_on_prompt ? m->dt : m->Tc;
+  int64_t n = rup64((int64_t)32 * (m->dim + 1) * 4, 256) + rup64((int64_t)32 * m->dt * 4, 256);
+  n += rup64((int64_t)std::max(skinny_linear_workspace_bytes(32, kt, m->Jtot, plan_B), skinny_linear_workspace_bytes(32, m->dim + 1, m->dt, plan_B)), 256);
+  return n + 256;
+}
+extern "C" int ns2_model_time_table(ns2_model* m, const float* times, int T, int plan_B, float* table, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+  if (!m || !m->finalized) { set_error("model not finalized"); return NS2_ERR_STATE; }
+  if (!times || !table || !workspace || T <= 0 || plan_B <= 0) { set_error("ns2_model_time_table: bad arguments"); return NS2_ERR_ARG; }
+  if (workspace_bytes < ns2_model_time_table_workspace_bytes(m, plan_B)) { set_error("ns2_model_time_table: workspace too small"); return NS2_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const bool cond = m->cfg.condition_on_prompt;
+  const int kt = cond ? m->dt : m->Tc;               // unconditional: Tc == dt
+  Carver c(workspace, workspace_bytes);
+  float* feat = c.take<float>((int64_t)32 * (m->dim + 1));
+  float* tt = c.take<float>((int64_t)32 * m->dt);
+  const size_t wsb = std::max(skinny_linear_workspace_bytes(32, kt, m->Jtot, plan_B), skinny_linear_workspace_bytes(32, m->dim + 1, m->dt, plan_B));
+  float* ws = c.take<float>((int64_t)(wsb / sizeof(float)));
+  for (int t0 = 0; t0 < T; t0 += 32) {
+    const int nb = std::min(32, T - t0);
+    HIPCHK(launch_time_embed(times + t0, m->freqs, m->wt_time, m->b_time, feat, tt, m->dt, nb, m->dim, m->dt, ws, wsb, s, plan_B));
+    HIPCHK(launch_skinny_linear(tt, m->dt, m->wt_cond, cond ? nullptr : m->b_cond, table + (size_t)t0 * m->Jtot, m->Jtot, nb, kt, m->Jtot, 0, ws,
+                                wsb, s, plan_B));
+  }
   return NS2_OK;
 }

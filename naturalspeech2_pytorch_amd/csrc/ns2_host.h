@@ -40,5 +40,7 @@ std::vector<int> geglu_row_map(int f, int rows_p);
 struct ns2_weight {
   ns2::PackedW w;
   int taps, geglu, has_extra, cols_p;
+  int cols = 0;                  // source columns (per tap)
+  int* d_map = nullptr;          // device copy of the row map the weight was packed with (ns2_weight_update re-packs in place)
   std::vector<void*> owned;
 };

@@ -62,6 +62,7 @@ struct GemmArgs {
   const float* film; int film_ld;           // gamma at film[b*film_ld + col], beta at film[b*film_ld + N + col]
   const float* resid; int ldr;
   float* out_f; int ldo_f;
+  long out_f_zs;     // EPI_F32 with nz > 1: slice z writes out_f + z * out_f_zs (split-K partial sums of the weight gradients)
   bf16_t* out_hi; bf16_t* out_lo; int ldo_s; int out_ncols;   // writes columns [0, out_ncols) (zero beyond N)
   bf16_t* vt_hi; bf16_t* vt_lo; int vt_ld; int vt_rows; int split_col;
   // batching over blockIdx-z (wavenet columns): element offsets per z
@@ -90,6 +91,8 @@ struct AttnArgs {
   int B, H, Nq, Nk;
   float scale;
   const unsigned char* kmask;                            // optional key-padding mask [B, Nk], 1 = attend (ATT:92-94, 136-138)
+  float* lse;                                            // optional [B, H, Nq]: log2 of the softmax denominator of the SCALED scores
+                                                         // (m + log2 l), what the backward kernels recompute P from; null = not wanted
 };                                                       // precision: 3 bf16x3, 1 bf16, 2 and 4: one IEEE-half product
 hipError_t launch_attention(const AttnArgs& a, int precision, hipStream_t s);
 
@@ -112,13 +115,15 @@ hipError_t launch_split(const float* x, int ldx, const float* add, int ldadd, in
 // LearnedSinusoidalPosEmb + Linear(d+1, dt) + SiLU (NS2:108-120, 839-843): times[B] -> out[B, ld_out] columns [0, dt)
 // wt is the Linear weight stored K-major [dim+1, dt]; feat_ws is a [B, dim+1] fp32 scratch.
 hipError_t launch_time_embed(const float* times, const float* freqs, const float* wt, const float* bias, float* feat_ws,
-                             float* out, int ld_out, int B, int dim, int dt, float* ws, size_t ws_bytes, hipStream_t s);
+                             float* out, int ld_out, int B, int dim, int dt, float* ws, size_t ws_bytes, hipStream_t s, int plan_B = 0);
 
 // out[b, j] = act( sum_k in[b,k] * wt[k, j] + bias[j] ), wt stored K-major ([K, J]); act 0 none, 1 SiLU
 // ws: caller-owned scratch of skinny_linear_workspace_bytes(B, K, J) for the split-K partial sums (null: no K split)
-size_t skinny_linear_workspace_bytes(int B, int K, int J);
+// plan_B > 0: split K as a batch of plan_B rows would (same order of partial sums: ns2_model_time_table)
+size_t skinny_linear_workspace_bytes(int B, int K, int J, int plan_B = 0);
 hipError_t launch_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out,
-                                int B, int K, int J, int act, float* ws, size_t ws_bytes, hipStream_t s);
+                                int B, int K, int J, int act, float* ws, size_t ws_bytes, hipStream_t s, int plan_B = 0);
+hipError_t launch_add_row(const float* row, const float* add, float* out, int B, long J, hipStream_t s);
 
 // batched fp32 [R, C] -> [C, R]
 hipError_t launch_transpose_f32(const float* in, int batch, int R, int C, float* out, hipStream_t s);
@@ -204,5 +209,61 @@ hipError_t launch_rvq_encode(const RvqArgs& a, hipStream_t s);
 // decode: emb[m] = sum_q codebooks[q][codes[m][q]]  (HFENC:440-447)
 hipError_t launch_rvq_decode(const int64_t* codes, const float* codebooks, float* emb, int M, int Q, int C, int D,
                              hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------- backward pass (backward.hip)
+// fp32 [M, C] (xf) or operand planes (in_hi / in_lo, interleaved bf16 hi/lo) -> row planes and / or TRANSPOSED planes
+// T[c][m] (the operands of the weight-gradient GEMMs and of the attention backward), optionally shifted along the token axis
+// inside each utterance: T[c][m] = in[m - shift][c] if m - shift lies in the utterance of m, else 0.
+struct TPlanesArgs {
+  const float* xf; long ldx;
+  const bf16_t* in_hi; const bf16_t* in_lo; int ld_in; int in_col0;
+  int M, C;
+  int seq_len, shift;
+  bf16_t* row_hi; bf16_t* row_lo; int ld_row;      // optional (fp32 input, shift 0): planes [M, ld_row], zero beyond C
+  bf16_t* t_hi; bf16_t* t_lo; long ld_t;           // optional transposed planes, ld_t (logical, multiple of 32) token columns, zero beyond
+  int per_batch;                                   // 0: row c, column m (all M tokens); 1: row b * t_rows_per_batch + c, column n
+  int t_rows_per_batch; int t_rows;                // rows written (>= C, zeros beyond C): per utterance / in total
+  float* colsum_partial;                           // optional (fp32 input): [slices][C] column sums of 64-row tiles (bias gradients)
+};
+hipError_t launch_tplanes(const TPlanesArgs& a, hipStream_t s);
+long tplanes_slices(int M, long ld_t);             // number of 64-row tiles (= colsum slots) of a non-per_batch launch
+hipError_t launch_reduce_slices(const float* partial, long outer, int S, long inner, float* out, int accumulate, hipStream_t s);
+hipError_t launch_wgrad_reduce(const float* partial, int S, int R, long ldp, int T, int Kp, int K, float* out, hipStream_t s);
+hipError_t launch_film_gate_fwd(const float* h, long ldh, const float* film, int film_ld, int seq_len, long M, int d, float* out,
+                                long ldo, hipStream_t s);
+int film_gate_slices(int seq_len);
+hipError_t launch_film_gate_bwd(const float* dg, long lddg, const float* h, long ldh, const float* film, int film_ld, int B, int seq_len,
+                                int d, float* dh, long lddh, float* partial, hipStream_t s);
+hipError_t launch_geglu_fwd(const float* pre, long ldp, long M, int f, bf16_t* out_hi, bf16_t* out_lo, int ldo, hipStream_t s);
+hipError_t launch_geglu_bwd(const float* dh, long lddh, const float* pre, long ldp, long M, int f, float* dpre, long lddp, hipStream_t s);
+struct NormBwdArgs {
+  const float* x; long ldx;            // the norm's input [B * seq_len, d]
+  const float* dy; long lddy;          // gradient of its output
+  const float* gamma;                  // learned scale [d] or null
+  const float* cond; int cond_ld;      // adaptive [gamma_c | beta_c] per utterance or null
+  const float* dx_add; float* dx; long lddx;   // dx = (dx_add ? dx_add : 0) + d(loss)/dx ; dx may alias dx_add
+  float* cond_partial;                 // [B * slices][2 d] (required with cond)
+  float* gamma_partial;                // [B * slices][d] or null
+  int B, seq_len, d;
+};
+int rmsnorm_bwd_slices(int seq_len);
+hipError_t launch_rmsnorm_bwd(const NormBwdArgs& a, hipStream_t s);
+hipError_t launch_attn_delta(const float* dO, long lddo, const bf16_t* o_hi, const bf16_t* o_lo, int ldo, int B, int H, int Nq, float* delta,
+                             hipStream_t s);
+struct AttnBwdArgs {
+  const bf16_t* q_hi; const bf16_t* q_lo; int ldq, q_col0;        // [B*Nq, ldq], head h at columns q_col0 + 64 h
+  const bf16_t* k_hi; const bf16_t* k_lo; int ldk, k_col0;        // [B*Nk, ldk]
+  const bf16_t* v_hi; const bf16_t* v_lo; int ldv, v_col0;        // [B*Nk, ldv] values, ROW-major
+  const bf16_t* do_hi; const bf16_t* do_lo; int lddo;             // [B*Nq, lddo] gradient of the attention output, head h at 64 h
+  const bf16_t* kt_hi; const bf16_t* kt_lo; int kt_ld;            // transposed [B][H*64][kt_ld] (dQ)
+  const bf16_t* qt_hi; const bf16_t* qt_lo; int qt_ld;            // transposed [B][H*64][qt_ld] (dK)
+  const bf16_t* dot_hi; const bf16_t* dot_lo; int dot_ld;         // transposed [B][H*64][dot_ld] (dV)
+  const float* lse; const float* delta;                           // [B, H, Nq]
+  float* dq; int lddq, dq_col0;                                   // fp32 outputs (null = not wanted; dk and dv come together)
+  float* dk; int lddk, dk_col0;
+  float* dv; int lddv, dv_col0;
+  int B, H, Nq, Nk; float scale;
+};
+hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
 
 }  // namespace ns2

@@ -150,10 +150,16 @@ class NaturalSpeech2(nn.Module):
         # `time_difference` only shifts times_next AFTER gamma_next was taken (NS2:1396-1406): it has no effect upstream either
         if not self._fused_ddim_ok():
             return self._ddim_sample_unfused(audio, pairs, prompt, cond, cond_scale)
+        # the run's times are known here and shared by the batch, so every time-conditioning projection of the run is
+        # computed once, ahead of the loop; step i reads row i (Model.time_table)
+        table = None
+        if hasattr(self.model, "time_table") and audio.is_cuda:
+            table = self.model.time_table(torch.stack([p[0][0] for p in pairs]), batch)
         if use_graph:
-            return self._ddim_sample_graph(audio, pairs, prompt, cond, cond_scale)
-        for times, times_next in pairs:
-            out = self.model.forward_with_cond_scale(audio, times, prompt=prompt, cond_scale=cond_scale, cond=cond)
+            return self._ddim_sample_graph(audio, pairs, prompt, cond, cond_scale, table)
+        for i, (times, times_next) in enumerate(pairs):
+            kw = {} if table is None else dict(cond_row=table[i])
+            out = self.model.forward_with_cond_scale(audio, times, prompt=prompt, cond_scale=cond_scale, cond=cond, **kw)
             ops.ddim_step(audio, out, times, times_next, self.objective, self.noise_schedule, self.scale, out=audio)
         return audio
 
@@ -170,11 +176,14 @@ class NaturalSpeech2(nn.Module):
             audio = x0 * alpha_n + eps * sigma_n
         return audio
 
-    def _ddim_sample_graph(self, audio, pairs, prompt, cond, cond_scale):
-        """one (model + DDIM update) step captured in a HIP graph; times are device tensors rewritten per step."""
+    def _ddim_sample_graph(self, audio, pairs, prompt, cond, cond_scale, table=None):
+        """one (model + DDIM update) step captured in a HIP graph; times (and the step's row of the conditioning table) are device
+        buffers rewritten per step."""
         t_buf, tn_buf = pairs[0][0].clone(), pairs[0][1].clone()
+        row = table[0].clone() if table is not None else None
+        kw = {} if row is None else dict(cond_row=row)
         step = lambda: ops.ddim_step(                                                   # noqa: E731
-            audio, self.model.forward_with_cond_scale(audio, t_buf, prompt=prompt, cond_scale=cond_scale, cond=cond),
+            audio, self.model.forward_with_cond_scale(audio, t_buf, prompt=prompt, cond_scale=cond_scale, cond=cond, **kw),
             t_buf, tn_buf, self.objective, self.noise_schedule, self.scale, out=audio)
         keep = audio.clone()
         side = torch.cuda.Stream()
@@ -187,9 +196,11 @@ class NaturalSpeech2(nn.Module):
         with torch.cuda.graph(g):
             step()
         audio.copy_(keep)
-        for times, times_next in pairs:
+        for i, (times, times_next) in enumerate(pairs):
             t_buf.copy_(times)
             tn_buf.copy_(times_next)
+            if row is not None:
+                row.copy_(table[i])
             g.replay()
         return audio
 

@@ -324,20 +324,42 @@ class HipDenoiserMixin:
         """forget the cached step-invariant conditioning (call when prompt / cond were rewritten in place through `.data`)"""
         self._native.cond_cache = {}
 
+    # ---- step-invariant time conditioning (SURVEY §8f-1)
+    @torch.no_grad()
+    def time_table(self, times, batch):
+        """[T, cols] conditioning table for the sampler's times (1-D tensor, shared by the batch: NS2:1303-1308): EVERY
+        time-conditioning projection of the run in one pass before the loop.  `forward(..., cond_row=table[i])` then launches no
+        projection in step i; for an unconditional model the result is bit-identical to `forward(x, times_i.expand(batch))`.
+        Tied to the packed weights: build it after the last parameter change (the sampler does, per run)."""
+        ns = self._ensure_native()
+        lib = _lib.load()
+        dev = next(self.parameters()).device
+        t = times.to(device=dev, dtype=torch.float32).contiguous()
+        cols = lib.ns2_model_table_cols(ns.handle)
+        table = torch.empty(t.numel(), cols, dtype=torch.float32, device=dev)
+        nws = lib.ns2_model_time_table_workspace_bytes(ns.handle, int(batch))
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.ns2_model_time_table(ns.handle, t.data_ptr(), t.numel(), int(batch), table.data_ptr(), ws.data_ptr(), nws,
+                                           torch.cuda.current_stream().cuda_stream), "ns2_model_time_table")
+        return table
+
     # ---- forward (NS2:929-1000)
-    def forward(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None):
+    def forward(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, cond_row=None):
+        """`cond_row` (not in the reference): a row of `time_table()` standing in for `times` (inference only)"""
         p = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(q.requires_grad for q in self.parameters()))
         stochastic = self._hip_cfg["condition_on_prompt"] and p not in (0, 0., 1, 1.)
         if needs_grad or stochastic:
             # training (loss.backward(), NS2:1635/1886) and per-utterance stochastic conditioning dropout (a training /
-            # validation feature, NS2:79-85) run the differentiable PyTorch composite; sampling never gets here
+            # validation feature, NS2:79-85) run the differentiable path: on an MI355X the HIP training kernels (training.py),
+            # on the CPU the PyTorch composite; sampling never gets here
             self._native.autograd_seen = True
             return self._forward_autograd(x, times, prompt=prompt, prompt_mask=prompt_mask, cond=cond, cond_drop_prob=cond_drop_prob)
-        return self._forward_hip(x, times, prompt, prompt_mask, cond, cond_drop_prob)
+        return self._forward_hip(x, times, prompt, prompt_mask, cond, cond_drop_prob, cond_row=cond_row)
 
     @torch.no_grad()
-    def _forward_hip(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, out=None):
+    def _forward_hip(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, out=None, cond_row=None):
         if prompt_mask is not None:
             raise NotImplementedError("prompt_mask: no reference caller passes one (NS2:1333, 1410, 1635)")
         p = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
@@ -350,8 +372,12 @@ class HipDenoiserMixin:
         assert x.ndim == 3 and x.shape[-1] == dim, f"x must be [b, n, {dim}]"
         B, N, _ = x.shape
         xin = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
-        t = times.to(device=xin.device, dtype=torch.float32).contiguous()
-        assert t.shape == (B,)
+        if cond_row is None:
+            t = times.to(device=xin.device, dtype=torch.float32).contiguous()
+            assert t.shape == (B,)
+        else:
+            assert cond_row.is_cuda and cond_row.dtype == torch.float32 and cond_row.is_contiguous() and \
+                cond_row.numel() == _lib.load().ns2_model_table_cols(ns.handle), "cond_row must be a row of Model.time_table()"
         out = torch.empty_like(xin) if out is None else out
         state_ptr, n_c = None, 0
         if conditional:
@@ -363,8 +389,13 @@ class HipDenoiserMixin:
             ws = self._workspace(ns, B, N, pr.shape[1], n_c)
         else:
             ws = self._workspace(ns, B, N, 0, 0)
-        check(_lib.load().ns2_model_forward(ns.handle, xin.data_ptr(), t.data_ptr(), state_ptr, n_c, out.data_ptr(), B, N,
-                                            ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "ns2_model_forward")
+        if cond_row is None:
+            check(_lib.load().ns2_model_forward(ns.handle, xin.data_ptr(), t.data_ptr(), state_ptr, n_c, out.data_ptr(), B, N,
+                                                ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "ns2_model_forward")
+        else:
+            check(_lib.load().ns2_model_forward_row(ns.handle, xin.data_ptr(), cond_row.data_ptr(), state_ptr, n_c, out.data_ptr(), B, N,
+                                                    ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                  "ns2_model_forward_row")
         if self._range_guarded() and not torch.cuda.is_current_stream_capturing():
             ns.calls_since_peek += 1
             if ns.sat_event is None and (ns.peek_now or ns.calls_since_peek >= self.SAT_PEEK_EVERY):
@@ -406,6 +437,16 @@ class HipDenoiserMixin:
             for k in bufs:
                 lib.ns2_model_debug_tap(ns.handle, k.encode(), None, 0)
         return out, bufs
+
+
+def _train_forward(m, x, times, prompt, cond, cond_drop_prob):
+    import os
+    from . import training
+    which = os.environ.get("NS2_TRAIN_BACKEND") or getattr(m, "train_backend", "hip")
+    if which == "hip" and training.available(next(m.parameters()).device):
+        return training.model_forward_train(m, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)
+    from .autograd_path import model_forward_autograd
+    return model_forward_autograd(m, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)
 
 
 # ------------------------------------------------------------------------------------------ Model
@@ -497,6 +538,7 @@ class Model(HipDenoiserMixin, nn.Module):
         tr.to_pred = _seq(_RMSNorm(dim), nn.Linear(dim, dim, bias=False))
         self.transformer = tr
 
+        self.train_backend = "hip"                    # "composite": the PyTorch composite also on the GPU (A/B, tests)
         self._hip_init(dict(dim=dim, depth=depth, dim_head=dim_head, heads=heads, ff_mult=ff_mult, wavenet_layers=wavenet_layers,
                             wavenet_stacks=wavenet_stacks, dim_cond_mult=dim_cond_mult, condition_on_prompt=condition_on_prompt,
                             dim_prompt=dim_prompt, num_latents_m=num_latents_m, resampler_depth=resampler_depth), precision)
@@ -507,5 +549,8 @@ class Model(HipDenoiserMixin, nn.Module):
         return next(self.parameters()).device
 
     def _forward_autograd(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None):
-        from .autograd_path import model_forward_autograd
-        return model_forward_autograd(self, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)
+        """forward under autograd (loss.backward(), NS2:1635 / 1886).  Parameters on an MI355X: the HIP training path
+        (training.py: forward and backward kernels of libns2hip behind torch.autograd.Functions).  `train_backend = "composite"`
+        (or NS2_TRAIN_BACKEND=composite), and parameters on the CPU (BASELINE config 1 as the reference runs it): the PyTorch
+        composite of autograd_path.py."""
+        return _train_forward(self, x, times, prompt, cond, cond_drop_prob)

@@ -1,0 +1,594 @@
+"""Training path of `Model`: forward + backward of the denoiser in the HIP kernels of libns2hip.
+
+Reference call sites: `pred = self.model(noised_audio, times, prompt = prompt, cond = cond)` under autograd (NS2:1635), the
+v-target MSE with min-SNR weight (NS2:1637-1666), `accelerator.backward(loss)` (NS2:1886).
+
+How it is cut.  The differentiable graph consists of a handful of coarse `torch.autograd.Function`s whose boundaries are the
+fp32 residual-stream tensors [B*N, dim] of the reference's forward (NS2:929-1000):
+
+    GemmFn            nn.Linear / CausalConv1d / 1x1 conv (+ bias, + residual)                 NS2:583-595, 718-725
+    WavenetBlockFn    dilated conv -> FiLM -> tanh*sigmoid gate, + res_conv                   NS2:597-642
+    AttnFn            adaptive RMSNorm -> q, k, v -> attention -> to_out, + residual         NS2:1029-1069, 727-746, ATT:77-155
+    FeedForwardFn     adaptive RMSNorm -> Linear -> GEGLU -> causal conv k3 -> Linear, + res  NS2:1004-1025
+    NormLinearFn      RMSNorm(gamma) -> Linear                                                NS2:781-784
+
+Inside a Function everything is a launch of libns2hip (`HipBackend` below; C ABI: include/ns2hip.h "training"): activations
+travel between the GEMMs as bf16 hi/lo operand planes, the backward contractions are the FORWARD GEMM kernels on re-packed
+weights (dgrad) and on transposed planes with a fixed-slot split-K (wgrad), attention backward is a flash kernel that recomputes
+P from the forward's log-sum-exp.  Arithmetic: precision 3 ("exact", bf16 x3 products, fp32 accumulate) whatever inference
+precision the `Model` was built with -- gradients match the reference's fp32 autograd to ~1e-5.
+
+What stays in PyTorch ops (rows = batch entries, not tokens; < 0.1 % of the FLOPs): the sinusoidal time embedding and the
+[B, dim_cond] -> [B, 2 dim] conditioning Linears feeding FiLM / adaptive norms (NS2:108-120, 623, 744, 841), the prompt
+mean-pool Linear and the 32-token PerceiverResampler of the conditioned model (NS2:532-579, 858-862) and the `torch.where`
+null-conditioning selects.  Autograd chains them with the Functions above.
+
+`Backend` is the seam the CPU tests use: `tests/emu_backend.py` restates every backend call with plain torch ops on CPU, so the
+chain rule, tap flips, shifts and layouts of THIS file are checked against torch autograd without a GPU; the kernels behind
+`HipBackend` are checked one by one and end to end on the MI355X (`tests/test_backward_gpu.py`).
+"""
+import ctypes
+import math
+import weakref
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+from ._lib import check
+from .ops import Planes, round_up
+
+
+# =============================================================================================== HIP backend
+class TPlanes:
+    """transposed operand planes: `rows` rows of `ld` token columns (bf16 hi/lo lines along the token axis)"""
+    __slots__ = ("buf", "rows", "ld")
+
+    def __init__(self, rows, ld, device):
+        self.buf = torch.empty(rows, 2 * ld, dtype=torch.bfloat16, device=device)
+        self.rows, self.ld = rows, ld
+
+    def ptr(self, row_off=0):
+        return self.buf.data_ptr() + row_off * 4 * self.ld          # 2 planes x 2 bytes per logical column
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class _PackedCache:
+    """Packed weights of a training run: packed once, refreshed IN PLACE (`ns2_weight_update`: no allocation, no
+    synchronisation) when the parameter's version counter moved -- an optimizer step bumps it."""
+
+    def __init__(self):
+        self.map = {}
+
+    def _purge(self):
+        dead = [k for k, v in self.map.items() if any(r() is None for r in v[4])]
+        for k in dead:
+            del self.map[k]
+
+    def get(self, key, params, make_src, **pack_kw):
+        """`key` carries id()s of `params`: an entry is only a hit while those very objects are alive (weak references), so a
+        recycled id can never return another model's weights"""
+        sig = tuple((p.data_ptr(), p._version) for p in params)
+        hit = self.map.get(key)
+        if hit is not None and any(r() is not p for r, p in zip(hit[4], params)):
+            hit = None
+        refs = tuple(weakref.ref(p) for p in params)
+        if hit is None and len(self.map) >= 4096:
+            self._purge()
+        if hit is not None and hit[1] == sig:
+            return hit[0]
+        src = make_src()
+        src = src if isinstance(src, tuple) else (src, None)
+        w, extra = (t.detach().float().contiguous() if t is not None else None for t in src)
+        if hit is not None and hit[2] == (tuple(w.shape), None if extra is None else tuple(extra.shape)):
+            check(_lib.load().ns2_weight_update(hit[0].handle, w.data_ptr(), _p(extra), _s()), "ns2_weight_update")
+            self.map[key] = (hit[0], sig, hit[2], (w, extra), refs)  # keep the sources alive until the stream has consumed them
+            return hit[0]
+        pw = ops.PackedWeight(w, extra1x1=extra, precision=3, **pack_kw)
+        self.map[key] = (pw, sig, (tuple(w.shape), None if extra is None else tuple(extra.shape)), (w, extra), refs)
+        return pw
+
+
+class HipBackend:
+    """every method = launches of libns2hip on the current stream; torch provides the buffers"""
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.packs = _PackedCache()
+
+    # ---- weights
+    def pack(self, key, params, make_src):
+        return self.packs.get(key, params, make_src)
+
+    # ---- forward pieces
+    def split(self, x, C=None):
+        x = x if x.is_contiguous() else x.contiguous()
+        return ops.split(x, precision=3)
+
+    def rmsnorm(self, x, seq_len, gamma=None, cond=None):
+        return ops.rmsnorm(x, seq_len=seq_len, gamma=gamma, cond=cond, precision=3)
+
+    def gemm_f32(self, pw, a, bias=None, resid=None, taps=0, dil=1, seq_len=0, pad_left=-1):
+        """-> fp32 [M, ldo] with ldo = round_up(N, 32); columns >= N are NOT written"""
+        M, N = a.rows, pw.rows
+        ldo = round_up(N, 32)
+        out = torch.empty(M, ldo, dtype=torch.float32, device=a.device)
+        ldr = resid.stride(0) if resid is not None else 0
+        check(self.lib.ns2_linear_f32(pw.handle, a.hi, a.lo, a.ld, M, taps, dil, seq_len, _p(bias), _p(resid), ldr, out.data_ptr(), ldo,
+                                      pad_left, 0, 3, _s()), "ns2_linear_f32")
+        return out
+
+    def gemm_split(self, pw, a, bias=None, taps=0, dil=1, seq_len=0):
+        return ops.linear_split(pw, a, bias=bias, conv_taps=taps, dilation=dil, seq_len=seq_len, precision=3)
+
+    def film_gate_fwd(self, h, film, seq_len, d):
+        out = torch.empty(h.shape[0], d, dtype=torch.float32, device=h.device)
+        check(self.lib.ns2_film_gate_fwd(h.data_ptr(), h.stride(0), film.data_ptr(), film.stride(0), seq_len, h.shape[0], d, out.data_ptr(), d,
+                                         _s()), "ns2_film_gate_fwd")
+        return out
+
+    def geglu_fwd(self, pre, f):
+        M = pre.shape[0]
+        out = ops.empty_planes(M, round_up(f, 32), pre.device)
+        check(self.lib.ns2_geglu_fwd(pre.data_ptr(), pre.stride(0), M, f, out.hi, out.lo, out.ld, _s()), "ns2_geglu_fwd")
+        return out
+
+    def attention(self, q, q_col0, k, k_col0, vt, B, H, Nq, Nk):
+        o = ops.empty_planes(B * Nq, H * 64, q.device)
+        lse = torch.empty(B, H, Nq, dtype=torch.float32, device=q.device)
+        check(self.lib.ns2_attention_lse(q.hi, q.lo, q.ld, q_col0, k.hi, k.lo, k.ld, k_col0, vt.ptr(), vt.ptr() + 64, vt.ld, o.hi, o.lo, H * 64,
+                                         B, H, Nq, Nk, 0.125, lse.data_ptr(), 3, _s()), "ns2_attention_lse")
+        return o, lse
+
+    # ---- backward pieces
+    def grad_prep(self, x, C, want_row=False, want_t=False, want_colsum=False, seq_len=0, per_batch=False, t_rows=None):
+        """x fp32 [M, >= C] -> (row planes [M, round_up(C, 32)], transposed planes, column sums [C])"""
+        M, dev = x.shape[0], x.device
+        row = ops.empty_planes(M, round_up(C, 32), dev) if want_row else None
+        tp, ld_t = None, 0
+        if want_t:
+            ld_t = round_up(seq_len if per_batch else M, 32)
+            t_rows = t_rows or C
+            tp = TPlanes((M // seq_len) * t_rows if per_batch else t_rows, ld_t, dev)
+        part = None
+        if want_colsum:
+            S = self.lib.ns2_grad_prep_slices(M, ld_t)
+            part = torch.empty(S, C, dtype=torch.float32, device=dev)
+        check(self.lib.ns2_grad_prep(x.data_ptr(), x.stride(0), M, C, seq_len, 0, row.hi if row else None, row.lo if row else None,
+                                     row.ld if row else 0, tp.ptr() if tp else None, tp.ptr() + 64 if tp else None, ld_t, t_rows or 0,
+                                     int(per_batch), _p(part), _s()), "ns2_grad_prep")
+        cs = None
+        if want_colsum:
+            cs = torch.empty(C, dtype=torch.float32, device=dev)
+            check(self.lib.ns2_reduce_slices(part.data_ptr(), 1, part.shape[0], C, cs.data_ptr(), 0, _s()), "ns2_reduce_slices")
+        return row, tp, cs
+
+    def transpose(self, p, col0, C, seq_len, shifts=(0,), per_batch=False, pad_rows=256):
+        """planes [M, ld] columns [col0, col0 + C) -> transposed planes; one row block of Cp = round_up(C, 32) rows per shift
+        (the taps of a conv's weight gradient), rows zero-padded to what a W operand of ns2_wgrad may read"""
+        M = p.rows
+        Cp = round_up(C, 32)
+        if per_batch:
+            B = M // seq_len
+            tp = TPlanes(B * C, round_up(seq_len, 32), p.device)
+            check(self.lib.ns2_planes_transpose(p.hi, p.lo, p.ld, col0, M, C, seq_len, 0, tp.ptr(), tp.ptr() + 64, tp.ld, C, 1, _s()),
+                  "ns2_planes_transpose")
+            return tp
+        T = len(shifts)
+        # a W operand is read in whole 256-row tiles from wherever a wgrad starts (row 0 for all taps, row 2 Cp for res_conv)
+        rows = max((T - 1) * Cp + round_up(Cp, pad_rows), round_up(T * Cp, pad_rows))
+        tp = TPlanes(rows, round_up(M, 32), p.device)
+        for t, sh in enumerate(shifts):
+            t_rows = Cp if t < T - 1 else rows - (T - 1) * Cp
+            check(self.lib.ns2_planes_transpose(p.hi, p.lo, p.ld, col0, M, C, seq_len, sh, tp.ptr(t * Cp), tp.ptr(t * Cp) + 64, tp.ld, t_rows, 0,
+                                                _s()), "ns2_planes_transpose")
+        return tp
+
+    def wgrad(self, dyt, xt, R, T, K, row_off=0):
+        """dW [R, K, T] = dY^T X_t ; xt: T blocks of Kp = round_up(K, 32) rows starting at row_off"""
+        Kp = round_up(K, 32)
+        nbytes = self.lib.ns2_wgrad_workspace_bytes(R, T * Kp, dyt.ld)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dyt.buf.device)
+        dw = torch.empty(R, K, T, dtype=torch.float32, device=dyt.buf.device)
+        check(self.lib.ns2_wgrad(dyt.ptr(), dyt.ptr() + 64, xt.ptr(row_off), xt.ptr(row_off) + 64, dyt.ld, R, T, Kp, K, dw.data_ptr(), ws.data_ptr(),
+                                 nbytes, _s()), "ns2_wgrad")
+        return dw
+
+    def film_gate_bwd(self, dg, h, film, B, seq_len, d):
+        S = self.lib.ns2_film_gate_slices(seq_len)
+        dh = torch.empty(h.shape[0], d, dtype=torch.float32, device=h.device)
+        part = torch.empty(B * S, 2 * d, dtype=torch.float32, device=h.device)
+        check(self.lib.ns2_film_gate_bwd(dg.data_ptr(), dg.stride(0), h.data_ptr(), h.stride(0), film.data_ptr(), film.stride(0), B, seq_len, d,
+                                         dh.data_ptr(), d, part.data_ptr(), _s()), "ns2_film_gate_bwd")
+        dfilm = torch.empty(B, 2 * d, dtype=torch.float32, device=h.device)
+        check(self.lib.ns2_reduce_slices(part.data_ptr(), B, S, 2 * d, dfilm.data_ptr(), 0, _s()), "ns2_reduce_slices")
+        return dh, dfilm
+
+    def geglu_bwd(self, dh, pre, f):
+        M = pre.shape[0]
+        dpre = torch.empty(M, round_up(2 * f, 32), dtype=torch.float32, device=pre.device)
+        check(self.lib.ns2_geglu_bwd(dh.data_ptr(), dh.stride(0), pre.data_ptr(), pre.stride(0), M, f, dpre.data_ptr(), dpre.stride(0), _s()),
+              "ns2_geglu_bwd")
+        return dpre
+
+    def rmsnorm_bwd(self, x, dy, B, seq_len, d, gamma=None, cond=None, dx_add=None):
+        """-> (dx [M, d] = dx_add + dL/dx, dcond [B, 2 d] or None, dgamma [d] or None)"""
+        S = self.lib.ns2_rmsnorm_bwd_slices(seq_len)
+        dev = x.device
+        dx = torch.empty(B * seq_len, d, dtype=torch.float32, device=dev)
+        cpart = torch.empty(B * S, 2 * d, dtype=torch.float32, device=dev) if cond is not None else None
+        gpart = torch.empty(B * S, d, dtype=torch.float32, device=dev) if gamma is not None else None
+        check(self.lib.ns2_rmsnorm_bwd(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), _p(gamma), _p(cond),
+                                       cond.stride(0) if cond is not None else 0, B, seq_len, d, _p(dx_add), dx.data_ptr(), d, _p(cpart),
+                                       _p(gpart), _s()), "ns2_rmsnorm_bwd")
+        dcond = dgamma = None
+        if cond is not None:
+            dcond = torch.empty(B, 2 * d, dtype=torch.float32, device=dev)
+            check(self.lib.ns2_reduce_slices(cpart.data_ptr(), B, S, 2 * d, dcond.data_ptr(), 0, _s()), "ns2_reduce_slices")
+        if gamma is not None:
+            dgamma = torch.empty(d, dtype=torch.float32, device=dev)
+            check(self.lib.ns2_reduce_slices(gpart.data_ptr(), 1, B * S, d, dgamma.data_ptr(), 0, _s()), "ns2_reduce_slices")
+        return dx, dcond, dgamma
+
+    def attention_delta(self, do, o, B, H, Nq):
+        delta = torch.empty(B, H, Nq, dtype=torch.float32, device=do.device)
+        check(self.lib.ns2_attention_delta(do.data_ptr(), do.stride(0), o.hi, o.lo, o.ld, B, H, Nq, delta.data_ptr(), _s()), "ns2_attention_delta")
+        return delta
+
+    def attention_bwd(self, q, q_col0, k, k_col0, v, v_col0, do_row, kt, qt, dot, lse, delta, B, H, Nq, Nk, dq=None, dkv=None):
+        """dq: (fp32 tensor [B*Nq, ld], col0) or None; dkv: (tensor [B*Nk, ld], k col0, v col0) or None"""
+        a = _lib.AttnBwdArgs()
+        a.q_hi, a.q_lo, a.ldq, a.q_col0 = q.hi, q.lo, q.ld, q_col0
+        a.k_hi, a.k_lo, a.ldk, a.k_col0 = k.hi, k.lo, k.ld, k_col0
+        a.v_hi, a.v_lo, a.ldv, a.v_col0 = v.hi, v.lo, v.ld, v_col0
+        a.do_hi, a.do_lo, a.lddo = do_row.hi, do_row.lo, do_row.ld
+        if kt is not None:
+            a.kt_hi, a.kt_lo, a.kt_ld = kt.ptr(), kt.ptr() + 64, kt.ld
+        if qt is not None:
+            a.qt_hi, a.qt_lo, a.qt_ld = qt.ptr(), qt.ptr() + 64, qt.ld
+            a.dot_hi, a.dot_lo, a.dot_ld = dot.ptr(), dot.ptr() + 64, dot.ld
+        a.lse, a.delta = lse.data_ptr(), delta.data_ptr()
+        if dq is not None:
+            a.dq, a.lddq, a.dq_col0 = dq[0].data_ptr(), dq[0].stride(0), dq[1]
+        if dkv is not None:
+            a.dk, a.lddk, a.dk_col0 = dkv[0].data_ptr(), dkv[0].stride(0), dkv[1]
+            a.dv, a.lddv, a.dv_col0 = dkv[0].data_ptr(), dkv[0].stride(0), dkv[2]
+        a.B, a.H, a.Nq, a.Nk, a.scale = B, H, Nq, Nk, 0.125
+        check(self.lib.ns2_attention_bwd(ctypes.byref(a), _s()), "ns2_attention_bwd")
+
+
+_BACKEND = None
+
+
+def backend():
+    global _BACKEND
+    if _BACKEND is None:
+        _BACKEND = HipBackend()
+    return _BACKEND
+
+
+def set_backend(b):
+    """tests: install a substitute backend (tests/emu_backend.py); returns the previous one"""
+    global _BACKEND
+    prev, _BACKEND = _BACKEND, b
+    return prev
+
+
+# =============================================================================================== weight sources of the two packs
+def _taps(w):
+    return w.shape[2] if w.ndim == 3 else 0
+
+
+def _fwd_pack(bk, w):
+    return bk.pack(("f", id(w)), (w,), lambda: w)
+
+
+def _bwd_pack(bk, w):
+    """the dgrad weight: dX = dY W  ->  rows = input channels, columns = output channels, taps flipped (the gradient of a causal
+    conv reads dY[n + (k - 1 - t) dil], i.e. a conv with pad_left = 0 whose tap t' is the forward's tap k - 1 - t')"""
+    if w.ndim == 3:
+        return bk.pack(("b", id(w)), (w,), lambda: w.detach().permute(1, 0, 2).flip(-1))
+    return bk.pack(("b", id(w)), (w,), lambda: w.detach().t())
+
+
+def _shifts(taps, dil):
+    return tuple((taps - 1 - t) * dil for t in range(taps)) if taps else (0,)
+
+
+def _dw(dw, w):
+    """[R, K, T] from ns2_wgrad -> the parameter's own shape"""
+    return dw if w.ndim == 3 else dw[:, :, 0]
+
+
+# =============================================================================================== Functions
+class GemmFn(torch.autograd.Function):
+    """y = conv_or_linear(x) + b (+ resid);  x [M, Cin] fp32, w [Cout, Cin(, k)], causal with dilation `dil` inside utterances of
+    `seq_len` tokens (NS2:583-595)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, resid, seq_len, dil):
+        bk = backend()
+        taps = _taps(w)
+        xp = bk.split(x)
+        y = bk.gemm_f32(_fwd_pack(bk, w), xp, bias=b, resid=resid, taps=taps, dil=dil, seq_len=seq_len if taps else 0)
+        ctx.save_for_backward(w, b)
+        ctx.xp, ctx.cfg = xp, (taps, dil, seq_len, x.shape[1], resid is not None)
+        return y[:, :w.shape[0]]
+
+    @staticmethod
+    def backward(ctx, dy):
+        bk = backend()
+        w, b = ctx.saved_tensors
+        taps, dil, seq_len, cin, has_resid = ctx.cfg
+        cout = w.shape[0]
+        dy = dy if dy.stride(1) == 1 else dy.contiguous()
+        dy_row, dy_t, db = bk.grad_prep(dy, cout, want_row=ctx.needs_input_grad[0], want_t=True, want_colsum=b is not None)
+        xt = bk.transpose(ctx.xp, 0, cin, seq_len if taps else 0, _shifts(taps, dil))
+        dw = _dw(bk.wgrad(dy_t, xt, cout, max(taps, 1), cin), w)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = bk.gemm_f32(_bwd_pack(bk, w), dy_row, taps=taps, dil=dil, seq_len=seq_len if taps else 0, pad_left=0 if taps else -1)[:, :cin]
+        return dx, dw, db, (dy if has_resid else None), None, None
+
+
+class WavenetBlockFn(torch.autograd.Function):
+    """WavenetResBlock (NS2:597-642) without its skip conv: out = tanh(z) sigmoid(z) + res_conv(u), z = conv_dil(u) gamma + beta"""
+
+    @staticmethod
+    def forward(ctx, u, film, wc, bc, wr, br, seq_len, dil):
+        bk = backend()
+        d = u.shape[1]
+        up = bk.split(u)
+        hc = bk.gemm_f32(_fwd_pack(bk, wc), up, bias=bc, taps=3, dil=dil, seq_len=seq_len)
+        g = bk.film_gate_fwd(hc, film, seq_len, d)
+        out = bk.gemm_f32(_fwd_pack(bk, wr), up, bias=br, resid=g, taps=1, dil=1, seq_len=seq_len)
+        ctx.save_for_backward(film, wc, wr, hc)
+        ctx.up, ctx.cfg = up, (seq_len, dil, d)
+        return out[:, :d]
+
+    @staticmethod
+    def backward(ctx, dout):
+        bk = backend()
+        film, wc, wr, hc = ctx.saved_tensors
+        seq_len, dil, d = ctx.cfg
+        B = dout.shape[0] // seq_len
+        dout = dout if dout.stride(1) == 1 else dout.contiguous()
+        dout_row, dout_t, dbr = bk.grad_prep(dout, d, want_row=True, want_t=True, want_colsum=True)
+        dhc, dfilm = bk.film_gate_bwd(dout, hc, film, B, seq_len, d)
+        dhc_row, dhc_t, dbc = bk.grad_prep(dhc, d, want_row=True, want_t=True, want_colsum=True)
+        xt = bk.transpose(ctx.up, 0, d, seq_len, _shifts(3, dil))           # taps 0, 1, 2: shifts 2 dil, dil, 0
+        dwc = bk.wgrad(dhc_t, xt, d, 3, d)
+        dwr = bk.wgrad(dout_t, xt, d, 1, d, row_off=2 * round_up(d, 32))    # res_conv reads the unshifted block (tap 2)
+        du = bk.gemm_f32(_bwd_pack(bk, wc), dhc_row, taps=3, dil=dil, seq_len=seq_len, pad_left=0)
+        du = bk.gemm_f32(_bwd_pack(bk, wr), dout_row, resid=du, taps=1, dil=1, seq_len=seq_len, pad_left=0)
+        return du[:, :d], dfilm, dwc, dbc, dwr, dbr, None, None
+
+
+class AttnFn(torch.autograd.Function):
+    """h + to_out(attention(q, k, v)) with q = to_q(norm(h)), k, v = to_kv(context or norm(h)); norm = RMSNorm with the adaptive
+    (gamma, beta) of `film` (Model, NS2:727-746) -- heads of 64, non-causal, no mask (ATT:77-155)"""
+
+    @staticmethod
+    def forward(ctx, h, film, ctxt, wq, wkv, wout, seq_len, heads, ctx_len):
+        bk = backend()
+        M, d = h.shape
+        B, a = M // seq_len, heads * 64
+        xn = bk.rmsnorm(h, seq_len, cond=film)
+        if ctxt is None:                                                    # self attention: one GEMM for q | k | v
+            wqkv = bk.pack(("qkv", id(wq), id(wkv)), (wq, wkv), lambda: torch.cat((wq.detach(), wkv.detach()), 0))
+            qkv = bk.gemm_split(wqkv, xn)
+            q, k, v, qc, kc, vc, Nk, cp = qkv, qkv, qkv, 0, a, 2 * a, seq_len, None
+        else:
+            q = bk.gemm_split(_fwd_pack(bk, wq), xn)
+            cp = bk.split(ctxt)
+            kv = bk.gemm_split(_fwd_pack(bk, wkv), cp)
+            k, v, qc, kc, vc, Nk = kv, kv, 0, 0, a, ctx_len
+        vt = bk.transpose(v, vc, a, Nk, per_batch=True)
+        o, lse = bk.attention(q, qc, k, kc, vt, B, heads, seq_len, Nk)
+        y = bk.gemm_f32(_fwd_pack(bk, wout), o, resid=h)
+        ctx.save_for_backward(h, film, wq, wkv, wout, lse)
+        ctx.pl, ctx.cfg = (xn, q, k, v, o, cp), (seq_len, heads, Nk, qc, kc, vc, ctxt is not None)
+        return y[:, :d]
+
+    @staticmethod
+    def backward(ctx, dy):
+        bk = backend()
+        h, film, wq, wkv, wout, lse = ctx.saved_tensors
+        xn, q, k, v, o, cp = ctx.pl
+        seq_len, heads, Nk, qc, kc, vc, cross = ctx.cfg
+        M, d = h.shape
+        B, a = M // seq_len, heads * 64
+        dy = dy if dy.stride(1) == 1 else dy.contiguous()
+        dy_row, dy_t, _ = bk.grad_prep(dy, d, want_row=True, want_t=True)
+        dwout = bk.wgrad(dy_t, bk.transpose(o, 0, a, 0), d, 1, a)[:, :, 0]
+        do = bk.gemm_f32(_bwd_pack(bk, wout), dy_row)                       # [M, a]
+        delta = bk.attention_delta(do, o, B, heads, seq_len)
+        do_row, do_tb, _ = bk.grad_prep(do, a, want_row=True, want_t=True, seq_len=seq_len, per_batch=True)
+        kt = bk.transpose(k, kc, a, Nk, per_batch=True)
+        qt = bk.transpose(q, qc, a, seq_len, per_batch=True)
+        if not cross:
+            dqkv = torch.empty(M, 3 * a, dtype=torch.float32, device=h.device)
+            bk.attention_bwd(q, qc, k, kc, v, vc, do_row, kt, qt, do_tb, lse, delta, B, heads, seq_len, Nk, dq=(dqkv, 0), dkv=(dqkv, a, 2 * a))
+            g_row, g_t, _ = bk.grad_prep(dqkv, 3 * a, want_row=True, want_t=True)
+            dwqkv = bk.wgrad(g_t, bk.transpose(xn, 0, d, 0), 3 * a, 1, d)[:, :, 0]
+            dwq, dwkv = dwqkv[:a], dwqkv[a:]
+            wqkv = bk.pack(("qkv_b", id(wq), id(wkv)), (wq, wkv), lambda: torch.cat((wq.detach(), wkv.detach()), 0).t())
+            dxn = bk.gemm_f32(wqkv, g_row)
+            dctx = None
+        else:
+            dq = torch.empty(M, a, dtype=torch.float32, device=h.device)
+            dkv = torch.empty(B * Nk, 2 * a, dtype=torch.float32, device=h.device)
+            bk.attention_bwd(q, qc, k, kc, v, vc, do_row, kt, qt, do_tb, lse, delta, B, heads, seq_len, Nk, dq=(dq, 0), dkv=(dkv, 0, a))
+            q_row, q_t, _ = bk.grad_prep(dq, a, want_row=True, want_t=True)
+            dwq = bk.wgrad(q_t, bk.transpose(xn, 0, d, 0), a, 1, d)[:, :, 0]
+            dxn = bk.gemm_f32(_bwd_pack(bk, wq), q_row)
+            kv_row, kv_t, _ = bk.grad_prep(dkv, 2 * a, want_row=True, want_t=True)
+            dwkv = bk.wgrad(kv_t, bk.transpose(cp, 0, d, 0), 2 * a, 1, d)[:, :, 0]
+            dctx = bk.gemm_f32(_bwd_pack(bk, wkv), kv_row)[:, :d] if ctx.needs_input_grad[2] else None
+        dh, dfilm, _ = bk.rmsnorm_bwd(h, dxn, B, seq_len, d, cond=film, dx_add=dy)
+        return dh, dfilm, dctx, dwq, dwkv, dwout, None, None, None
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """h + Linear(CausalConv1d_k3(GEGLU(Linear(norm(h)))))   (NS2:1004-1025 with the adaptive RMSNorm in front, NS2:805-807)"""
+
+    @staticmethod
+    def forward(ctx, h, film, w1, b1, wc, bc, w2, b2, seq_len):
+        bk = backend()
+        M, d = h.shape
+        f = w2.shape[1]
+        xn = bk.rmsnorm(h, seq_len, cond=film)
+        pre = bk.gemm_f32(_fwd_pack(bk, w1), xn, bias=b1)                   # [M, 2 f]: x | gate
+        hp = bk.geglu_fwd(pre, f)
+        cp = bk.gemm_split(_fwd_pack(bk, wc), hp, bias=bc, taps=3, dil=1, seq_len=seq_len)
+        y = bk.gemm_f32(_fwd_pack(bk, w2), cp, bias=b2, resid=h)
+        ctx.save_for_backward(h, film, w1, wc, w2, pre)
+        ctx.pl, ctx.cfg = (xn, hp, cp), (seq_len, f)
+        return y[:, :d]
+
+    @staticmethod
+    def backward(ctx, dy):
+        bk = backend()
+        h, film, w1, wc, w2, pre = ctx.saved_tensors
+        xn, hp, cp = ctx.pl
+        seq_len, f = ctx.cfg
+        M, d = h.shape
+        B = M // seq_len
+        dy = dy if dy.stride(1) == 1 else dy.contiguous()
+        dy_row, dy_t, db2 = bk.grad_prep(dy, d, want_row=True, want_t=True, want_colsum=True)
+        dw2 = bk.wgrad(dy_t, bk.transpose(cp, 0, round_up(f, 32), 0), d, 1, f)[:, :, 0]
+        dc = bk.gemm_f32(_bwd_pack(bk, w2), dy_row)                         # [M, f]
+        dc_row, dc_t, dbc = bk.grad_prep(dc, f, want_row=True, want_t=True, want_colsum=True)
+        dwc = bk.wgrad(dc_t, bk.transpose(hp, 0, round_up(f, 32), seq_len, _shifts(3, 1)), f, 3, f)
+        dhh = bk.gemm_f32(_bwd_pack(bk, wc), dc_row, taps=3, dil=1, seq_len=seq_len, pad_left=0)
+        dpre = bk.geglu_bwd(dhh, pre, f)                                    # [M, 2 f]
+        p_row, p_t, db1 = bk.grad_prep(dpre, 2 * f, want_row=True, want_t=True, want_colsum=True)
+        dw1 = bk.wgrad(p_t, bk.transpose(xn, 0, d, 0), 2 * f, 1, d)[:, :, 0]
+        dxn = bk.gemm_f32(_bwd_pack(bk, w1), p_row)
+        dh, dfilm, _ = bk.rmsnorm_bwd(h, dxn, B, seq_len, d, cond=film, dx_add=dy)
+        return dh, dfilm, dw1, db1, dwc, dbc, dw2, db2, None
+
+
+class NormLinearFn(torch.autograd.Function):
+    """Linear(RMSNorm(h) * gamma), no bias: `to_pred` (NS2:781-784)"""
+
+    @staticmethod
+    def forward(ctx, h, gamma, w, seq_len):
+        bk = backend()
+        xn = bk.rmsnorm(h, seq_len, gamma=gamma)
+        y = bk.gemm_f32(_fwd_pack(bk, w), xn)
+        ctx.save_for_backward(h, gamma, w)
+        ctx.xn, ctx.seq_len = xn, seq_len
+        return y[:, :w.shape[0]]
+
+    @staticmethod
+    def backward(ctx, dy):
+        bk = backend()
+        h, gamma, w = ctx.saved_tensors
+        M, d = h.shape
+        dy = dy if dy.stride(1) == 1 else dy.contiguous()
+        dy_row, dy_t, _ = bk.grad_prep(dy, w.shape[0], want_row=True, want_t=True)
+        dw = bk.wgrad(dy_t, bk.transpose(ctx.xn, 0, d, 0), w.shape[0], 1, d)[:, :, 0]
+        dxn = bk.gemm_f32(_bwd_pack(bk, w), dy_row)
+        dh, _, dgamma = bk.rmsnorm_bwd(h, dxn, M // ctx.seq_len, ctx.seq_len, d, gamma=gamma)
+        return dh, dgamma, dw, None
+
+
+# =============================================================================================== Model.forward under autograd
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None):
+    """`Model.forward` (NS2:929-1000) as a differentiable graph whose token-sized arithmetic is HIP (module docstring).
+    `m` owns the reference's parameters (this package's `Model` or `compat.HipBackedModel`)."""
+    from . import autograd_path as AP
+    b, n, d = x.shape
+    M = b * n
+    p = m.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
+    heads = m._hip_cfg["heads"]
+    # ---- rows = batch entries: time embedding and every conditioning projection (PyTorch ops, see the module docstring)
+    w = getattr(m.to_time_cond, "0").weights
+    tt = times.float()[:, None]
+    fr = tt * w[None] * 2 * math.pi
+    t = F.silu(getattr(m.to_time_cond, "1")(torch.cat((tt, fr.sin(), fr.cos()), dim=-1)))
+    c = None
+    h = x.float().reshape(M, d)
+    if m.condition_on_prompt:
+        assert prompt is not None and cond is not None
+
+        def mask():
+            if p == 1:
+                return torch.ones(b, dtype=torch.bool, device=x.device)
+            if p == 0:
+                return torch.zeros(b, dtype=torch.bool, device=x.device)
+            return torch.rand(b, device=x.device) < p
+
+        dm = mask()
+        pc = F.silu(getattr(m.to_prompt_cond, "1")(prompt.mean(dim=1)))
+        pc = torch.where(dm[:, None], m.null_prompt_cond, pc)
+        t = torch.cat((t, pc), dim=-1)
+        pr = m.perceiver_resampler                                          # 32 latents per utterance: the PyTorch composite
+        px = pr.proj_context(prompt) if hasattr(pr, "proj_context") else prompt
+        lat = pr.latents[None].expand(b, -1, -1)
+        for attn, ff in pr.layers:
+            lat = AP._attention(lat, attn, heads, context=px, include_queries=True) + lat
+            lat = AP._feedforward(lat, ff, False) + lat
+        c = torch.where(dm[:, None, None], m.null_prompt_tokens, AP._rmsnorm(lat, pr.norm))       # [b, Lm, d]
+        # cond_to_model_dim: 1x1 conv over channel-first cond (NS2:978) = a Linear over the frames
+        n_c = cond.shape[-1]
+        cm = GemmFn.apply(_c(cond.float().transpose(1, 2)).reshape(b * n_c, -1), m.cond_to_model_dim.weight, m.cond_to_model_dim.bias, None,
+                          n_c, 1)
+        cm = cm.reshape(b, n_c, d)
+        cm = torch.where(mask()[:, None, None], m.null_cond.t()[None], cm)
+        if n_c > n:
+            cm = cm[:, :n]
+        elif n_c < n:
+            cm = F.pad(cm, (0, 0, 0, n - n_c))
+        h = h + _c(cm).reshape(M, d)
+        c2 = _c(c.float()).reshape(b * c.shape[1], d)
+    t = _c(t)
+
+    def film_of(lin):
+        return _c(lin(t))
+
+    wn = m.wavenet
+    h0 = GemmFn.apply(h, wn.init_conv.weight, wn.init_conv.bias, None, n, 1)
+    cols = [h0] * m._hip_cfg["wavenet_layers"]
+    skip = None
+    for st in wn.stacks:
+        nxt = []
+        for i, blk in enumerate(st.blocks):
+            z = WavenetBlockFn.apply(_c(cols[i]), film_of(blk.to_time_cond), blk.conv.weight, blk.conv.bias, blk.res_conv.weight,
+                                     blk.res_conv.bias, n, 2 ** i)
+            nxt.append(z)
+            if blk.skip_conv is not None:                                    # sum of the skip convs (NS2:685-686, 725) as a chain of residuals
+                skip = GemmFn.apply(_c(z), blk.skip_conv.weight, blk.skip_conv.bias, skip if skip is None else _c(skip), n, 1)
+        cols = nxt
+    h = GemmFn.apply(_c(skip), wn.final_conv.weight, wn.final_conv.bias, None, n, 1)
+    for layer in m.transformer.layers:
+        a1 = getattr(layer, "1")
+        h = AttnFn.apply(_c(h), film_of(getattr(layer, "0").to_gamma_beta), None, a1.to_q.weight, a1.to_kv.weight, a1.to_out.weight, n, heads, 0)
+        if m.condition_on_prompt:
+            a3 = getattr(layer, "3")
+            h = AttnFn.apply(_c(h), film_of(getattr(layer, "2").to_gamma_beta), c2, a3.to_q.weight, a3.to_kv.weight, a3.to_out.weight, n,
+                             heads, c.shape[1])
+        ff = getattr(layer, "5")
+        l1, cv, l2 = getattr(ff, "0"), getattr(getattr(ff, "2"), "1"), getattr(ff, "3")
+        h = FeedForwardFn.apply(_c(h), film_of(getattr(layer, "4").to_gamma_beta), l1.weight, l1.bias, cv.weight, cv.bias, l2.weight, l2.bias, n)
+    tp = m.transformer.to_pred
+    out = NormLinearFn.apply(_c(h), getattr(tp, "0").gamma, getattr(tp, "1").weight, n)
+    return out.reshape(b, n, d).to(x.dtype)
+
+
+def available(device):
+    """the HIP training path needs the library and parameters on an MI355X"""
+    return device.type == "cuda" and torch.cuda.is_available()

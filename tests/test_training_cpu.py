@@ -1,0 +1,90 @@
+"""Host logic of the HIP training path (`naturalspeech2_pytorch_amd/training.py`) on CPU: the autograd Functions run on
+`tests/emu_backend.EmuBackend` -- a plain-torch restatement of every backend call with the kernels' layout contracts -- and every
+parameter gradient is compared with torch autograd through the PyTorch composite (`autograd_path.model_forward_autograd`, itself
+pinned to the reference's goldens in test_host_cpu.py).  What this pins: the chain rule inside the Functions, the transposed /
+flipped weight of the dgrad GEMMs (pad_left = 0), the per-tap shifts of the wgrad operands, the stacking offsets, which saved
+tensor feeds which kernel.  The kernels themselves are checked on the MI355X (tests/test_backward_gpu.py)."""
+import pytest
+import torch
+
+from naturalspeech2_pytorch_amd import Model, training
+from naturalspeech2_pytorch_amd.autograd_path import model_forward_autograd
+from tests.emu_backend import EmuBackend
+from tests.golden.gen import make_input, make_weights
+
+
+@pytest.fixture()
+def emu():
+    prev = training.set_backend(EmuBackend())
+    yield
+    training.set_backend(prev)
+
+
+def _grads(m, fwd, x, t, **kw):
+    for p in m.parameters():
+        p.grad = None
+    x = x.clone().requires_grad_(True)
+    y = fwd(m, x, t, **kw)
+    w = make_input("gw", tuple(y.shape), seed=11)
+    (y * w).sum().backward()
+    return y.detach(), x.grad.clone(), {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+
+
+def _rel(a, b):
+    return ((a - b).norm() / b.norm().clamp(min=1e-30)).item()
+
+
+@pytest.mark.parametrize("cond", [False, True], ids=["uncond", "cond"])
+def test_training_functions_match_autograd_composite(emu, cond):
+    kw = dict(dim=64, depth=2, wavenet_layers=3, wavenet_stacks=2)
+    if cond:
+        kw.update(dim_prompt=64, condition_on_prompt=True, num_latents_m=8)
+    m = Model(**kw)
+    sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=5)
+    m.load_state_dict(sd)
+    b, n = 2, 40                                     # ragged against every tile size; dilation 4 reaches across 8 of 40 frames
+    x = make_input("x", (b, n, 64), seed=6)
+    t = make_input("times", (b,), seed=6, uniform=True)
+    extra = {}
+    if cond:
+        extra = dict(prompt=make_input("prompt", (b, 11, 64), seed=7), cond=make_input("cond", (b, 64, 33), seed=7), cond_drop_prob=0.)
+    y0, dx0, g0 = _grads(m, model_forward_autograd, x, t, **extra)
+    y1, dx1, g1 = _grads(m, training.model_forward_train, x, t, **extra)
+    assert _rel(y1, y0) < 1e-5
+    assert _rel(dx1, dx0) < 1e-4
+    worst = ("", 0.0)
+    for k in g0:
+        if g0[k] is None:
+            assert g1[k] is None or g1[k].abs().max() == 0, k
+            continue
+        assert g1[k] is not None, f"no gradient for {k}"
+        assert g1[k].shape == g0[k].shape, k
+        e = _rel(g1[k], g0[k])
+        worst = max(worst, (k, e), key=lambda z: z[1])
+        assert e < 2e-4, (k, e)
+    print("worst parameter gradient:", worst)
+
+
+def test_packed_cache_refreshes_in_place_and_never_serves_a_dead_parameter():
+    """the training packs are keyed by id(parameter): a recycled id must not return another tensor's pack"""
+    from naturalspeech2_pytorch_amd.training import _PackedCache
+    made = []
+
+    class FakePW:
+        def __init__(self, w, extra1x1=None, precision=3):
+            self.handle = len(made)
+            made.append(tuple(w.shape))
+
+    import naturalspeech2_pytorch_amd.training as T
+    orig = T.ops.PackedWeight
+    T.ops.PackedWeight = FakePW
+    try:
+        c = _PackedCache()
+        w = torch.nn.Parameter(torch.randn(4, 4))
+        a = c.get(("f", id(w)), (w,), lambda: w)
+        assert c.get(("f", id(w)), (w,), lambda: w) is a and len(made) == 1
+        w2 = torch.nn.Parameter(torch.randn(4, 4))
+        b = c.get(("f", id(w)), (w2,), lambda: w2)          # same key, another live object: a miss, never `a`
+        assert b is not a and len(made) == 2
+    finally:
+        T.ops.PackedWeight = orig
