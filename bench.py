@@ -68,6 +68,53 @@ def dominant_flops(B, N, dim, depth, ff_mult, wn_layers, conv_only=False, condit
     return depth * ffconv + init + skip, depth + 2
 
 
+def train_step_side(dev):
+    import torch
+    from naturalspeech2_pytorch_amd import Model, NaturalSpeech2
+    out = {}
+    for tag, kw, b, n, iters in (("config1_d128_L6_b4", dict(dim=128, depth=6), 4, 1024, 6), ("headline_d512_L12_b32", dict(dim=512, depth=12), 32, 1024, 5)):
+        res = {}
+        for backend, k in (("hip", iters), ("composite", 2)):
+            torch.manual_seed(0)
+            m = Model(**kw).to(dev).train()
+            m.train_backend = backend
+            d = NaturalSpeech2(m, codec=None, target_sample_hz=24000).to(dev)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+            g = torch.Generator().manual_seed(1)
+            audio, times, noise = torch.randn(b, n, kw["dim"], generator=g).to(dev), torch.rand(b, generator=g).to(dev), torch.randn(b, n, kw["dim"], generator=g).to(dev)
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                loss = d(audio, times=times, noise=noise)
+                loss.backward()
+                opt.step()
+                return loss
+
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                loss = step()
+            torch.cuda.synchronize()
+            res[backend] = ((time.perf_counter() - t0) / k, float(loss.detach()))
+            del m, d, opt
+            torch.cuda.empty_cache()
+        flops = 3.0 * UTT_GFLOP[(kw["dim"], kw["depth"], False)] * 1e9 * b * n / 1024        # forward + dgrad + wgrad
+        ms = 1e3 * res["hip"][0]
+        out[tag] = dict(metric=f"warm training step (loss + backward + Adam), Model(dim={kw['dim']}, depth={kw['depth']}), {b} x {n} frames",
+                        ms_per_step=round(ms, 2), iterations=iters, steps_per_s=round(1e3 / ms, 3),
+                        algorithmic_tflops=round(flops / (ms * 1e-3) / 1e12, 1), algorithmic_flops="3 x the forward's (SURVEY 8d)",
+                        frac_of_16bit_peak=round(flops / (ms * 1e-3) / 1e12 / PEAK_16BIT_TFLOPS, 4),
+                        arithmetic="bf16 x3 split operands (3 MFMA units per algorithmic FLOP), fp32 accumulate, fp32 master weights",
+                        pytorch_composite_ms_per_step=round(1e3 * res["composite"][0], 2),
+                        speedup_vs_pytorch_composite=round(res["composite"][0] / res["hip"][0], 2),
+                        loss_hip=res["hip"][1], loss_composite=res["composite"][1],
+                        parity="every parameter's .grad vs the reference's own autograd: tests/test_backward_gpu.py, "
+                               "profiles/r04_parity.json keys backward_vs_reference_autograd/*")
+    return out
+
+
 def physical_cores():
     try:
         import psutil
@@ -462,6 +509,14 @@ def main():
                                     whole_step_algorithmic_tflops=round(UTT_GFLOP[(128, 6, False)] * B * 1e9 / (e2_ / 20) / 1e12, 2),
                                     roofline=dict(frac=r2["frac"], achieved=r2["achieved"], unit="TFLOP/s", kernel=r2["kernel"]) if r2 else None)
         del m2, sd2
+        torch.cuda.empty_cache()
+        # --- one WARM training step (NaturalSpeech2.forward loss, NS2:1635-1666 + loss.backward(), NS2:1886 + Adam) on the
+        #     HIP training path (training.py: forward and backward kernels of libns2hip, bf16 x3 arithmetic) at BASELINE config 1's
+        #     training shape and at the headline shape; the PyTorch composite (fp32 torch ops on the same GPU) timed beside it
+        try:
+            side["train_step"] = train_step_side(dev)
+        except Exception as e:                                        # report, do not fail the line
+            side["train_step"] = dict(skipped=f"{type(e).__name__}: {e}")
         torch.cuda.empty_cache()
 
     if cpu_sd is not None:

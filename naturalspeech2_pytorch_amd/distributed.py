@@ -69,80 +69,131 @@ def sharded_sample(sample_fn: Callable[[torch.Tensor], torch.Tensor], total: int
 class GradientAllReducer:
     """Data-parallel training step for `NaturalSpeech2.forward` (NS2:1635, NS2:1886: the reference hands this to
     accelerate / DDP): one process per GPU, replicated weights, each rank's loss on its own shard of the batch, gradients averaged
-    with bucketed `all_reduce`s (backend "nccl" == RCCL over xGMI) that start WHILE backward is still running.
+    with bucketed `all_reduce`s (backend "nccl" == RCCL over xGMI) that start WHILE backward is still running.  The backward
+    arithmetic underneath is the HIP training path (training.py); this is the collective around it, built for the xGMI topology:
 
-    SURVEY §8f-4 has two halves.  The backward arithmetic itself still runs in the PyTorch composite (`autograd_path.py`; HIP
-    backward kernels are the open half); this class is the other half, built for the xGMI topology rather than copied from
-    DDP: xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduce is bound per link, so buckets are LARGE
-    (default 64 MiB: 1.04 GB of fp32 gradients of the d512/L12 model = 17 collectives, each long enough to run at link rate)
-    and are launched in reverse parameter order as soon as their last gradient has been accumulated
-    (`register_post_accumulate_grad_hook`), on the side stream RCCL uses, overlapping the rest of backward.
+      * xGMI is point-to-point (7 links x ~153 GB/s per GPU) and a ring all-reduce is bound per link, so buckets are LARGE
+        (default 64 MiB: the 1.04 GB of fp32 gradients of the d512/L12 model = 17 collectives, each long enough to run at link
+        rate), formed in reverse parameter order -- gradients become ready back to front;
+      * ONE flat fp32 buffer holds every gradient and every `p.grad` is a VIEW into it: backward accumulates straight into the
+        collective's buffer, the averaged result is already where the optimizer reads it -- no per-step concatenation or copy
+        back (a `zero_grad(set_to_none=True)` in between is tolerated: the fresh gradient is copied into its view once);
+      * a bucket's all-reduce is launched from the post-accumulate hook of its last gradient, but STRICTLY in bucket order: a
+        ready bucket waits for the earlier ones, so every rank issues the same collectives in the same order even when ranks
+        differ in which parameters received a gradient (whatever is left is issued, in order, by `finish()`);
+      * gradient accumulation (`gradient_accumulate_every`, NS2:1877-1885): backward passes inside `with reducer.accumulate():`
+        only accumulate; the pass outside it reduces.  A second reducing backward without `finish()` raises instead of silently
+        dropping gradients.
 
         reducer = GradientAllReducer(diffusion.parameters())        # once
-        loss = diffusion(audio_shard); loss.backward()              # hooks fire all_reduce per bucket during backward
-        reducer.finish()                                            # wait + write the averaged gradients back
-        optimizer.step()
+        for micro in micro_batches[:-1]:
+            with reducer.accumulate():
+                diffusion(micro).backward()
+        diffusion(micro_batches[-1]).backward()                     # hooks fire the all-reduces during this backward
+        reducer.finish()                                            # wait; p.grad now holds the rank-averaged gradient
+        optimizer.step(); reducer.zero_grad()
     """
 
     def __init__(self, parameters, bucket_bytes: int = 64 << 20, process_group=None):
         self.group = process_group
         self.params = [p for p in parameters if p.requires_grad]
+        assert self.params, "no parameters to reduce"
+        assert all(p.dtype == torch.float32 for p in self.params), "gradients are reduced in fp32"
         self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        # buckets in REVERSE registration order: gradients become ready roughly back to front
-        self.buckets, cur, cur_bytes = [], [], 0
-        for p in reversed(self.params):
+        order = list(reversed(self.params))                      # reverse registration order: ready roughly back to front
+        self.flat = torch.zeros(sum(p.numel() for p in order), dtype=torch.float32, device=order[0].device)
+        self._view, self.buckets, self._range = {}, [], []
+        off, cur, cur_bytes, start = 0, [], 0, 0
+        for p in order:
+            self._view[id(p)] = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
             cur.append(p)
-            cur_bytes += p.numel() * p.element_size()
+            cur_bytes += p.numel() * 4
             if cur_bytes >= bucket_bytes:
                 self.buckets.append(cur)
-                cur, cur_bytes = [], 0
+                self._range.append((start, off))
+                cur, cur_bytes, start = [], 0, off
         if cur:
             self.buckets.append(cur)
+            self._range.append((start, off))
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
-        self._pending = [0] * len(self.buckets)
-        self._flat = [None] * len(self.buckets)
-        self._work = [None] * len(self.buckets)
+        for p in self.params:                                    # adopt gradients that exist already, then point .grad at the views
+            if p.grad is not None:
+                self._view[id(p)].copy_(p.grad)
+            p.grad = self._view[id(p)]
+        self._sync = True
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._reset()
 
     def _reset(self):
         self._pending = [len(b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
+        self._launched = 0                                       # buckets [0, _launched) have been issued
+        self._armed = True
 
-    def _launch(self, i):
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[i]]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        self._flat[i] = flat
-        if self.world > 1:
-            self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    # ---- gradient accumulation
+    class _Accumulate:
+        def __init__(self, owner):
+            self.owner = owner
+
+        def __enter__(self):
+            self.prev, self.owner._sync = self.owner._sync, False
+
+        def __exit__(self, *exc):
+            self.owner._sync = self.prev
+
+    def accumulate(self):
+        """context manager: backward passes inside only accumulate into `.grad` (no collective is launched)"""
+        return GradientAllReducer._Accumulate(self)
+
+    def zero_grad(self):
+        """zero every gradient in place (they stay views of the flat buffer)"""
+        self.flat.zero_()
+        for p in self.params:
+            p.grad = self._view[id(p)]
+
+    def _adopt(self, p):
+        v = self._view[id(p)]
+        if p.grad is not None and p.grad.data_ptr() != v.data_ptr():     # zero_grad(set_to_none=True) happened: autograd made a new tensor
+            v.copy_(p.grad)
+            p.grad = v
+
+    def _issue_ready(self):
+        while self._launched < len(self.buckets) and self._pending[self._launched] == 0:
+            i = self._launched
+            if self.world > 1:
+                lo, hi = self._range[i]
+                self._work[i] = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._launched += 1
 
     def _on_grad(self, p):
+        self._adopt(p)
+        if not self._sync:
+            return
         i = self._bucket_of[id(p)]
         self._pending[i] -= 1
-        if self._pending[i] == 0:
-            self._launch(i)
+        if self._pending[i] < 0:
+            raise RuntimeError("GradientAllReducer: a second reducing backward ran before finish(); wrap all but the last backward of a "
+                               "step in `with reducer.accumulate():` (gradients of the extra pass would be lost)")
+        self._issue_ready()
 
     def finish(self):
-        """wait for every bucket (parameters that received no gradient this step count as zeros on this rank) and write the
-        rank-averaged gradients back into `.grad`"""
-        for i, b in enumerate(self.buckets):
-            if self._pending[i] > 0:                 # some parameter of the bucket was unused in this step's graph
-                self._launch(i)
-        for i, b in enumerate(self.buckets):
-            if self._work[i] is not None:
-                self._work[i].wait()
-            flat, off = self._flat[i], 0
-            if self.world > 1:
-                flat.div_(self.world)
-            for p in b:
-                n = p.numel()
-                g = flat[off:off + n].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-                off += n
-            self._flat[i] = None
+        """issue what is left (parameters without a gradient this step contribute their view's content: zero after
+        `zero_grad()`), wait for every collective and divide by the world size: `.grad` holds the rank-averaged gradients"""
+        for p in self.params:
+            if p.grad is None:                                   # never touched since a set_to_none: counts as zero
+                self._view[id(p)].zero_()
+                p.grad = self._view[id(p)]
+            else:
+                self._adopt(p)
+        for i in range(len(self.buckets)):
+            self._pending[i] = 0
+        self._issue_ready()
+        for w in self._work:
+            if w is not None:
+                w.wait()
+        if self.world > 1:
+            self.flat.div_(self.world)
         self._reset()
 
     def remove(self):

@@ -334,16 +334,56 @@ for r in range(world):
 # data parallel: this rank's shard, bucketed all-reduce overlapped with backward (tiny buckets: several collectives)
 red = D.GradientAllReducer(d.parameters(), bucket_bytes=1 << 16)
 assert len(red.buckets) > 3
-d.zero_grad()
+assert all(p.grad.data_ptr() == red._view[id(p)].data_ptr() for p in red.params)      # gradients live in the flat buffer
+red.zero_grad()
 lo, hi = D.shard_range(4, rank, world)
 d(audio[lo:hi], times=times[lo:hi], noise=noise[lo:hi]).backward()
 red.finish()
 err = max(float((p.grad - r).abs().max()) for p, r in zip(d.parameters(), ref_grads))
 assert err < 1e-5, f"rank {rank}: averaged gradients differ from the single-process gradients: {err}"
-# a second step works too (hooks re-armed)
-d.zero_grad(); d(audio[lo:hi], times=times[lo:hi], noise=noise[lo:hi]).backward(); red.finish()
+# a second step after zero_grad(set_to_none=True): fresh gradient tensors are adopted back into their views
+d.zero_grad(set_to_none=True); d(audio[lo:hi], times=times[lo:hi], noise=noise[lo:hi]).backward(); red.finish()
 err2 = max(float((p.grad - r).abs().max()) for p, r in zip(d.parameters(), ref_grads))
 assert err2 < 1e-5
+assert all(p.grad.data_ptr() == red._view[id(p)].data_ptr() for p in red.params)
+# gradient accumulation (NS2:1877-1885): two micro-batches per rank, only the last backward reduces
+red.zero_grad()
+mid = (lo + hi) // 2
+with red.accumulate():
+    (d(audio[lo:mid], times=times[lo:mid], noise=noise[lo:mid]) / 2).backward()
+(d(audio[mid:hi], times=times[mid:hi], noise=noise[mid:hi]) / 2).backward()
+red.finish()
+ref_acc = None
+for r in range(world):
+    rlo, rhi = D.shard_range(4, r, world); rm = (rlo + rhi) // 2
+    for a, b in ((rlo, rm), (rm, rhi)):
+        d2 = [p.grad for p in d.parameters()]
+        gs = torch.autograd.grad(d(audio[a:b], times=times[a:b], noise=noise[a:b]) / (2 * world), list(d.parameters()), allow_unused=True)
+        gs = [g if g is not None else torch.zeros_like(p) for g, p in zip(gs, d.parameters())]
+        ref_acc = gs if ref_acc is None else [x + y for x, y in zip(ref_acc, gs)]
+err3 = max(float((p.grad - r).abs().max()) for p, r in zip(d.parameters(), ref_acc))
+assert err3 < 1e-5, f"rank {rank}: accumulated gradients differ: {err3}"
+# a second reducing backward without finish() must raise, not drop gradients
+red.zero_grad()
+d(audio[lo:hi], times=times[lo:hi], noise=noise[lo:hi]).backward()
+try:
+    d(audio[lo:hi], times=times[lo:hi], noise=noise[lo:hi]).backward()
+    raise SystemExit("second reducing backward did not raise")
+except RuntimeError as e:
+    assert "accumulate" in str(e)
+red.finish()
+# ranks that differ in which parameters got a gradient still issue the same collectives in the same order
+red.zero_grad()
+loss = d(audio[lo:hi], times=times[lo:hi], noise=noise[lo:hi])
+if rank == 0:
+    loss.backward()
+else:                                       # rank 1: the last layer's parameters receive no gradient from this graph
+    frozen = [p for n, p in d.named_parameters() if "to_pred" in n]
+    for p in frozen: p.requires_grad_(False)
+    d(audio[lo:hi], times=times[lo:hi], noise=noise[lo:hi]).backward()
+    for p in frozen: p.requires_grad_(True)
+red.finish()
+assert all(torch.isfinite(p.grad).all() for p in d.parameters())
 dist.barrier()
 if rank == 0:
     print("OK", world, len(red.buckets), err)

@@ -65,7 +65,7 @@ def test_time_table_conditioned_and_cfg():
             t = ts[i].expand(b).contiguous().to(DEV)
             y0 = m.forward_with_cond_scale(x, t, prompt=prompt, cond=cond, cond_scale=1.3)
             y1 = m.forward_with_cond_scale(x, None, prompt=prompt, cond=cond, cond_scale=1.3, cond_row=tab[i])
-            assert rel(y1, y0) < 2e-6, (i, rel(y1, y0))
+            assert rel(y1, y0) < 2e-5, (i, rel(y1, y0))       # the two halves of the projection are summed in another order
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -74,13 +74,14 @@ def test_sampler_with_table_equals_sampler_without(use_graph):
     d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=12).to(DEV)
     noise = make_input("noise", (2, 80, 64), seed=77)
     a = d.sample(length=80, batch_size=2, noise=noise, use_graph=use_graph)
-    tt = Model.time_table
+    from naturalspeech2_pytorch_amd.model import HipDenoiserMixin
+    tt = HipDenoiserMixin.time_table
     try:
-        del Model.time_table                              # the loop then recomputes the projections in every step (rounds 1-3)
+        del HipDenoiserMixin.time_table                   # the loop then recomputes the projections in every step (rounds 1-3)
         assert not hasattr(m, "time_table")
         b = d.sample(length=80, batch_size=2, noise=noise, use_graph=use_graph)
     finally:
-        Model.time_table = tt
+        HipDenoiserMixin.time_table = tt
     assert torch.equal(a, b)
     assert rel(a, O.ddim_sample(sd, noise, 12)) < 1e-4
 
