@@ -42,13 +42,15 @@ PARITY_RECORD = "r04_parity.json"    # profiles/: the tracked key-wise parity re
 PEAK_16BIT_TFLOPS = 2500.0         # dense bf16 / f16 MFMA peak, MI355X_MICROARCH.md (spec; 2495 measured)
 PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (RVQ)
 UTT_GFLOP = {(512, 12, False): 316.37, (512, 12, True): 331.98, (128, 6, False): 26.74}   # per 1024-frame utterance, SURVEY §8d
-MFMA_UNITS = {"exact": 3, "mixed": 2, "half": 1, "fast": 1, "hybrid": 1}   # MFMA-pipe time per algorithmic FLOP of the dominant kernel, in 16-bit-product units
+MFMA_UNITS = {"exact": 3, "mixed": 2, "half": 1, "fast": 1, "hybrid": 1, "hybrid_ff": 1}   # MFMA-pipe time per algorithmic FLOP of the dominant kernel, in 16-bit-product units
 KERNEL_NAME = {"exact": "gemm2_kernel<3, 1, false, 0>", "mixed": "gemm2_kernel<2, 1, true, 0>", "half": "gemm2_kernel<1, 1, true, 0>",
-               "fast": "gemm2_kernel<1, 1, false, 0>", "hybrid": "gemm2_kernel<1, 1, true, 0>"}     # <NSPLIT, EPI_SPLIT = 1, F16, P1>
+               "fast": "gemm2_kernel<1, 1, false, 0>", "hybrid": "gemm2_kernel<1, 1, true, 0>", "hybrid_ff": "gemm2_kernel<1, 1, true, 0>"}     # <NSPLIT, EPI_SPLIT = 1, F16, P1>
 DTYPE = {"exact": "bf16x3 split operands on the bf16 MFMA, fp32 accumulate",
          "mixed": "fp16 operands on the f16 MFMA + both first-order correction terms as e5m2 on the block-scaled fp8 MFMA, fp32 accumulate",
          "hybrid": "fp16 operands on the f16 MFMA + both first-order correction terms as e5m2 on the block-scaled fp8 MFMA "
                    "(FF causal conv: the fp16 product alone), fp32 accumulate",
+         "hybrid_ff": "fp16 operands on the f16 MFMA + both first-order correction terms as e5m2 on the block-scaled fp8 MFMA "
+                      "(whole feed-forward branch and the Wavenet's dilated convs: the fp16 product alone), fp32 accumulate",
          "half": "fp16 operands on the f16 MFMA (one product), fp32 accumulate",
          "fast": "bf16 operands, fp32 accumulate"}
 
@@ -185,7 +187,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="hybrid", choices=["hybrid", "mixed", "half", "exact", "fast"],
+    ap.add_argument("--precision", default="hybrid", choices=["hybrid", "hybrid_ff", "mixed", "half", "exact", "fast"],
                     help="hybrid (default): half product + fp8 correction terms, FF causal conv half only, ~6e-5 from the fp32 "
                          "reference; mixed: correction terms everywhere, ~5e-5; half: one fp16 product, ~8e-4 (thin margin); "
                          "exact: bf16x3 split, 1e-5; fast: bf16, ~1e-2 (outside the tolerance)")
@@ -279,7 +281,7 @@ def main():
                 audio.copy_(keep)
             ns = model._ensure_native()
             # the FF causal convs (bit 7); in the other modes init conv + skip GEMM share their kernel symbol (bit 1)
-            prof_mask = ((1 << 7) | (0 if precision == "hybrid" else (1 << 1))) if (profile and not graph) else 0
+            prof_mask = ((1 << 7) | (0 if precision in ("hybrid", "hybrid_ff") else (1 << 1))) if (profile and not graph) else 0
             barrier()
             if prof_mask:
                 lib.ns2_model_profile_begin(ns.handle, prof_mask)
@@ -327,7 +329,7 @@ def main():
     def roofline_obj(precision, dim, depth, kern_ms_v, kern_n_v, conditioned=False):
         if not kern_n_v:
             return None
-        fl, nl = dominant_flops(B, N, dim, depth, 4, 8, conv_only=(precision == "hybrid"), conditioned=conditioned)
+        fl, nl = dominant_flops(B, N, dim, depth, 4, 8, conv_only=(precision in ("hybrid", "hybrid_ff")), conditioned=conditioned)
         avg_ms = kern_ms_v / kern_n_v
         ach = (fl / nl) / (avg_ms * 1e-3) / 1e12
         traffic, tsrc = None, None
@@ -338,8 +340,8 @@ def main():
             if traffic is not None:
                 tsrc = (f"profiles/{PMC_TRAFFIC}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command "
                         "(tools/pmc_bench.sh), read side doubled per MI355X_MICROARCH.md; a committed profile, NOT measured in this run")
-        what = f"FF causal conv k3 x{depth}" + ("" if precision == "hybrid" else ", wavenet init conv, skip-sum GEMM") + \
-               (f", cross-attention q projection x{depth}" if conditioned and precision != "hybrid" else "")
+        what = f"FF causal conv k3 x{depth}" + ("" if precision in ("hybrid", "hybrid_ff") else ", wavenet init conv, skip-sum GEMM") + \
+               (f", cross-attention q projection x{depth}" if conditioned and precision not in ("hybrid", "hybrid_ff") else "")
         return dict(bound="mfma", kernel=f"ns2::{KERNEL_NAME[precision]} = EPI_SPLIT ({what})",
                     achieved=round(ach, 2), peak=PEAK_16BIT_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_16BIT_TFLOPS, 4),
                     traffic=traffic, traffic_source=tsrc, avg_launch_ms=round(avg_ms, 4), launches=kern_n_v,

@@ -216,7 +216,9 @@ typedef struct {
                                   "half", 1 = bf16 single product "fast"; 5 = "hybrid": the per-site plan of this model
                                   only: precision 4 everywhere except the feed-forward causal conv (NS2:1016) and the dilated
                                   convs of the Wavenet blocks (NS2:612), which run as one fp16 product on the same operands.
-                                  At precisions 2 / 4 / 5 the step-invariant pass (ns2_model_prepare_cond) computes in
+                                  6 = "hybrid_ff": 5, with the rest of the feed-forward branch (FF-in + GEGLU, NS2:1021, and
+                                  FF-out, NS2:1024) as one fp16 product on dense half planes too.
+                                  At precisions 2 / 4 / 5 / 6 the step-invariant pass (ns2_model_prepare_cond) computes in
                                   precision 3: its few rows condition every frame of every step */
 } ns2_model_config;
 
@@ -249,6 +251,12 @@ int ns2_model_time_table(ns2_model* m, const float* times, int T, int plan_B, fl
                          void* stream);
 int ns2_model_forward_row(ns2_model* m, const float* x, const float* cond_row, const void* cond_state, int n_cond, float* out, int B, int N,
                           void* workspace, int64_t workspace_bytes, void* stream);
+/* Sampled content checksum of every registered parameter (sum and absolute sum of ~2048 evenly spaced elements each), stream-ordered
+ * and NON-synchronising: 2 * ns2_model_param_count(m) floats land in host_out (pinned memory) once the stream passes this point.
+ * The parameters are read where ns2_model_set_param found them, so a caller that compares two checksums notices parameters
+ * rewritten through `.data` (ema_pytorch, NS2:1793-1801) without a device synchronisation -- the host-side Model does, every few forwards. */
+int ns2_model_param_count(const ns2_model* m);
+int ns2_model_param_checksum(ns2_model* m, float* host_out, int capacity, void* stream);
 /* optional intermediate taps for parity tests (fp32 copies made during forward / prepare_cond): "t", "c",
  * "wavenet.init", "wavenet.stack<s>", "wavenet.out", "layer<i>.attn", "layer<i>"; dst = null unregisters */
 int ns2_model_debug_tap(ns2_model* m, const char* name, float* dst, int64_t dst_elems);

@@ -20,22 +20,25 @@ def tensors_fingerprint(tensors):
 
 
 class PackedCache:
-    def __init__(self):
+    FINGERPRINT_EVERY = 64     # default: content check (a device reduction + a host read) every this many hits of the cheap signature
+
+    def __init__(self, fingerprint_every=None):
+        """fingerprint_every=1: check the CONTENT on every call -- for modules that run once per utterance (Transformer, the two
+        encoders), where a host read per call costs nothing against a stale EMA copy (ema_pytorch writes through `.data`)."""
         self.value, self.sig, self._fp, self._hits = None, None, None, 0
+        self.every = fingerprint_every or self.FINGERPRINT_EVERY
 
     def __deepcopy__(self, memo):
-        return PackedCache()
+        return type(self)(getattr(self, "every", None))
 
     def __getstate__(self):
-        return {}
+        return {"every": getattr(self, "every", None)}
 
     def __setstate__(self, state):
-        self.__init__()
+        self.__init__(state.get("every"))
 
     def clear(self):
         self.value, self.sig, self._fp, self._hits = None, None, None, 0
-
-    FINGERPRINT_EVERY = 64     # content check (a device reduction + a host read) every this many hits of the cheap signature
 
     def get(self, tensors, build, extra=()):
         """`build()` is re-run when any of `tensors` moved, was resized or was written (version counter) -- checked on every call,
@@ -45,7 +48,7 @@ class PackedCache:
         cheap = (tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors), tuple(extra))
         if self.value is not None and self.sig == cheap:
             self._hits = getattr(self, "_hits", 0) + 1
-            if self._hits < self.FINGERPRINT_EVERY or torch.cuda.is_current_stream_capturing():
+            if self._hits < getattr(self, "every", self.FINGERPRINT_EVERY) or torch.cuda.is_current_stream_capturing():
                 return self.value
             if tensors_fingerprint(tensors) == self._fp:
                 self._hits = 0

@@ -93,6 +93,8 @@ SIGNATURES = {
     "ns2_model_time_table_workspace_bytes": (L, [P, I]),
     "ns2_model_time_table": (I, [P, P, I, I, P, P, L, P]),
     "ns2_model_forward_row": (I, [P, P, P, P, I, P, I, I, P, L, P]),
+    "ns2_model_param_count": (I, [P]),
+    "ns2_model_param_checksum": (I, [P, P, I, P]),
     "ns2_model_debug_tap": (I, [P, c_char_p, P, L]),
     "ns2_model_profile_begin": (I, [P, ctypes.c_uint]),
     "ns2_model_profile_end": (I, [P, POINTER(ctypes.c_double), POINTER(c_int64)]),

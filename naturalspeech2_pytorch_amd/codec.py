@@ -107,6 +107,14 @@ class EncodecWrapperHIP(nn.Module):
     def num_quantizers(self):
         return self.rvq.codebooks.shape[0]
 
+    def refresh_weights(self):
+        """run-boundary content check of everything this wrapper packed (SEANet stacks, codebook norms): an EMA copy of the whole
+        `NaturalSpeech2` (NS2:1793) rewrites these through `.data`"""
+        for m in (self.encoder, self.decoder):
+            if hasattr(m, "refresh_weights"):
+                m.refresh_weights()
+        self.rvq._norm.refresh([self.rvq.codebooks])
+
     @torch.no_grad()
     def forward(self, x, return_encoded=True, curtail_from_left=False, **kwargs):
         """x: raw audio [b, t] (needs `encoder`) or latents [b, n, 128] -> (emb [b,n,128], codes [b,n,Q], None)."""

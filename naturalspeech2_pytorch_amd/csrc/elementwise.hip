@@ -347,6 +347,30 @@ hipError_t launch_mean_rows(const float* in, int B, int n, int d, float* out, hi
   return hipGetLastError();
 }
 
+// Sampled content checksum of a list of parameter tensors (one workgroup per tensor: the sum and the absolute sum of ~2048 evenly
+// spaced elements, reduced in a fixed order).  What the host-side Model compares, one call later and without synchronising, to notice
+// parameters rewritten through `.data` (an EMA update touches every element) between two version-counter checks.
+__global__ __launch_bounds__(256) void param_sample_kernel(const float* const* ptrs, const long* numels, float* out) {
+  __shared__ float r0[256], r1[256];
+  const float* p = ptrs[blockIdx.x];
+  const long n = numels[blockIdx.x];
+  const long stride = n > 2048 ? n / 2048 : 1;
+  float s = 0.f, a = 0.f;
+  for (long i = (long)threadIdx.x * stride; i < n; i += 256 * stride) { const float v = p[i]; s += v; a += fabsf(v); }
+  r0[threadIdx.x] = s; r1[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) { r0[threadIdx.x] += r0[threadIdx.x + w]; r1[threadIdx.x] += r1[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = r0[0]; out[2 * blockIdx.x + 1] = r1[0]; }
+}
+hipError_t launch_param_sample(const float* const* ptrs, const long* numels, int n, float* out, hipStream_t s) {
+  if (n <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(param_sample_kernel, dim3(n), dim3(256), 0, s, ptrs, numels, out);
+  return hipGetLastError();
+}
+
 // out[b, j] = row[j] + add[b, j]: the step's conditioning of a CONDITIONED model from the hoisted time table row and the
 // per-utterance prompt part (ns2_model_forward_row)
 __global__ void add_row_kernel(const float* row, const float* add, float* out, long J, long n_total) {

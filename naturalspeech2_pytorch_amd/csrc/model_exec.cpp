@@ -81,6 +81,8 @@ struct ns2_model {
   struct RLayer { PackedW q, kv, out, ffin, ffout; float* b_ffin; const float* b_ffout; };
   std::vector<RLayer> rlayers;
   const float* g_resampler;
+  // sampled content checksum of the registered parameters (ns2_model_param_checksum)
+  const float** d_param_ptrs = nullptr; long* d_param_numels = nullptr; float* d_param_sums = nullptr; int n_params = 0;
   // debug taps
   std::map<std::string, std::pair<float*, int64_t>> taps;
   // live kernel timing (bench.py roofline): HIP events around the launches of the selected kernel categories
@@ -106,8 +108,14 @@ struct PackCtx { std::vector<void*>* owned; bool il; int fmt; };   // il: interl
 // blocks (16 % of the FLOPs), which multiply the half parts of the same FMT_H8 operands as one product while the block's
 // res_conv keeps the correction terms (gemm2.hip, P1).  tools/precision_study.py: these are the two sites whose rounding
 // error reaches the output least (4.1e-5 -> 9.4e-5 for both at d128; every other site costs 1.6e-4 ... 3.5e-4).
-static inline int op_precision(int model_precision) { return model_precision == 5 ? 4 : model_precision; }
-static inline bool hybrid_plan(int model_precision) { return model_precision == 5; }
+// Model precision 6 ("hybrid_ff") extends the plan to the whole feed-forward branch: FF-in (+ GEGLU) and FF-out run as one IEEE-half
+// product as well -- the adaptive RMSNorm in front of the branch writes dense half planes, the conv writes dense half planes for
+// FF-out -- so the branch moves 2 bytes per operand element instead of 4 and spends 1 MFMA unit per FLOP instead of 2.  Every other
+// site (q / k / v, the attention out-projection, the Wavenet's 1x1 convs, to_pred: the sites whose rounding reaches the output most)
+// keeps the correction terms.  Error measured on the MI355X: tests/test_parity_r2_gpu.py sweeps, profiles/r04_parity.json.
+static inline int op_precision(int model_precision) { return (model_precision == 5 || model_precision == 6) ? 4 : model_precision; }
+static inline bool hybrid_plan(int model_precision) { return model_precision == 5 || model_precision == 6; }
+static inline bool ff_half_plan(int model_precision) { return model_precision == 6; }
 // The step-invariant conditioning (ns2_model_prepare_cond: perceiver resampler, cond_to_model_dim, per-layer cross-attention
 // K / V) runs once per sampling run on a few rows, and every frame of every step consumes its 32 resampled tokens: their
 // rounding is a systematic error of the whole run (measured on the conditioned d512/L12 model: tokens 2.1e-4 -> output
@@ -288,7 +296,7 @@ extern "C" int ns2_model_create(const ns2_model_config* cfg, ns2_model** out) {
   if (!cfg || !out) { set_error("null argument"); return NS2_ERR_ARG; }
   if (cfg->dim_head != 64) { set_error("dim_head must be 64 (attention kernel head dim), got %d", cfg->dim_head); return NS2_ERR_ARG; }
   if (cfg->dim % 32) { set_error("dim must be a multiple of 32, got %d", cfg->dim); return NS2_ERR_ARG; }
-  if (cfg->precision < 1 || cfg->precision > 5) { set_error("precision must be 1 (bf16), 2 (fp16), 3 (bf16 x3), 4 (fp16 + fp8 correction terms) or 5 (4, with the FF causal conv as one fp16 product)"); return NS2_ERR_ARG; }
+  if (cfg->precision < 1 || cfg->precision > 6) { set_error("precision must be 1 (bf16), 2 (fp16), 3 (bf16 x3), 4 (fp16 + fp8 correction terms), 5 (4, with the FF causal conv and the Wavenet's dilated convs as one fp16 product) or 6 (5, with the whole feed-forward branch as fp16 products)"); return NS2_ERR_ARG; }
   if (cfg->wavenet_layers < 1 || cfg->wavenet_layers > 16 || cfg->wavenet_stacks < 1) { set_error("bad wavenet shape"); return NS2_ERR_ARG; }
   ns2_model* m = new ns2_model();
   m->cfg = *cfg;
@@ -334,6 +342,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
   char key[256];
   const PackCtx pc = pack_ctx_for(&m->owned, op_precision(m->cfg.precision));
   const PackCtx pc_conv = hybrid_plan(m->cfg.precision) ? pack_ctx_for(&m->owned, 2) : pc;
+  const PackCtx pc_ff = ff_half_plan(m->cfg.precision) ? pack_ctx_for(&m->owned, 2) : pc;       // FF-in / FF-out weights
   const PackCtx pc_cond = pack_ctx_for(&m->owned, cond_precision(op_precision(m->cfg.precision)));   // weights of prepare_cond
   const bool il = pc.il;
 
@@ -428,10 +437,10 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
       GETP(cw, p + ".5.2.1.weight"); GETP(cb, p + ".5.2.1.bias");
       GETP(w2, p + ".5.3.weight"); GETP(b2, p + ".5.3.bias");
       if (w1->dims[0] != 2 * f) { set_error("FF inner dim mismatch: expected %d got %lld", 2 * f, (long long)w1->dims[0]); return NS2_ERR_STATE; }
-      NSCHK(pack_geglu(pc, &ly.ffin, w1->p, f, dim, s));
+      NSCHK(pack_geglu(pc_ff, &ly.ffin, w1->p, f, dim, s));
       NSCHK(pack_geglu_bias(&m->owned, &ly.b_ffin, b1->p, f, ly.ffin.rows_p));
       NSCHK(pack_linear(pc_conv, &ly.conv, cw->p, f, f, 3, s)); ly.b_conv = cb->p;
-      NSCHK(pack_linear(pc, &ly.ffout, w2->p, dim, f, 1, s)); ly.b_ffout = b2->p; }
+      NSCHK(pack_linear(pc_ff, &ly.ffout, w2->p, dim, f, 1, s)); ly.b_ffout = b2->p; }
   }
   { GETP(g, "transformer.to_pred.0.gamma"); GETP(w, "transformer.to_pred.1.weight");
     m->g_pred = g->p; NSCHK(pack_linear(pc, &m->w_pred, w->p, dim, dim, 1, s)); }
@@ -468,8 +477,35 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
       NSCHK(pack_linear(pc_cond, &r.ffout, w2->p, dim, f, 1, s)); r.b_ffout = b2->p;
     }
   }
+  {   // device-side list of the registered parameter tensors (read in place: they alias the module's parameters)
+    std::vector<const float*> ptrs; std::vector<long> numels;
+    for (auto& kv : m->params) {
+      long n = 1;
+      for (int64_t d : kv.second.dims) n *= (long)d;
+      if (n > 0) { ptrs.push_back(kv.second.p); numels.push_back(n); }
+    }
+    m->n_params = (int)ptrs.size();
+    NSCHK(dev_alloc(&m->owned, (void**)&m->d_param_ptrs, ptrs.size() * sizeof(float*)));
+    NSCHK(dev_alloc(&m->owned, (void**)&m->d_param_numels, numels.size() * sizeof(long)));
+    NSCHK(dev_alloc(&m->owned, (void**)&m->d_param_sums, 2 * ptrs.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(m->d_param_ptrs, ptrs.data(), ptrs.size() * sizeof(float*), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->d_param_numels, numels.data(), numels.size() * sizeof(long), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipStreamSynchronize(s));
   m->finalized = true;
+  return NS2_OK;
+}
+
+// Sampled content checksum of every registered parameter, stream-ordered and non-synchronising: 2 * ns2_model_param_count(m) floats
+// are copied into host_out (pinned memory for a truly asynchronous copy; valid once the stream has passed this point).  The
+// parameters are read where ns2_model_set_param found them, so writes through `.data` show up.
+extern "C" int ns2_model_param_count(const ns2_model* m) { return (m && m->finalized) ? m->n_params : 0; }
+extern "C" int ns2_model_param_checksum(ns2_model* m, float* host_out, int capacity, void* stream) {
+  if (!m || !m->finalized || !host_out) { set_error("ns2_model_param_checksum: model not finalized / null output"); return NS2_ERR_STATE; }
+  if (capacity < 2 * m->n_params) { set_error("ns2_model_param_checksum: output holds fewer than 2 * ns2_model_param_count floats"); return NS2_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(launch_param_sample(m->d_param_ptrs, m->d_param_numels, m->n_params, m->d_param_sums, s));
+  HIPCHK(hipMemcpyAsync(host_out, m->d_param_sums, 2 * (size_t)m->n_params * sizeof(float), hipMemcpyDeviceToHost, s));
   return NS2_OK;
 }
 
@@ -809,6 +845,9 @@ static int forward_impl(ns2_model* m, const float* x, const float* times, const 
   const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, L = m->L, S = m->S, H = m->cfg.heads, prec = op_precision(m->cfg.precision);
   const int M = B * N, Jtot = m->Jtot, Lm = m->Lm;
   const int conv_prec = hybrid_plan(m->cfg.precision) ? 2 : prec;
+  const int ff_prec = ff_half_plan(m->cfg.precision) ? 2 : prec;
+  Planes xn_ff = w.xn, ffc_ff = w.ffc;                 // precision 6: dense IEEE-half views of the same memory
+  if (ff_half_plan(m->cfg.precision)) { xn_ff.lo = nullptr; xn_ff.fmt = FMT_F16; ffc_ff.lo = nullptr; ffc_ff.fmt = FMT_F16; }
   const int xprec = fmts_for(prec).xatt_prec;
   char name[64];
 
@@ -869,12 +908,12 @@ static int forward_impl(ns2_model* m, const float* x, const float* times, const 
       PROF(PC_ATTENTION, attention_call(w.xq.hi, w.xq.lo, a, 0, cs.ck[l].hi, cs.ck[l].lo, a, 0, cs.cvt[l], cs.Lmp, w.o, a, B, H, N, Lm, xprec, s));
       PROF(PC_GEMM_F32, gemm_f32(ly.cout, w.o.hi, w.o.lo, a, M, 0, 1, 0, nullptr, w.xres, dim, w.xres, dim, prec, s));
     }
-    // feedforward: Linear -> GEGLU -> causal conv k3 -> Linear (NS2:1009-1025)
-    PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + (size_t)(m->nnorm - 1) * 2 * dim, cld, w.xn, dp, nullptr, 0, s));
-    PROF(PC_GEMM_GEGLU, gemm_geglu(ly.ffin, w.xn.hi, w.xn.lo, dp, M, ly.b_ffin, w.ffh_conv.hi, w.ffh_conv.lo, fp, prec, s, w.ffh_conv.fmt));
-    PROF(PC_GEMM_FFCONV, gemm_split(ly.conv, w.ffh_conv.hi, w.ffh_conv.lo, fp, M, 3, 1, N, ly.b_conv, w.ffc.hi, w.ffc.lo, fp,
-                                    conv_prec, s, -1, 0, w.ffc.fmt));
-    PROF(PC_GEMM_F32, gemm_f32(ly.ffout, w.ffc.hi, w.ffc.lo, fp, M, 0, 1, 0, ly.b_ffout, w.xres, dim, w.xres, dim, prec, s));
+    // feedforward: Linear -> GEGLU -> causal conv k3 -> Linear (NS2:1009-1025); precision 6: the whole branch on dense IEEE-half planes
+    PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + (size_t)(m->nnorm - 1) * 2 * dim, cld, xn_ff, dp, nullptr, 0, s));
+    PROF(PC_GEMM_GEGLU, gemm_geglu(ly.ffin, xn_ff.hi, xn_ff.lo, dp, M, ly.b_ffin, w.ffh_conv.hi, w.ffh_conv.lo, fp, ff_prec, s, w.ffh_conv.fmt));
+    PROF(PC_GEMM_FFCONV, gemm_split(ly.conv, w.ffh_conv.hi, w.ffh_conv.lo, fp, M, 3, 1, N, ly.b_conv, ffc_ff.hi, ffc_ff.lo, fp,
+                                    conv_prec, s, -1, 0, ffc_ff.fmt));
+    PROF(PC_GEMM_F32, gemm_f32(ly.ffout, ffc_ff.hi, ffc_ff.lo, fp, M, 0, 1, 0, ly.b_ffout, w.xres, dim, w.xres, dim, ff_prec, s));
     snprintf(name, sizeof name, "layer%d", l);
     NSCHK(tap_f32(m, name, w.xres, (int64_t)M * dim, s));
   }

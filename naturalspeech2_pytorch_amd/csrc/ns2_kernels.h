@@ -123,6 +123,7 @@ hipError_t launch_time_embed(const float* times, const float* freqs, const float
 size_t skinny_linear_workspace_bytes(int B, int K, int J, int plan_B = 0);
 hipError_t launch_skinny_linear(const float* in, int ld_in, const float* wt, const float* bias, float* out, int ld_out,
                                 int B, int K, int J, int act, float* ws, size_t ws_bytes, hipStream_t s, int plan_B = 0);
+hipError_t launch_param_sample(const float* const* ptrs, const long* numels, int n, float* out, hipStream_t s);
 hipError_t launch_add_row(const float* row, const float* add, float* out, int B, long J, hipStream_t s);
 
 // batched fp32 [R, C] -> [C, R]

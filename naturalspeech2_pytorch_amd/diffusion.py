@@ -223,11 +223,20 @@ class NaturalSpeech2(nn.Module):
         assert prompt is not None, "conditional model: pass `prompt` (raw audio or codec latents) or `prompt_enc`"
         return self.prompt_enc(self.process_prompt(prompt))                            # NS2:1474-1475 / 1542-1543 (HIP encoder)
 
+    def refresh_weights(self):
+        """run boundary: every HIP module re-checks its packed weights against the parameters' CONTENT (writes through `.data` --
+        what ema_pytorch does to the copy of this whole object it samples from, NS2:1793-1801 -- bump no version counter)"""
+        for name in ("model", "prompt_enc", "phoneme_enc", "codec"):
+            mod = getattr(self, name, None)
+            if mod is not None and hasattr(mod, "refresh_weights"):
+                mod.refresh_weights()
+
     @torch.no_grad()
     def sample(self, *, length, prompt=None, batch_size=1, cond_scale=1., text=None, text_lens=None,
                cond=None, prompt_enc=None, noise=None, use_graph=False):
         """NS2:1457-1501.  Extra keywords (not in the reference): `cond` / `prompt_enc` = pre-computed conditioning (module
         docstring), `noise` = injected initial latents (parity tests), `use_graph` = HIP-graph replay of the step."""
+        self.refresh_weights()
         p_enc = None
         if self.conditional:
             assert (prompt is not None or prompt_enc is not None) and (text is not None or cond is not None)   # NS2:1473

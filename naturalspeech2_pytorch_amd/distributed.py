@@ -100,6 +100,7 @@ class GradientAllReducer:
         assert self.params, "no parameters to reduce"
         assert all(p.dtype == torch.float32 for p in self.params), "gradients are reduced in fp32"
         self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        self._collective = dist.is_initialized()                 # a world of 1 still issues its (degenerate) all-reduces: same code path
         order = list(reversed(self.params))                      # reverse registration order: ready roughly back to front
         self.flat = torch.zeros(sum(p.numel() for p in order), dtype=torch.float32, device=order[0].device)
         self._view, self.buckets, self._range = {}, [], []
@@ -161,7 +162,7 @@ class GradientAllReducer:
     def _issue_ready(self):
         while self._launched < len(self.buckets) and self._pending[self._launched] == 0:
             i = self._launched
-            if self.world > 1:
+            if self._collective:
                 lo, hi = self._range[i]
                 self._work[i] = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._launched += 1

@@ -16,10 +16,11 @@ from .transformer import Transformer
 
 
 class _ConvStack(PackedCache):
-    """packed k-tap convs, re-packed when the parameters change (by content); dropped by deepcopy / pickling."""
+    """packed k-tap convs, re-packed when the parameters change (by content, checked on every call: these encoders run once per
+    utterance); dropped by deepcopy / pickling."""
 
-    def __deepcopy__(self, memo):
-        return _ConvStack()
+    def __init__(self, fingerprint_every=1):
+        super().__init__(fingerprint_every)
 
     def packed_for(self, convs, prec):
         ts = [t for c in convs for t in (c.weight, c.bias)]
@@ -48,10 +49,15 @@ class SpeechPromptEncoder(nn.Module):
         """Under autograd (the reference trains prompt_enc jointly, NS2:1542-1543) the differentiable composite runs; inference
         runs in the HIP kernels."""
         assert x.shape[-1] == self.dim
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
             from .autograd_path import speech_prompt_encoder_autograd
             return speech_prompt_encoder_autograd(self, x)
         return self._forward_hip(x)
+
+    def refresh_weights(self):
+        convs = [m for m in self.conv if isinstance(m, nn.Conv1d)]
+        self._stack.refresh([t for c in convs for t in (c.weight, c.bias)])
+        self.transformer.refresh_weights()
 
     @torch.no_grad()
     def _forward_hip(self, x):
@@ -89,10 +95,14 @@ class PhonemeEncoder(nn.Module):
     def forward(self, x, mask=None):
         if not torch.is_tensor(x):
             raise NotImplementedError("List[str] input needs the tokenizer / espeak front-end (out of scope); pass token ids")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
             from .autograd_path import phoneme_encoder_autograd
             return phoneme_encoder_autograd(self, x, mask)
         return self._forward_hip(x, mask)
+
+    def refresh_weights(self):
+        self._stack.refresh([self.conv[1].weight, self.conv[1].bias])
+        self.transformer.refresh_weights()
 
     @torch.no_grad()
     def _forward_hip(self, x, mask=None):

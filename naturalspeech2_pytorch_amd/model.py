@@ -110,6 +110,11 @@ class _NativeState:
         self.sat_seen = 0                # counter total already accounted for
         self.calls_since_peek = 0
         self.peek_now = True             # read the counters right behind the next forward (first forward of a run)
+        # sampled content checksum (ns2_model_param_checksum): what the packed weights were made from, and the read in flight
+        self.chk_ref = None              # torch.Tensor (CPU) taken at pack time
+        self.chk_pinned = None
+        self.chk_event = None
+        self.calls_since_chk = 0
 
     def __deepcopy__(self, memo):
         return _NativeState()
@@ -131,6 +136,7 @@ class _NativeState:
         self.fingerprint = None
         self.cond_cache = {}
         self.sat_event = None
+        self.chk_ref = self.chk_event = None
 
     def __del__(self):
         self.release()
@@ -139,7 +145,8 @@ class _NativeState:
 _CFG_KEYS = ("dim", "depth", "dim_head", "heads", "ff_mult", "wavenet_layers", "wavenet_stacks", "dim_cond_mult",
              "condition_on_prompt", "dim_prompt", "num_latents_m", "resampler_depth")
 _PRECISIONS = {"exact": 3, "mixed": 4, "half": 2, "fast": 1}          # op-level arithmetic modes (include/ns2hip.h)
-_MODEL_PRECISIONS = dict(_PRECISIONS, hybrid=5)                        # + the per-site plan of the denoiser ("mixed", FF conv "half")
+_MODEL_PRECISIONS = dict(_PRECISIONS, hybrid=5, hybrid_ff=6)           # + the per-site plans of the denoiser: "mixed" with the FF causal conv
+                                                                       # and the Wavenet's dilated convs "half" (5); the whole FF branch "half" (6)
 
 
 # ------------------------------------------------------------------------------------------ HIP execution mixin
@@ -158,7 +165,9 @@ class HipDenoiserMixin:
 
     # ---- cache invalidation: version counters do not see `.data` writes (ema_pytorch updates its shadow model that way)
     REFRESH_IDLE_S = 0.25      # a pause this long between two HIP forwards marks a new sampling run
-    REFRESH_EVERY = 256        # ... and the content check runs at least this often inside a run
+    REFRESH_EVERY = 256        # ... and the full content check runs at least this often inside a run
+    CHECKSUM_EVERY = 8         # forwards between two ASYNCHRONOUS sampled checksums of the parameters (no synchronisation): bounds the
+                               # staleness after a `.data` write to CHECKSUM_EVERY + 1 forwards whatever the host's timing
     SAT_PEEK_EVERY = 16        # forwards between two asynchronous reads of the range-guard counters
 
     def invalidate(self):
@@ -175,6 +184,10 @@ class HipDenoiserMixin:
         if fp != ns.fingerprint:
             ns.release()
             return True
+        if self._range_guarded() and ns.sat_event is None:
+            # run boundary: what the per-device counters hold by now (another model, a codec run) is not this run's
+            from . import ops
+            ns.sat_seen = ops.saturation_count(reset=False, device=next(self.parameters()).device)
         return False
 
     def _guards(self):
@@ -200,10 +213,35 @@ class HipDenoiserMixin:
                 ns.peek_now = True
         ns.autograd_seen, ns.mode_flag = False, self.training     # (last_call is stamped when the forward has been enqueued)
         ns.calls_since_refresh += 1
+        self._poll_checksum()
         self.check_saturation(sync=False)
 
+    def _poll_checksum(self):
+        """deterministic half of the staleness guard: every CHECKSUM_EVERY forwards a sampled checksum of the parameters is computed
+        on the step's stream and copied to pinned memory (no synchronisation); a later call compares it with the one taken when the
+        weights were packed and drops the pack on a difference.  Independent of wall-clock time and of the caller."""
+        ns = self._native
+        if ns.handle is None or ns.chk_ref is None:
+            return
+        ev = ns.chk_event
+        if ev is not None and ev.query():
+            ns.chk_event = None
+            if not torch.equal(ns.chk_pinned.view(torch.int32), ns.chk_ref.view(torch.int32)):     # bitwise: NaNs compare equal to themselves
+                ns.release()                                      # re-packed by this call's _ensure_native()
+                ns.peek_now = True
+                return
+        ns.calls_since_chk += 1
+        if ns.chk_event is None and ns.calls_since_chk >= self.CHECKSUM_EVERY:
+            dev = next(self.parameters()).device
+            with torch.cuda.device(dev):
+                check(_lib.load().ns2_model_param_checksum(ns.handle, ns.chk_pinned.data_ptr(), ns.chk_pinned.numel(),
+                                                           torch.cuda.current_stream().cuda_stream), "ns2_model_param_checksum")
+                ns.chk_event = torch.cuda.Event()
+                ns.chk_event.record()
+            ns.calls_since_chk = 0
+
     def _range_guarded(self):
-        return self.precision in ("half", "mixed", "hybrid")
+        return self.precision in ("half", "mixed", "hybrid", "hybrid_ff")
 
     def check_saturation(self, sync=False):
         """look at the last asynchronous counter read (sync=True: take one now and wait for it); raises Ns2Error on a new count"""
@@ -290,6 +328,12 @@ class HipDenoiserMixin:
         ns.fingerprint = tensors_fingerprint(list(self.parameters()))
         ns.cond_cache = {}
         ns.calls_since_refresh = 0
+        with torch.cuda.device(dev):                                  # the sampled checksum of what was just packed
+            n = lib.ns2_model_param_count(h)
+            ns.chk_pinned = torch.zeros(2 * n, dtype=torch.float32).pin_memory()
+            check(lib.ns2_model_param_checksum(h, ns.chk_pinned.data_ptr(), 2 * n, torch.cuda.current_stream().cuda_stream), "ns2_model_param_checksum")
+            torch.cuda.current_stream().synchronize()
+        ns.chk_ref, ns.chk_event, ns.calls_since_chk = ns.chk_pinned.clone(), None, 0
         if self._range_guarded():          # what the device counters hold already (other models, earlier runs) is not ours
             from . import ops
             ns.sat_seen = ops.saturation_count(reset=False, device=dev)
@@ -345,7 +389,7 @@ class HipDenoiserMixin:
         return table
 
     # ---- forward (NS2:929-1000)
-    def forward(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, cond_row=None):
+    def forward(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, *, cond_row=None):
         """`cond_row` (not in the reference): a row of `time_table()` standing in for `times` (inference only)"""
         p = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(q.requires_grad for q in self.parameters()))

@@ -95,6 +95,11 @@ class _SEANetHIP(nn.Module):
     def _packed(self):
         return self._cache.get(self.net.parameters(), self._build, extra=(self.precision,))
 
+    def refresh_weights(self):
+        """re-pack iff the parameter CONTENTS changed since they were packed (`.data` writes bump no version counter); called at
+        run boundaries by NaturalSpeech2.sample / .forward and EncodecWrapperHIP.refresh_weights"""
+        self._cache.refresh(self.net.parameters())
+
     def _pack_conv(self, m):
         """EncodecConv1d (HFENC:81-181) -> (PackedWeight, bias, taps, dilation, stride, row prefix)"""
         prec = _PRECISIONS[self.precision]
@@ -254,6 +259,7 @@ class _SEANetHIP(nn.Module):
         (ns2_lstm2), one launch per layer, one launch per frame.  The first two need all their workgroups resident at once; the
         launchers check that (NS2_UNAVAILABLE / an internal fallback), and a launch that still had to give up -- a device shared
         with other work -- is reported by ns2_lstm_abort_count: its output is discarded and the next way is taken."""
+        import contextlib
         import ctypes
         import warnings
         prec = _PRECISIONS[self.precision]
@@ -309,7 +315,8 @@ class _SEANetHIP(nn.Module):
             if out is None:
                 continue
             n = ctypes.c_int64(0)
-            check(lib.ns2_lstm_abort_count(1, ctypes.byref(n)), "ns2_lstm_abort_count")   # one synchronisation per codec run
+            with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):   # the counter lives on the device the recurrence ran on
+                check(lib.ns2_lstm_abort_count(1, ctypes.byref(n)), "ns2_lstm_abort_count")   # one synchronisation per codec run
             if n.value == 0:
                 return _Act(out, B, T, H, 0)
             warnings.warn(f"LSTM recurrence ({name}) gave up waiting for a frame: not all of its workgroups were resident (CU masking / "

@@ -23,7 +23,11 @@ class Transformer(nn.Module):
             nn.ModuleList([_RMSNorm(dim), _Attention(dim, dim_head, heads), _RMSNorm(dim), _feedforward(dim, ff_mult, False)])
             for _ in range(depth)])
         self.norm = _RMSNorm(dim) if final_norm else nn.Identity()
-        self._cache = PackedCache()
+        self._cache = PackedCache(fingerprint_every=1)         # once per utterance: check the content every call (EMA copies)
+
+    def refresh_weights(self):
+        """re-pack iff the parameter CONTENTS changed since they were packed (run boundaries: NaturalSpeech2.sample / .forward)"""
+        self._cache.refresh(self.parameters())
 
     def _pack(self):
         return self._cache.get(self.parameters(), self._build_packed, extra=(self.precision,))
@@ -45,7 +49,10 @@ class Transformer(nn.Module):
         return packed
 
     def _needs_autograd(self, x):
-        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        """the differentiable composite only when a gradient can be wanted: grad mode on AND (the input carries one, or the module
+        is in training mode with trainable parameters).  An `eval()` module called without `torch.no_grad()` keeps the HIP
+        kernels and its `precision` (a freshly built module has requires_grad parameters)."""
+        return torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters())))
 
     def forward(self, x, mask=None):
         """x [b, n, dim]; mask: optional bool [b, n] key-padding mask (True = attend).  Under autograd (training: the reference

@@ -339,3 +339,45 @@ def test_optimizer_steps_through_the_hip_path_reduce_the_loss():
     assert losses[-1] < 0.9 * losses[0], losses
     out = d.sample(length=128, batch_size=2)
     assert torch.isfinite(out).all()
+
+
+def test_gradient_allreducer_over_rccl_world1_with_hip_backward():
+    """the data-parallel training step over an RCCL ("nccl") process group with the HIP backward underneath: world 1 on a one-GPU box,
+    so the all-reduces degenerate, but hooks, flat-buffer gradient views, ordered bucket launches on RCCL, accumulation and finish()
+    are the code path of the 8-GPU run (NS2:1723-1726, 1820, 1877-1886)"""
+    import torch.distributed as dist
+    from naturalspeech2_pytorch_amd import distributed as D
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29900 + os.getpid() % 90)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        m = Model(dim=64, depth=2).to(DEV)
+        d = NaturalSpeech2(m, codec=None, target_sample_hz=24000).to(DEV)
+        audio = make_input("audio", (4, 96, 64), seed=81).to(DEV)
+        times = torch.tensor([0.1, 0.3, 0.6, 0.9], device=DEV)
+        noise = make_input("noise", (4, 96, 64), seed=82).to(DEV)
+        d.zero_grad()
+        d(audio, times=times, noise=noise).backward()
+        ref = [p.grad.clone() for p in d.parameters()]
+        red = D.GradientAllReducer(d.parameters(), bucket_bytes=1 << 16)
+        assert len(red.buckets) > 3 and red._collective
+        red.zero_grad()
+        d(audio, times=times, noise=noise).backward()
+        red.finish()
+        assert all(torch.equal(p.grad, r) for p, r in zip(d.parameters(), ref))           # same kernels, fixed-slot reductions: bit-identical
+        # two micro-batches, the first under accumulate(): the mean of the halves' losses
+        red.zero_grad()
+        with red.accumulate():
+            (d(audio[:2], times=times[:2], noise=noise[:2]) / 2).backward()
+        (d(audio[2:], times=times[2:], noise=noise[2:]) / 2).backward()
+        red.finish()
+        d2 = [p.grad.clone() for p in d.parameters()]
+        red.remove()
+        for p in d.parameters():
+            p.grad = None
+        (d(audio[:2], times=times[:2], noise=noise[:2]) / 2).backward()
+        (d(audio[2:], times=times[2:], noise=noise[2:]) / 2).backward()
+        assert max(rel(a, p.grad) for a, p in zip(d2, d.parameters())) < 1e-6
+    finally:
+        dist.destroy_process_group()

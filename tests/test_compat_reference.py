@@ -61,7 +61,7 @@ def test_reference_naturalspeech2_trains_and_samples_through_the_subclass():
     noise = make_input("noise", (fix["batch"], fix["n"], kw["dim"]), seed=fix["input_seed"])
     seen = []
 
-    def fake_hip(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, out=None):
+    def fake_hip(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, out=None, cond_row=None):
         seen.append((tuple(x.shape), tuple(times.shape), cond_drop_prob))
         return O.model_forward(sd, x, times)
 

@@ -118,8 +118,10 @@ def test_reference_signatures_are_kept():
     assert all(smp[k].kind is inspect.Parameter.KEYWORD_ONLY for k in list(smp)[1:])
     dd = list(inspect.signature(NaturalSpeech2.ddim_sample).parameters)
     assert dd[:6] == ["self", "shape", "prompt", "time_difference", "cond_scale", "cond"]
-    mf = list(inspect.signature(Model.forward).parameters)
-    assert mf == ["self", "x", "times", "prompt", "prompt_mask", "cond", "cond_drop_prob"]
+    mfp = inspect.signature(Model.forward).parameters
+    mf = list(mfp)
+    assert mf[:7] == ["self", "x", "times", "prompt", "prompt_mask", "cond", "cond_drop_prob"]          # NS2:929-937
+    assert all(mfp[k].kind is inspect.Parameter.KEYWORD_ONLY and mfp[k].default is None for k in mf[7:])   # extras: keyword-only, optional
 
 
 def test_conditional_wrapper_accepts_reference_kwargs_and_names_the_missing_module():
@@ -305,7 +307,7 @@ def test_encoder_composites_equal_the_reference():
     x = torch.randn(2, 20, 32, requires_grad=True)
     assert torch.allclose(r(x), o(x), atol=1e-6)
     r = ns2.PhonemeEncoder(num_tokens=50, dim=32, dim_hidden=64, depth=2, conv_dropout=0.).eval()
-    o = PhonemeEncoder(num_tokens=50, dim=32, dim_hidden=64, depth=2, conv_dropout=0.).eval()
+    o = PhonemeEncoder(num_tokens=50, dim=32, dim_hidden=64, depth=2, conv_dropout=0.)   # training mode (no dropout): the composite; eval() is the HIP path
     o.load_state_dict(r.state_dict())
     ids = torch.randint(0, 50, (2, 17)); ids[1, 12:] = -1
     assert torch.allclose(r(ids, mask=ids >= 0), o(ids, mask=ids >= 0), atol=1e-5)

@@ -111,3 +111,70 @@ def test_trajectory_at_the_headline_architecture_100_steps():
         del m, d
         torch.cuda.empty_cache()
     record("trajectory_d512_L12_b2_n1024_100steps", {k: v for k, v in res.items() if k != "ref"})
+
+
+# ------------------------------------------------------------------------------------------------ staleness guards
+def test_async_checksum_bounds_staleness_without_wall_clock():
+    """parameters rewritten through `.data` (no version bump) inside a tight loop, with the wall-clock boundary disabled: the sampled
+    checksum taken every CHECKSUM_EVERY forwards on the stream (no synchronisation) makes the model re-pack within
+    CHECKSUM_EVERY + 2 forwards, deterministically"""
+    m, _ = _model(dict(dim=64, depth=1), 91)
+    m.REFRESH_IDLE_S, m.REFRESH_EVERY, m.CHECKSUM_EVERY = 1e9, 10 ** 9, 3
+    x = make_input("x", (2, 64, 64), seed=92).to(DEV)
+    t = torch.tensor([0.4, 0.4], device=DEV)
+    with torch.no_grad():
+        y0 = m(x, t).clone()
+        w = getattr(m.transformer.layers[0], "1").to_q.weight
+        v0 = w._version
+        w.data.mul_(1.5)
+        assert w._version == v0
+        outs = []
+        for _ in range(m.CHECKSUM_EVERY + 3):
+            outs.append(m(x, t).clone())
+            torch.cuda.synchronize()                       # (lets the pending read complete: the bound counts forwards, not time)
+        sd2 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ref = O.model_forward(sd2, x.cpu(), t.cpu())
+    assert torch.equal(outs[0], y0)                         # the first forwards still run on the old pack ...
+    assert rel(outs[-1], ref) < 1e-4 and not torch.equal(outs[-1], y0)     # ... and within the bound the new weights are in
+
+
+def test_data_writes_reach_transformer_encoder_and_codec_packs():
+    """ema_pytorch rewrites the shadow copy of the WHOLE NaturalSpeech2 through `.data` (NS2:1793): Transformer / SpeechPromptEncoder
+    check their packs by content on every call, the SEANet codec at the run boundary (`refresh_weights`, called by sample())"""
+    from naturalspeech2_pytorch_amd import SpeechPromptEncoder, Transformer
+    torch.manual_seed(0)
+    tr = Transformer(dim=64, depth=2).to(DEV).eval()
+    x = make_input("x", (2, 40, 64), seed=93).to(DEV)
+    with torch.no_grad():
+        a = tr(x).clone()
+        for _ in range(3):
+            tr(x)
+        tr.layers[0][1].to_q.weight.data.mul_(2.0)
+        b = tr(x)
+        assert not torch.equal(a, b)
+        tr.train()
+        ref = tr(x.clone().requires_grad_(True)).detach()           # the composite on the current parameters
+    assert rel(b, ref) < 1e-4
+    enc = SpeechPromptEncoder(dim_codebook=32, dims=(64, 64), depth=1, dropout=0.).to(DEV).eval()
+    xe = make_input("xe", (2, 24, 32), seed=94).to(DEV)
+    with torch.no_grad():
+        a = enc(xe).clone()
+        enc.conv[1].weight.data.mul_(1.5)
+        b = enc(xe)
+    assert not torch.equal(a, b)
+    tf = pytest.importorskip("transformers")
+    from naturalspeech2_pytorch_amd import EncodecWrapperHIP
+    torch.manual_seed(0)
+    hf = tf.EncodecModel(tf.EncodecConfig()).eval().to(DEV)
+    with torch.no_grad():
+        for layer in hf.quantizer.layers:
+            layer.codebook.embed.normal_()
+        codec = EncodecWrapperHIP.from_hf(hf, hip_seanet=True).to(DEV).eval()
+        wav = make_input("wav", (1, 3200), seed=95).to(DEV)
+        e0 = codec.encoder(wav[:, None]).clone()                     # latents (the codes may survive a small change)
+        p = max(codec.encoder.net.parameters(), key=lambda t: t.numel())
+        p.data.mul_(1.25)
+        codec.refresh_weights()                                      # the run boundary (NaturalSpeech2.sample / .refresh_weights call it)
+        e1 = codec.encoder(wav[:, None])
+        ref = hf.encoder(wav[:, None])                               # HF's own module on the rewritten parameters
+    assert not torch.equal(e0, e1) and rel(e1, ref) < 1e-4

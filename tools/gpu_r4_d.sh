@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-.}"
+O=gpurun_out/r4d; mkdir -p $O
+timeout 900 python -m pytest tests/test_round4_gpu.py -q -m gpu --tb=short -k "data_writes or checksum" > $O/t_round4.txt 2>&1; echo "round4 rc=$?" >> $O/summary.txt
+timeout 900 python -m pytest tests/test_backward_gpu.py -q -m gpu --tb=short -k "not d512_L12 and not d128_L6" > $O/t_backward.txt 2>&1; echo "backward rc=$?" >> $O/summary.txt
+timeout 900 python tools/bench_train.py --shapes d128,d512 --backends hip --iters 4 --out $O/train_step.json > $O/train_step.txt 2>&1
+cat $O/summary.txt; grep -h ms_per_step $O/train_step.txt | cut -c1-220; tail -3 $O/t_backward.txt
