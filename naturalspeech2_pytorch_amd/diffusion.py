@@ -129,20 +129,39 @@ class NaturalSpeech2(nn.Module):
 
     # ------------------------------------------------------------------ sampling (NS2:1379-1431)
     @torch.no_grad()
-    def ddim_sample(self, shape, prompt=None, time_difference=None, cond_scale=1., cond=None, noise=None, use_graph=False):
-        """`prompt` here is what the reference passes at NS2:1486-1491: the ENCODED prompt [b, n_p, dim_prompt]."""
+    def ddim_sample(self, shape, prompt=None, time_difference=None, cond_scale=1., cond=None, noise=None, use_graph=False,
+                    on_saturation="demote"):
+        """`prompt` here is what the reference passes at NS2:1486-1491: the ENCODED prompt [b, n_p, dim_prompt].
+
+        on_saturation (not in the reference): what to do when a checkpoint's activations leave the IEEE-half range in one of the
+        fast precisions (half / mixed / hybrid: conversions clamp at 65504 -- finite but wrong; the model counts them on the
+        device).  "demote" (default): the run is REPEATED from the same initial latents with `model.precision = "exact"` (bf16
+        planes keep the fp32 exponent range) and the model stays there -- a fast mode never returns clamped audio and never
+        needs a hand-picked precision per checkpoint; "raise": Ns2Error, as rounds 2-3 did."""
+        assert on_saturation in ("demote", "raise")
+        from ._lib import Ns2Error
         batch, device = shape[0], self.device
-        audio = torch.randn(shape, device=device) if noise is None else noise.to(device).float().clone()
-        if hasattr(self.model, "refresh_weights"):
-            self.model.refresh_weights()        # parameters rewritten through `.data` since the last pack (EMA) -> re-pack
-        if hasattr(self.model, "clear_cond_cache"):
-            self.model.clear_cond_cache()
-        audio = self._ddim_loop(audio, prompt, cond, cond_scale, use_graph)
-        if hasattr(self.model, "check_saturation") and audio.is_cuda:
-            # IEEE-half modes: activations beyond 65504 are clamped -- finite but wrong.  The model polls the device counters
-            # every few forwards on its own (any caller); the end of a run takes one synchronous look (Ns2Error on a new count)
-            self.model.check_saturation(sync=True)
-        return audio
+        start = torch.randn(shape, device=device) if noise is None else noise.to(device).float().clone()
+        for attempt in (0, 1):
+            if hasattr(self.model, "refresh_weights"):
+                self.model.refresh_weights()        # parameters rewritten through `.data` since the last pack (EMA) -> re-pack
+            if hasattr(self.model, "clear_cond_cache"):
+                self.model.clear_cond_cache()
+            try:
+                audio = self._ddim_loop(start.clone(), prompt, cond, cond_scale, use_graph)
+                if hasattr(self.model, "check_saturation") and audio.is_cuda:
+                    # the model polls the device counters every few forwards on its own (any caller); the end of a run takes one
+                    # synchronous look (Ns2Error on a new count)
+                    self.model.check_saturation(sync=True)
+                return audio
+            except Ns2Error as e:
+                guarded = getattr(self.model, "precision", "exact") in ("half", "mixed", "hybrid", "hybrid_ff")
+                if on_saturation == "raise" or attempt == 1 or not guarded or "IEEE-half range" not in str(e):
+                    raise
+                import warnings
+                warnings.warn(f"precision='{self.model.precision}': activations of this checkpoint leave the IEEE-half range; repeating "
+                              f"the sampling run with precision='exact' and keeping the model there ({e})")
+                self.model.precision = "exact"
 
     def _ddim_loop(self, audio, prompt, cond, cond_scale, use_graph):
         batch, device = audio.shape[0], audio.device

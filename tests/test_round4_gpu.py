@@ -178,3 +178,34 @@ def test_data_writes_reach_transformer_encoder_and_codec_packs():
         e1 = codec.encoder(wav[:, None])
         ref = hf.encoder(wav[:, None])                               # HF's own module on the rewritten parameters
     assert not torch.equal(e0, e1) and rel(e1, ref) < 1e-4
+
+
+def test_baseline_config1_waveform_is_pinned_numerically():
+    """README:33-70 / BASELINE.json configs[0] at its stated size -- NaturalSpeech2(Model(dim=128, depth=6), EncodecWrapper,
+    timesteps=1000).sample(length=1024) -> waveform [1, 327680] -- with the initial latents injected, against the oracle's 1000-step
+    DDIM loop (its tensors on the GPU: plain PyTorch fp32 ops) followed by HF's own EncodecDecoder on the same weights
+    (VERDICT r3 weak #2: the round-3 test asserted shape and finiteness only)."""
+    tf = pytest.importorskip("transformers")
+    from naturalspeech2_pytorch_amd import EncodecWrapperHIP
+    torch.manual_seed(0)
+    hf = tf.EncodecModel(tf.EncodecConfig()).eval().to(DEV)
+    with torch.no_grad():
+        for layer in hf.quantizer.layers:
+            layer.codebook.embed.normal_()
+        codec = EncodecWrapperHIP.from_hf(hf, hip_seanet=True).to(DEV).eval()
+    res = {}
+    noise = make_input("noise", (1, 1024, 128), seed=97)
+    ref_wav = None
+    for precision, ceil in (("exact", 2e-4), ("hybrid", 1e-3)):
+        m, sd = _model(dict(dim=128, depth=6), 96, precision)
+        d = NaturalSpeech2(m, codec, timesteps=1000).to(DEV)
+        wav = d.sample(length=1024, noise=noise)
+        assert wav.shape == (1, 327680) and torch.isfinite(wav).all()
+        if ref_wav is None:
+            with torch.no_grad():
+                lat = O.ddim_sample({k: v.to(DEV) for k, v in sd.items()}, noise.to(DEV), 1000)
+                ref_wav = hf.decoder(lat.transpose(1, 2))[:, 0]
+        res[precision] = rel(wav, ref_wav)
+        assert res[precision] < ceil, res
+        del m, d
+    record("config1_readme_at_size/waveform_vs_oracle_ddim_plus_hf_decoder", res)

@@ -28,8 +28,15 @@ constexpr int G2_BM = 256, G2_BN = 256;
 #ifndef G2_PHASED
 #define G2_PHASED 1            // -DG2_PHASED=0: the one-barrier-per-tile K loop of rounds 1-2 (A/B builds)
 #endif
-// (The schedule variants, the timing-diagnostic builds and the buffer-descriptor DMA experiment of round 3 -- G2_VAR, G2_DIAG,
-// G2_BUFLDS -- live in tools/experiments/gemm2_r3_with_diag_variants.hip; profiles/r03_kloop_decomposition.txt was measured with them.)
+#ifndef G2_VAR
+#define G2_VAR 0               // schedule variants of the phased loop (A/B builds): 1 = no s_setprio, 2 = refill pieces issued before the fragment reads, 3 = both
+#endif
+#ifndef G2_DIAG
+#define G2_DIAG 0              // timing diagnostics of the phased loop (WRONG results): 1 = half the fragment reads, 2 = no MFMAs, 3 = no DMA
+#endif
+#ifndef G2_BUFLDS
+#define G2_BUFLDS 0            // experiment: LDS-DMA through buffer descriptors (32-bit per-lane offsets) for the plain GEMMs
+#endif
 #ifndef G2_PHASED_CONV3
 #define G2_PHASED_CONV3 1      // -DG2_PHASED_CONV3=0: the tap-shared conv on the one-barrier-per-step loop (A/B builds)
 #endif
@@ -470,6 +477,25 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       }
     }
 
+#if G2_BUFLDS
+  // buffer-descriptor variant of the DMA (plain GEMMs: no row shift): base + 32-bit per-lane byte offset + scalar K offset; rows
+  // beyond M fall outside num_records and read as zeros
+  const bool use_buf = g.conv_taps == 0 && g.seq_len >= 0;
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(g.a_hi + pcol((int)(z * g.a_zs), ail)), 0,
+                                                       (int)(((long)g.M * a_rs - pcol((int)(z * g.a_zs), ail)) * 2), 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)(g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0))), 0,
+                                                       (int)(((long)((g.N + 255) / 256) * 256 * w_rs) * 2), 0x00020000);
+  unsigned pvoff[4][2];
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = 2 * wave + e;
+      const int rg = (h < 2) ? ((k & 7) + 16 * (k >> 3) + 8 * h) : ((k & 3) + 8 * (k >> 2) + 4 * (h - 2));
+      const int row = rg * RPI + lrow;
+      pvoff[h][e] = (h < 2) ? (unsigned)(((long)tm * G2_BM + row) * a_rs * 2) : (unsigned)(((long)tn * G2_BN + row) * w_rs * 2);
+    }
+#endif
   struct TileCoord { int tap, it; };
   auto tile_coord = [&](auto mode, int kt) __attribute__((always_inline)) {
     const int tpt = tiles_per_tap(mode);
@@ -488,6 +514,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     const bool half = !M::line32 && (g.kt_per_tap & 1) && (c.it == tpt - 1);
     const bool il = (H < 2) ? ail : wil;
     unsigned char* sbase = smem + stage * STAGE;
+    if (G2_DIAG == 3) return;
     int coff[2];
     bool chi[2];
 #pragma unroll
@@ -495,6 +522,17 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       coff[e] = M::line32 ? lchunk_par[e] * 8 : pcol(lchunk_par[e] * 8, il);
       chi[e] = lchunk_par[e] >= 4;
     }
+#if G2_BUFLDS
+    if (use_buf) {
+      const int soff = (int)(((H < 2) ? pcol(c.it * BK, ail) : pcol(c.tap * tap_k + c.it * BK, wil)) * 2);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned vo = (half && chi[e]) ? 0x80000000u : (pvoff[H][e] + (unsigned)(coff[e] * 2));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds((H < 2) ? rsrcA : rsrcW, (lds_void_t*)(sbase + pldst[H][e]), 16, (int)vo, soff, 0, 0);
+      }
+      return;
+    }
+#endif
     if constexpr (H < 2) {
       const int pl = g.pad_left < 0 ? g.conv_taps - 1 : g.pad_left;
       const int shift = (c.tap < g.conv_taps) ? (pl - c.tap) * dil : 0;
@@ -539,7 +577,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   };
   auto mma_quadrant = [&](auto mode, int a, int b, const AHalf& A, const WHalf& W) __attribute__((always_inline)) {
     using M = decltype(mode);
-    __builtin_amdgcn_s_setprio(1);
+    if (G2_DIAG == 2) {                                  // keep the fragments live, skip the matrix work
+      asm volatile("" :: "v"(A.f[0][0]), "v"(A.f[1][3]), "v"(W.f[0]), "v"(W.f[3]));
+      return;
+    }
+    if (!(G2_VAR & 1)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       f32x16& c = acc[2 * a + i][b];
@@ -569,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
                                                                             0, H8_E8M0_LO, 0, H8_E8M0_ONE);
       }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (!(G2_VAR & 1)) __builtin_amdgcn_s_setprio(0);
   };
 #define G2_VMWAIT(fill) do { if (fill) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
 
@@ -602,22 +644,25 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       const bool more1 = t + 1 < T, more2 = t + 2 < T;
       const TileCoord c2 = more2 ? tile_coord(mode, kt + 2) : c1;
       // ---- phase 0: quadrant (0, 0); request B1 of tile t + 1
+      if ((G2_VAR & 2) && more1) issue_half(mode, c1, (kt + 1) & 1, HB1{});
       if (wave_active) { load_a(mode, sb, a_row_off, fswz, 0, A); load_w(mode, sb, w_row_off, fswz, 0, W0); }
-      if (more1) issue_half(mode, c1, (kt + 1) & 1, HB1{});
+      if (!(G2_VAR & 2) && more1) issue_half(mode, c1, (kt + 1) & 1, HB1{});
       G2_VMWAIT(more1);
       __builtin_amdgcn_s_barrier();
       if (wave_active) mma_quadrant(mode, 0, 0, A, W0);
       __builtin_amdgcn_s_barrier();
       // ---- phase 1: quadrant (0, 1); request A1 of tile t + 1
-      if (wave_active) load_w(mode, sb, w_row_off, fswz, 1, W1);
-      if (more1) issue_half(mode, c1, (kt + 1) & 1, HA1{});
+      if ((G2_VAR & 2) && more1) issue_half(mode, c1, (kt + 1) & 1, HA1{});
+      if (wave_active && G2_DIAG != 1) load_w(mode, sb, w_row_off, fswz, 1, W1);
+      if (!(G2_VAR & 2) && more1) issue_half(mode, c1, (kt + 1) & 1, HA1{});
       G2_VMWAIT(more1);
       __builtin_amdgcn_s_barrier();
       if (wave_active) mma_quadrant(mode, 0, 1, A, W1);
       __builtin_amdgcn_s_barrier();
       // ---- phase 2: quadrant (1, 1); request A0 of tile t + 2 (the rows of A0(t) were last read in phase 0)
-      if (wave_active) load_a(mode, sb, a_row_off, fswz, 1, A);
-      if (more2) issue_half(mode, c2, kt & 1, HA0{});
+      if ((G2_VAR & 2) && more2) issue_half(mode, c2, kt & 1, HA0{});
+      if (wave_active && G2_DIAG != 1) load_a(mode, sb, a_row_off, fswz, 1, A);
+      if (!(G2_VAR & 2) && more2) issue_half(mode, c2, kt & 1, HA0{});
       G2_VMWAIT(more2);
       __builtin_amdgcn_s_barrier();
       if (wave_active) mma_quadrant(mode, 1, 1, A, W1);
