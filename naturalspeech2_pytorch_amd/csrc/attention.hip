@@ -16,9 +16,6 @@
 //   * O^T = V^T P^T accumulates with query = lane & 31 again, so the running rescale is a per-lane scalar;
 //   * V arrives already transposed ([b][h*64+d][n]) from the QKV GEMM epilogue (gemm.hip EPI_QKV).
 // NSPLIT = 3 evaluates both products as hi*hi + hi*lo + lo*hi (fp32-class accuracy), NSPLIT = 1 hi only.
-#include <atomic>
-#include <cstdlib>
-
 #include "ns2_common.h"
 #include "ns2_kernels.h"
 
@@ -48,15 +45,10 @@ NS2_DEVINL uint4 mask_chunk(uint4 v, int nvalid) {
 // wave's exp / max / convert work with another's MFMAs.  Four waves (<= 128 VGPRs) spills 60+ registers.
 // WLSE: also write the log-sum-exp the backward kernels recompute P from (training); a separate instantiation, so the inference
 // kernels keep their register allocation (three waves per SIMD is a one-register margin, see above)
-// QG = query groups of 32 per wave.  Round 4: with one group every wave re-reads the whole K and V^T tile from LDS for 16 MFMAs --
-// 64 KiB of fragment reads per 64-key tile and workgroup against 128 B / clk of LDS bandwidth = 512 clocks, as long as the tile's
-// MFMAs (16 x 32 clocks per wave): the single-product kernel was bound by LDS bandwidth as much as by the matrix pipe, and a third
-// wave per SIMD could not help.  With QG = 2 a wave multiplies every K / V^T fragment it reads against TWO query groups: half the
-// LDS bytes per FLOP (the accumulators and score tiles double: 2 waves per SIMD instead of 3).
-template <int NSPLIT, bool F16, int NW, bool WLSE, int QG>
-__global__ __launch_bounds__(64 * NW, (NSPLIT == 3 || QG == 2 ? 2 : 3)) void attn_kernel(const AttnArgs a) {
+template <int NSPLIT, bool F16, int NW, bool WLSE>
+__global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(const AttnArgs a) {
   constexpr int NP = (NSPLIT == 3) ? 2 : 1;
-  constexpr int QB = 32 * NW * QG;                   // query rows per workgroup
+  constexpr int QB = 32 * NW;                        // query rows per workgroup
   constexpr int NT = 64 * NW;                        // threads
   constexpr int CPT = 512 / NT;                      // 16-B chunks of one 64 x 64 plane per thread (2 or 1)
   constexpr int STAGE_BYTES = 2 * NP * AT_PLANE;     // K planes then V^T planes
@@ -71,10 +63,8 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 || QG == 2 ? 2 : 3)) void att
   const int qt = bid % nqt;
   bid /= nqt;
   const int h = bid % a.H, b = bid / a.H;
-  int qrow[QG];
-  bool q_ok[QG];
-#pragma unroll
-  for (int g = 0; g < QG; ++g) { qrow[g] = qt * QB + (wave * QG + g) * 32 + l31; q_ok[g] = qrow[g] < a.Nq; }
+  const int qrow = qt * QB + wave * 32 + l31;
+  const bool q_ok = qrow < a.Nq;
 
   const bf16_t* q_pl[2] = {a.q_hi, a.q_lo};
   const bf16_t* k_pl[2] = {a.k_hi, a.k_lo};
@@ -83,17 +73,15 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 || QG == 2 ? 2 : 3)) void att
   const bool qil = a.q_lo != nullptr, kil = a.k_lo != nullptr, vil = a.vt_lo != nullptr, oil = a.o_lo != nullptr;
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = l31][d = 16c + 8hi .. +7]
-  bf16x8 qf[QG][NP][4];
+  bf16x8 qf[NP][4];
 #pragma unroll
-  for (int g = 0; g < QG; ++g)
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (q_ok[g]) v = ld16g(q_pl[p] + ((long)b * a.Nq + qrow[g]) * pld(a.ldq, qil) + pcol(a.q_col0 + h * 64 + 16 * c + 8 * hi, qil));
-        qf[g][p][c] = *reinterpret_cast<bf16x8*>(&v);
-      }
+    for (int c = 0; c < 4; ++c) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (q_ok) v = ld16g(q_pl[p] + ((long)b * a.Nq + qrow) * pld(a.ldq, qil) + pcol(a.q_col0 + h * 64 + 16 * c + 8 * hi, qil));
+      qf[p][c] = *reinterpret_cast<bf16x8*>(&v);
+    }
 
   // ---- staging coordinates: CPT chunks per plane per thread
   int srow[CPT], sch[CPT];
@@ -144,16 +132,12 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 || QG == 2 ? 2 : 3)) void att
   const int k_frag_off = pi_row * AT_ROWB + hi * 16;          // + js*32*ROWB + c*32
   const int v_frag_off = l31 * AT_ROWB + hi * 16;             // + dt*32*ROWB + js*64 + g1*32
 
-  f32x16 ot[QG][2];
-  float m_run[QG], l_run[QG];
+  f32x16 ot[2];
 #pragma unroll
-  for (int g = 0; g < QG; ++g) {
-    m_run[g] = -INFINITY; l_run[g] = 0.f;
+  for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[g][dt][r] = 0.f;
-  }
+    for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
   const float sl2 = a.scale * 1.4426950408889634f;
 
   const int ntiles = (a.Nk + 63) / 64;
@@ -169,27 +153,22 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 || QG == 2 ? 2 : 3)) void att
     const int key0 = t * 64;
 
     // ---- S^T = K Q^T  (2 sub-tiles of 32 keys)
-    f32x16 st[QG][2];
+    f32x16 st[2];
 #pragma unroll
     for (int js = 0; js < 2; ++js) {
 #pragma unroll
-      for (int g = 0; g < QG; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[g][js][r] = 0.f;
+      for (int r = 0; r < 16; ++r) st[js][r] = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         bf16x8 kf[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p)
           kf[p] = *reinterpret_cast<const bf16x8*>(sb + p * AT_PLANE + k_frag_off + js * 32 * AT_ROWB + c * 32);
-#pragma unroll
-        for (int g = 0; g < QG; ++g) {                       // one K fragment, QG query groups
-          if constexpr (NSPLIT == 3) {
-            st[g][js] = mma16<F16>(kf[1], qf[g][0][c], st[g][js]);
-            st[g][js] = mma16<F16>(kf[0], qf[g][1][c], st[g][js]);
-          }
-          st[g][js] = mma16<F16>(kf[0], qf[g][0][c], st[g][js]);
+        if constexpr (NSPLIT == 3) {
+          st[js] = mma16<F16>(kf[1], qf[0][c], st[js]);
+          st[js] = mma16<F16>(kf[0], qf[1][c], st[js]);
         }
+        st[js] = mma16<F16>(kf[0], qf[0][c], st[js]);
       }
     }
 
@@ -197,44 +176,40 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 || QG == 2 ? 2 : 3)) void att
     // st holds RAW scores; the scale (and log2 e) is folded into the exponent's fma.  Key masking is a wave-uniform
     // slow path: only the last tile of a ragged key length, or a call with a key-padding mask, takes it.
     const unsigned char* km = a.kmask ? a.kmask + (long)b * a.Nk : nullptr;
+    if (key0 + 64 > a.Nk || km) {
 #pragma unroll
-    for (int g = 0; g < QG; ++g) {
-      if (key0 + 64 > a.Nk || km) {
-  #pragma unroll
-        for (int js = 0; js < 2; ++js)
-  #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = key0 + 32 * js + 16 * (r >> 3) + 8 * hi + (r & 7);
-            if (key >= a.Nk) st[g][js][r] = -INFINITY;
-            else if (km && !km[key]) st[g][js][r] = -3.0e38f;   // ATT:136-138 masked_fill(~mask, -finfo.max): finite, like the reference
-          }
-      }
-      float mx = -INFINITY;
-  #pragma unroll
       for (int js = 0; js < 2; ++js)
-  #pragma unroll
-        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, st[g][js][r]), st[g][js][r + 1]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[g], mx * sl2);           // sl2 > 0: the scaled maximum is the maximum of the scaled scores
-      const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
-      m_run[g] = m_new;
-      float psum = 0.f;
-  #pragma unroll
-      for (int js = 0; js < 2; ++js)
-  #pragma unroll
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[g][js][r], sl2, -m_new));
-          st[g][js][r] = p;
-          psum += p;
+          const int key = key0 + 32 * js + 16 * (r >> 3) + 8 * hi + (r & 7);
+          if (key >= a.Nk) st[js][r] = -INFINITY;
+          else if (km && !km[key]) st[js][r] = -3.0e38f;   // ATT:136-138 masked_fill(~mask, -finfo.max): finite, like the reference
         }
-      l_run[g] = l_run[g] * alpha + psum;
-      if (__any(alpha != 1.0f)) {                           // the running maximum rarely moves after the first tiles
-  #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-  #pragma unroll
-          for (int r = 0; r < 16; ++r) ot[g][dt][r] *= alpha;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int js = 0; js < 2; ++js)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, st[js][r]), st[js][r + 1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * sl2);           // sl2 > 0: the scaled maximum is the maximum of the scaled scores
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int js = 0; js < 2; ++js)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[js][r], sl2, -m_new));
+        st[js][r] = p;
+        psum += p;
       }
-
+    l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {                           // the running maximum rarely moves after the first tiles
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
     }
 
     // ---- O^T += V^T P^T
@@ -242,20 +217,19 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 || QG == 2 ? 2 : 3)) void att
     for (int js = 0; js < 2; ++js)
 #pragma unroll
       for (int g1 = 0; g1 < 2; ++g1) {
-        bf16x8 pf[QG][NP];
-#pragma unroll
-        for (int g = 0; g < QG; ++g) {
+        bf16x8 pf[NP];
+        {
           uint32_t ph[4], pl[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if constexpr (F16) { ph[e] = cvt2h_inrange(st[g][js][8 * g1 + 2 * e], st[g][js][8 * g1 + 2 * e + 1]); pl[e] = 0u; }   // p in [0, 1]
-            else split2(st[g][js][8 * g1 + 2 * e], st[g][js][8 * g1 + 2 * e + 1], ph[e], pl[e]);
+            if constexpr (F16) { ph[e] = cvt2h_inrange(st[js][8 * g1 + 2 * e], st[js][8 * g1 + 2 * e + 1]); pl[e] = 0u; }   // p in [0, 1]
+            else split2(st[js][8 * g1 + 2 * e], st[js][8 * g1 + 2 * e + 1], ph[e], pl[e]);
           }
           const uint4 uh = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-          pf[g][0] = *reinterpret_cast<const bf16x8*>(&uh);
+          pf[0] = *reinterpret_cast<const bf16x8*>(&uh);
           if constexpr (NSPLIT == 3) {
             const uint4 ul = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-            pf[g][1] = *reinterpret_cast<const bf16x8*>(&ul);
+            pf[1] = *reinterpret_cast<const bf16x8*>(&ul);
           }
         }
 #pragma unroll
@@ -265,14 +239,11 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 || QG == 2 ? 2 : 3)) void att
           for (int p = 0; p < NP; ++p)
             vf[p] = *reinterpret_cast<const bf16x8*>(sb + (NP + p) * AT_PLANE + v_frag_off + dt * 32 * AT_ROWB +
                                                     js * 64 + g1 * 32);
-#pragma unroll
-          for (int g = 0; g < QG; ++g) {                     // one V^T fragment, QG query groups
-            if constexpr (NSPLIT == 3) {
-              ot[g][dt] = mma16<F16>(vf[1], pf[g][0], ot[g][dt]);
-              ot[g][dt] = mma16<F16>(vf[0], pf[g][1], ot[g][dt]);
-            }
-            ot[g][dt] = mma16<F16>(vf[0], pf[g][0], ot[g][dt]);
+          if constexpr (NSPLIT == 3) {
+            ot[dt] = mma16<F16>(vf[1], pf[0], ot[dt]);
+            ot[dt] = mma16<F16>(vf[0], pf[1], ot[dt]);
           }
+          ot[dt] = mma16<F16>(vf[0], pf[0], ot[dt]);
         }
       }
 
@@ -281,57 +252,37 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 || QG == 2 ? 2 : 3)) void att
   }
 
   // ---- normalise and write O[q][h*64 + d]: lane holds d = 32dt + 8g + 4hi + e for its query
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if constexpr (WLSE) if (q_ok && hi == 0) a.lse[((long)b * a.H + h) * a.Nq + qrow] = m_run + log2f(l_tot);   // training: P is recomputed from this
+  if (q_ok) {
+    bf16_t* orow = a.o_hi + ((long)b * a.Nq + qrow) * pld(a.ldo, oil);
 #pragma unroll
-  for (int g = 0; g < QG; ++g) {
-    const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
-    const float inv = 1.0f / l_tot;
-    if constexpr (WLSE) if (q_ok[g] && hi == 0) a.lse[((long)b * a.H + h) * a.Nq + qrow[g]] = m_run[g] + log2f(l_tot);   // training: P is recomputed from this
-    if (q_ok[g]) {
-      bf16_t* orow = a.o_hi + ((long)b * a.Nq + qrow[g]) * pld(a.ldo, oil);
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-          store_cols4(orow, h * 64 + 32 * dt + 8 * gq + 4 * hi, ot[g][dt][4 * gq + 0] * inv, ot[g][dt][4 * gq + 1] * inv,
-                      ot[g][dt][4 * gq + 2] * inv, ot[g][dt][4 * gq + 3] * inv, a.o_fmt, oil);
-    }
+      for (int gq = 0; gq < 4; ++gq)
+        store_cols4(orow, h * 64 + 32 * dt + 8 * gq + 4 * hi, ot[dt][4 * gq + 0] * inv, ot[dt][4 * gq + 1] * inv,
+                    ot[dt][4 * gq + 2] * inv, ot[dt][4 * gq + 3] * inv, a.o_fmt, oil);
   }
 }
 
-template <int NSPLIT, bool F16, int NW, bool WLSE, int QG>
+template <int NSPLIT, bool F16, int NW, bool WLSE>
 static hipError_t launch_attn_w(const AttnArgs& a, hipStream_t s) {
   const size_t lds = 2 * 2 * (NSPLIT == 3 ? 2 : 1) * AT_PLANE;
   static DynLdsAttr attr;
   {
-    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attn_kernel<NSPLIT, F16, NW, WLSE, QG>), (int)lds);
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attn_kernel<NSPLIT, F16, NW, WLSE>), (int)lds);
     if (e != hipSuccess) return e;
   }
-  dim3 grid(((a.Nq + 32 * NW * QG - 1) / (32 * NW * QG)) * a.H * a.B);
-  hipLaunchKernelGGL((attn_kernel<NSPLIT, F16, NW, WLSE, QG>), grid, dim3(64 * NW), lds, s, a);
+  dim3 grid(((a.Nq + 32 * NW - 1) / (32 * NW)) * a.H * a.B);
+  hipLaunchKernelGGL((attn_kernel<NSPLIT, F16, NW, WLSE>), grid, dim3(64 * NW), lds, s, a);
   return hipGetLastError();
-}
-// test / A-B hook: NS2_ATTN_QG=1 keeps one query group per wave in the single-product kernels (read once)
-static int attn_qg() {
-  static std::atomic<int> v{-1};
-  int r = v.load(std::memory_order_relaxed);
-  if (r < 0) {
-    const char* e = getenv("NS2_ATTN_QG");
-    r = (e && atoi(e) == 1) ? 1 : 2;
-    v.store(r, std::memory_order_relaxed);
-  }
-  return r;
 }
 template <int NSPLIT, bool F16>
 static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
-  if constexpr (NSPLIT == 3) {
-    if (a.lse) return launch_attn_w<NSPLIT, F16, 4, true, 1>(a, s);     // training runs in precision 3
-    return launch_attn_w<NSPLIT, F16, 4, false, 1>(a, s);
-  } else {
-    if (a.lse) return hipErrorInvalidValue;
-    // two query groups per wave pay once a workgroup's 256 queries exist (self-attention); short query counts keep the finer grid
-    if (a.Nq >= 256 && attn_qg() == 2) return launch_attn_w<NSPLIT, F16, 4, false, 2>(a, s);
-    return launch_attn_w<NSPLIT, F16, 4, false, 1>(a, s);
-  }
+  if constexpr (NSPLIT == 3) { if (a.lse) return launch_attn_w<NSPLIT, F16, 4, true>(a, s); }   // training runs in precision 3
+  else if (a.lse) return hipErrorInvalidValue;
+  return launch_attn_w<NSPLIT, F16, 4, false>(a, s);
 }
 
 hipError_t launch_attention(const AttnArgs& a_in, int nsplit, hipStream_t s) {
