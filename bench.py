@@ -22,8 +22,12 @@ its own parity flag and roofline.
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events recorded by the executor on the launch stream
 around every launch of the dominant kernel symbol (hybrid: gemm2_kernel<1, EPI_SPLIT, true> = the 12 FF causal convs;
-other modes: gemm2_kernel<*, EPI_SPLIT, *> = the 12 FF causal convs + wavenet init conv + skip GEMM); `cpu_baseline` times the CPU oracle (a port of the reference path, SDPA attention like the reference's
-default) on the full batch of 32 once.  See DESIGN.md §Measurement.
+other modes: gemm2_kernel<*, EPI_SPLIT, *> = the 12 FF causal convs + wavenet init conv + skip GEMM); `cpu_baseline` times the
+reference's OWN `Model.forward` (unmodified source from the oracle/_ref archive, CPU SDPA attention, the benched weights) on the host
+cores: two timed forwards of the full batch of 32 after a warm-up, the minimum reported (kind "port" = the oracle restatement, only
+when the archive is absent).  Round 4: the steps read the run's time-conditioning table (built inside the timed region, as
+NaturalSpeech2.sample builds it per run; --no-time-table for the A/B), `side.train_step` = a warm training step on the HIP backward.
+See DESIGN.md §Measurement.
 """
 import argparse
 import ctypes
@@ -152,14 +156,18 @@ def cpu_baseline(sd, dim, depth, B, n):
             ref.load_state_dict(sd)
             with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
                 ref(x[:1], t[:1])                         # warm-up (thread pool, oneDNN primitives)
-                t0 = time.perf_counter()
-                y = ref(x, t)
-                el = time.perf_counter() - t0
+                els = []
+                for _ in range(2):                        # >= 2 timed steps; the minimum is reported
+                    t0 = time.perf_counter()
+                    y = ref(x, t)
+                    els.append(time.perf_counter() - t0)
+                el = min(els)
                 chk = float(((O.model_forward(sd, x[:1], t[:1]) - y[:1]).norm() / y[:1].norm()).item())   # the oracle against the reference, live
             return dict(value=round(1.0 / el, 5), unit="steps/s", cores=cores, kind="reference",
                         sample=f"the reference's own Model.forward (unmodified source, {ref_stub.reference_source()}), fp32, CPU SDPA "
-                               f"attention, ONE forward of the full batch {B} x {n} frames after a 1-utterance warm-up: {el:.2f} s, "
-                               f"{cores} threads = physical cores; oracle-vs-reference rel err on one utterance {chk:.1e}")
+                               f"attention, TWO timed forwards of the full batch {B} x {n} frames after a 1-utterance warm-up: "
+                               f"{els[0]:.2f} s, {els[1]:.2f} s (value = 1 / min), {cores} threads = physical cores; "
+                               f"oracle-vs-reference rel err on one utterance {chk:.1e}")
         O.USE_SDPA = True
         with torch.no_grad():
             O.model_forward(sd, x[:1], t[:1])
@@ -372,7 +380,7 @@ def main():
         parity["sweep_source"] = f"profiles/{PARITY_RECORD} (tests/test_parity_r2_gpu.py: 8 weight seeds x times {{0.002, 0.5, 0.999}})"
         if not args.no_secondary and not args.conditioned:
             k2 = min(args.steps, 10)
-            for other in ("mixed", "half", "exact"):
+            for other in ("hybrid_ff", "mixed", "half", "exact"):
                 if other == args.precision:
                     continue
                 e2, km, kn = measure(model, other, k2, 2)
@@ -381,6 +389,9 @@ def main():
                 extra[other + "_mode"] = dict(value=round(k2 / e2, 3), unit="steps/s", steps=k2, ms_per_step=round(1e3 * e2 / k2, 3),
                                               dtype=DTYPE[other], roofline_frac=r2["frac"] if r2 else None,
                                               dominant_kernel_tflops=r2["achieved"] if r2 else None)
+                if other == "hybrid_ff":
+                    extra[other + "_mode"]["note"] = ("not the default: 1.6e-4 on the random-init sweep but 1.0e-3 with an amplified feed-forward "
+                                                      "branch (hybrid: 5.0e-4) -- profiles/r04_plan_hybrid_ff.json, DESIGN.md section 2")
         extra["parity"] = parity
         cpu_sd = sd_cpu if (not args.no_cpu_baseline and not args.conditioned) else None   # timed after the side workloads (below)
         del sd_cpu
