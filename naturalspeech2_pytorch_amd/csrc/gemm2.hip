@@ -143,10 +143,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       nseq[i] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -0x40000000;
     } else {
       src[i] = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN + row) * w_rs;
-      // W rows at or beyond N are the packer's zero padding: their lanes read the zero page instead -- one line request for all of
-      // them where the padded rows cost one each (the FF conv's last column tile holds 85 valid rows of 256; line requests are
-      // what bounds these K loops: profiles/r04_h6_fetch_ab.txt).  Same zeros, bit-identical results.
-      nseq[i] = (tn * G2_BN + row < g.N) ? 0 : -1;
+      nseq[i] = 0;
     }
   }
 
@@ -194,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       const long off = pcol(tap * tap_k + it * BK, wil);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const bf16_t* p = ((half && chi[i & 1]) || nseq[i] < 0) ? zero_page : (src[i] + off + coff[i & 1]);   // nseq < 0: W row >= N (padding)
+        const bf16_t* p = (half && chi[i & 1]) ? zero_page : (src[i] + off + coff[i & 1]);
         glds16(p, sbase + ldst[i]);
       }
     }
@@ -341,8 +338,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = wave * 4 + i;
-        const bf16_t* p = ((half && ((i & 1) ? chi1 : chi0)) || tn * G2_BN + 8 * j + lrow >= g.N)
-                              ? zero_page : (w_base + (long)(8 * j + lrow) * w_rs + off + ((i & 1) ? cofW1 : cofW0));
+        const bf16_t* p = (half && ((i & 1) ? chi1 : chi0)) ? zero_page
+                                                            : (w_base + (long)(8 * j + lrow) * w_rs + off + ((i & 1) ? cofW1 : cofW0));
         glds16(p, sW + buf * W_BUF + j * 1024);
       }
     };
@@ -469,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
         psrc[h][e] = g.a_hi + pcol((int)(z * g.a_zs), ail) + m * a_rs;
         pnseq[h][e] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -0x40000000;
       } else {
-        psrc[h][e] = (tn * G2_BN + row < g.N) ? g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN + row) * w_rs : nullptr;   // null: padding row
+        psrc[h][e] = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN + row) * w_rs;
       }
     }
 
@@ -512,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       const long off = pcol(c.tap * tap_k + c.it * BK, wil);
 #pragma unroll
       for (int e = 0; e < 2; ++e)
-        glds16(((half && chi[e]) || !psrc[H][e]) ? zero_page : (psrc[H][e] + off + coff[e]), sbase + pldst[H][e]);
+        glds16((half && chi[e]) ? zero_page : (psrc[H][e] + off + coff[e]), sbase + pldst[H][e]);
     }
   };
   using HA0 = std::integral_constant<int, 0>; using HA1 = std::integral_constant<int, 1>;
@@ -670,8 +667,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       for (int e = 0; e < 2; ++e) {
         const int k = 2 * wave + e;
         const int rg = (k & 3) + 8 * (k >> 2) + 4 * b;       // parity == e
-        const bool pad = tn * G2_BN + 8 * rg + lrow >= g.N;                      // the packer's zero rows: one zero-page line for all of them
-        const bf16_t* p = ((half && (e ? chi1 : chi0)) || pad) ? zero_page : (w_base + (long)(8 * rg + lrow) * w_rs + off + (e ? cofW1 : cofW0));
+        const bf16_t* p = (half && (e ? chi1 : chi0)) ? zero_page : (w_base + (long)(8 * rg + lrow) * w_rs + off + (e ? cofW1 : cofW0));
         glds16(p, sW + (st & 1) * W_BUF + rg * 1024);
       }
     };

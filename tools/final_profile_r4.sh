@@ -13,6 +13,8 @@ for P in hybrid hybrid_ff mixed half exact; do
   cp $(ls $OUT/prof_$P/*/*kernel_stats.csv | head -1) $OUT/bench_${P}_kernel_stats.csv
   rm -rf $OUT/prof_$P
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_d128 -- python $R/bench.py --dim 128 --depth 6 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-side --no-parity > $OUT/prof_d128.log 2>&1
+cp $(ls $OUT/prof_d128/*/*kernel_stats.csv | head -1) $OUT/bench_d128_hybrid_kernel_stats.csv; rm -rf $OUT/prof_d128
 for shp in d512 d128; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train_$shp -- python $R/tools/bench_train.py --shapes $shp --backends hip --iters 3 > $OUT/prof_train_$shp.log 2>&1
   cp $(ls $OUT/prof_train_$shp/*/*kernel_stats.csv | head -1) $OUT/train_${shp}_kernel_stats.csv
