@@ -18,10 +18,11 @@ weights (dgrad) and on transposed planes with a fixed-slot split-K (wgrad), atte
 P from the forward's log-sum-exp.  Arithmetic: precision 3 ("exact", bf16 x3 products, fp32 accumulate) whatever inference
 precision the `Model` was built with -- gradients match the reference's fp32 autograd to ~1e-5.
 
-What stays in PyTorch ops (rows = batch entries, not tokens; < 0.1 % of the FLOPs): the sinusoidal time embedding and the
-[B, dim_cond] -> [B, 2 dim] conditioning Linears feeding FiLM / adaptive norms (NS2:108-120, 623, 744, 841), the prompt
-mean-pool Linear and the 32-token PerceiverResampler of the conditioned model (NS2:532-579, 858-862) and the `torch.where`
-null-conditioning selects.  Autograd chains them with the Functions above.
+Rows = batch entries: every conditioning Linear ([B, dim_cond] -> [B, 2 dim] for FiLM / adaptive norms, `to_time_cond.1`,
+`to_prompt_cond.1`: NS2:623, 744, 841, 860) is `SkinnyLinearFn` -- the fp32 weight-streaming kernel of the inference path in all
+three roles (y = x W^T + b, dx = dy W, dW = dy^T x).  What stays in PyTorch ops are pointwise glue on [B, *] rows (sin / cos of the
+time embedding, SiLU, cat, mean-pool, `torch.where` null selects) and the 32-token PerceiverResampler of the conditioned model
+(NS2:532-579: the composite of autograd_path.py).  Autograd chains them with the Functions above.
 
 `Backend` is the seam the CPU tests use: `tests/emu_backend.py` restates every backend call with plain torch ops on CPU, so the
 chain rule, tap flips, shifts and layouts of THIS file are checked against torch autograd without a GPU; the kernels behind
@@ -147,6 +148,25 @@ class HipBackend:
         check(self.lib.ns2_attention_lse(q.hi, q.lo, q.ld, q_col0, k.hi, k.lo, k.ld, k_col0, vt.ptr(), vt.ptr() + 64, vt.ld, o.hi, o.lo, H * 64,
                                          B, H, Nq, Nk, 0.125, lse.data_ptr(), 3, _s()), "ns2_attention_lse")
         return o, lse
+
+    # ---- rows = batch entries: the conditioning Linears (weight-streaming kernel of the inference path, fp32)
+    def skinny(self, x, wt, bias=None):
+        """x [R, K] @ wt [K, J] (+ bias) in fp32 (ns2_skinny_linear: deterministic split-K)"""
+        return ops.skinny_linear(x if x.is_contiguous() else x.contiguous(), wt if wt.is_contiguous() else wt.contiguous(), bias)
+
+    def transpose_f32(self, x):
+        x = x if x.is_contiguous() else x.contiguous()
+        R, C = x.shape
+        out = torch.empty(C, R, dtype=torch.float32, device=x.device)
+        check(self.lib.ns2_transpose_f32(x.data_ptr(), 1, R, C, out.data_ptr(), _s()), "ns2_transpose_f32")
+        return out
+
+    def colsum_rows(self, x):
+        """sum over the rows of a small [R, J] matrix in a fixed order (bias gradients of the conditioning Linears)"""
+        x = x if x.is_contiguous() else x.contiguous()
+        out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+        check(self.lib.ns2_reduce_slices(x.data_ptr(), 1, x.shape[0], x.shape[1], out.data_ptr(), 0, _s()), "ns2_reduce_slices")
+        return out
 
     # ---- backward pieces
     def grad_prep(self, x, C, want_row=False, want_t=False, want_colsum=False, seq_len=0, per_batch=False, t_rows=None):
@@ -502,6 +522,35 @@ class NormLinearFn(torch.autograd.Function):
         return dh, dgamma, dw, None
 
 
+class SkinnyLinearFn(torch.autograd.Function):
+    """nn.Linear on rows = batch entries: `to_time_cond.1`, every FiLM / adaptive-norm `to_gamma_beta` / block `to_time_cond`
+    (NS2:623, 744, 841), `to_prompt_cond.1` (NS2:860).  The weight-streaming fp32 kernel of the inference path in all three roles:
+    y = x W^T + b;  dx = dy W (the weight as stored is already K-major for this product);  dW = dy^T x;  db = column sums."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        bk = backend()
+        wt = bk.transpose_f32(w.detach())                                   # [K, J]
+        y = bk.skinny(x.detach(), wt, b.detach() if b is not None else None)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        bk = backend()
+        x, w = ctx.saved_tensors
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = bk.skinny(dy, w.detach()) if ctx.needs_input_grad[0] else None  # [B, J] @ [J, K]
+        dw = bk.skinny(bk.transpose_f32(dy), x.detach())                     # [J, B] @ [B, K]
+        db = bk.colsum_rows(dy) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def _lin(lin, x):
+    return SkinnyLinearFn.apply(x if x.is_contiguous() else x.contiguous(), lin.weight, lin.bias)
+
+
 # =============================================================================================== Model.forward under autograd
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
@@ -519,7 +568,7 @@ def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None
     w = getattr(m.to_time_cond, "0").weights
     tt = times.float()[:, None]
     fr = tt * w[None] * 2 * math.pi
-    t = F.silu(getattr(m.to_time_cond, "1")(torch.cat((tt, fr.sin(), fr.cos()), dim=-1)))
+    t = F.silu(_lin(getattr(m.to_time_cond, "1"), torch.cat((tt, fr.sin(), fr.cos()), dim=-1)))
     c = None
     h = x.float().reshape(M, d)
     if m.condition_on_prompt:
@@ -533,7 +582,7 @@ def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None
             return torch.rand(b, device=x.device) < p
 
         dm = mask()
-        pc = F.silu(getattr(m.to_prompt_cond, "1")(prompt.mean(dim=1)))
+        pc = F.silu(_lin(getattr(m.to_prompt_cond, "1"), prompt.float().mean(dim=1)))
         pc = torch.where(dm[:, None], m.null_prompt_cond, pc)
         t = torch.cat((t, pc), dim=-1)
         pr = m.perceiver_resampler                                          # 32 latents per utterance: the PyTorch composite
@@ -558,7 +607,7 @@ def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None
     t = _c(t)
 
     def film_of(lin):
-        return _c(lin(t))
+        return _lin(lin, t)
 
     wn = m.wavenet
     h0 = GemmFn.apply(h, wn.init_conv.weight, wn.init_conv.bias, None, n, 1)

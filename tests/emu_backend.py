@@ -124,6 +124,16 @@ class EmuBackend:
         o = (s.softmax(-1) @ vv).transpose(1, 2).reshape(B * Nq, a)
         return self.split(o), lse
 
+    def skinny(self, x, wt, bias=None):
+        y = x @ wt
+        return y + bias if bias is not None else y
+
+    def transpose_f32(self, x):
+        return x.t().contiguous()
+
+    def colsum_rows(self, x):
+        return x.sum(0)
+
     # ---- backward pieces
     def _shifted(self, x, seq_len, shift):
         M = x.shape[0]
