@@ -81,8 +81,8 @@ class _PackedCache:
         if hit is not None and any(r() is not p for r, p in zip(hit[4], params)):
             hit = None
         refs = tuple(weakref.ref(p) for p in params)
-        if hit is None and len(self.map) >= 4096:
-            self._purge()
+        if hit is None:
+            self._purge()                    # a miss is rare (first step of a model): drop the packs of models that no longer exist
         if hit is not None and hit[1] == sig:
             return hit[0]
         src = make_src()

@@ -294,6 +294,31 @@ def test_conditioned_model_gradients_match_the_composite():
     _compare("conditioned_d128_L2_vs_composite", g1, g0, dx1, dx0, y1, y0)
 
 
+@pytest.mark.parametrize("tag,kw,b,n,n_p,n_c", [
+    ("d96_b1_n50", dict(dim=96, depth=1, wavenet_layers=2, wavenet_stacks=1), 1, 50, 0, 0),
+    ("d64_b5_n333", dict(dim=64, depth=1, wavenet_layers=3, wavenet_stacks=2), 5, 333, 0, 0),
+    ("cond_pad_lm8", dict(dim=64, depth=2, wavenet_layers=2, wavenet_stacks=1, dim_prompt=64, condition_on_prompt=True, num_latents_m=8), 3, 130, 17, 90),
+    ("cond_curtail_proj", dict(dim=64, depth=1, wavenet_layers=2, wavenet_stacks=1, dim_prompt=96, condition_on_prompt=True, num_latents_m=40), 2, 77, 45, 120),
+])
+def test_backward_ragged_and_odd_shapes(tag, kw, b, n, n_p, n_c):
+    """shapes that line up with no tile: one utterance of 50 frames, 333 frames, dim 96, 8 / 40 resampler latents (cross-attention key
+    counts below and beside the 64-key tile), aligned conditioning shorter (zero padded, NS2:990-992) and longer (curtailed) than the
+    latents, dim_prompt != dim (proj_context) -- every gradient against the PyTorch composite"""
+    m = Model(**kw)
+    m.load_state_dict(make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=91))
+    m = m.to(DEV).train()
+    x = make_input("x", (b, n, kw["dim"]), seed=92).to(DEV)
+    t = make_input("times", (b,), seed=92, uniform=True).to(DEV)
+    extra = {}
+    if n_p:
+        extra = dict(prompt=make_input("prompt", (b, n_p, kw["dim_prompt"]), seed=93).to(DEV),
+                     cond=make_input("cond", (b, kw["dim_prompt"], n_c), seed=93).to(DEV), cond_drop_prob=0.)
+    y1, dx1, g1 = _grads(m, m, x, t, **extra)
+    comp = lambda xx, tt, **k: model_forward_autograd(m, xx, tt, **k)          # noqa: E731
+    y0, dx0, g0 = _grads(m, comp, x, t, **extra)
+    _compare("odd_shapes/" + tag, g1, g0, dx1, dx0, y1, y0)
+
+
 def test_stochastic_conditioning_dropout_runs_on_the_hip_path():
     """NS2:79-85, 950-958: 0 < cond_drop_prob < 1 draws a per-utterance mask (training / validation).  Rounds 1-3 sent that call to
     the PyTorch composite; it now runs the HIP training forward (with or without autograd) -- same device RNG stream, same masks"""
