@@ -22,7 +22,7 @@
 // double-buffered (one barrier per K-tile), rows padded to 80 B so that both the 16-B ds_write of the
 // staging pass and the ds_read_b128 fragment reads are bank-conflict free (80 = 5 x 16 B, 5 coprime to the
 // 16 slots of a 256-B bank row).  Tile ids are remapped so that consecutive ids share an XCD L2 (T1).
-#include "gemm_epi.h"
+#include "gemm_epi_fast.h"
 
 namespace ns2 {
 
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     nseq[i] = (g.seq_len > 0) ? (m % g.seq_len) : 0x3fffffff;   // 0x3fffffff: no sequence structure, never shifted
   }
 
-  auto load_stage = [&](Stage<NSPLIT>& st, int kt) {
+  auto load_stage = [&](Stage<NSPLIT>& st, int kt, auto npl) {      // npl: planes staged (1 = the half plane only, p1_half)
     // same K order as gemm2.hip: shifted conv taps tap-minor (L2 reuse of the shifted A rows), then the unshifted taps
     int tap, kin;
     if (kt < g.conv_taps * g.kt_per_tap) { kin = kt / g.conv_taps; tap = kt - kin * g.conv_taps; }
@@ -95,19 +95,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
       const long aoff = (m - shift) * pld(g.lda, ail) + pcol(kcol + skc[i] * 8, ail);
       const long woff = ((long)tn * BN + srow[i]) * pld(g.ldw, wil) + pcol((tap * g.kt_per_tap + kin) * BK + skc[i] * 8, wil);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
+      for (int p = 0; p < decltype(npl)::value; ++p) {
         st.a[p][i] = ok ? ld16(a_pl[p] + aoff) : zero16();
         st.w[p][i] = ld16(w_pl[p] + woff);
       }
     }
   };
-  auto store_stage = [&](const Stage<NSPLIT>& st, int s) {
+  auto store_stage = [&](const Stage<NSPLIT>& st, int s, auto npl) {
     unsigned char* base = smem + s * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int off = srow[i] * ROWB + skc[i] * 16;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
+      for (int p = 0; p < decltype(npl)::value; ++p) {
         *reinterpret_cast<uint4*>(base + p * PLANE + off) = st.a[p][i];
         *reinterpret_cast<uint4*>(base + (NP + p) * PLANE + off) = st.w[p][i];
       }
@@ -139,16 +139,37 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
   // software-pipelined K loop over tiles [kt0, kt1): stage kt+1 is in flight (global -> VGPR) while tile kt
   // is multiplied out of LDS; one barrier per tile.
-  auto run_k = [&](const int kt0, const int kt1) {
+  // half_only (mixed mode, EPI_WAVENET with g.p1_half: the dilated-conv taps of the hybrid plan): ONE IEEE-half product, the
+  // byte half of the operand lines is neither loaded nor staged -- the same arithmetic as gemm2.hip's p1_half phase
+  auto run_k = [&](const int kt0, const int kt1, auto half_only) {
+    constexpr bool HALF1 = decltype(half_only)::value;
+    using NPL = std::integral_constant<int, HALF1 ? 1 : NP>;
     Stage<NSPLIT> st;
-    load_stage(st, kt0);
-    store_stage(st, kt0 & 1);
+    load_stage(st, kt0, NPL{});
+    store_stage(st, kt0 & 1, NPL{});
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
       const bool more = (kt + 1) < kt1;
-      if (more) load_stage(st, kt + 1);
+      if (more) load_stage(st, kt + 1, NPL{});
       const unsigned char* sb = smem + (kt & 1) * STAGE_BYTES;
-      if constexpr (NSPLIT == 2) {
+      if constexpr (NSPLIT == 2 && HALF1) {
+        bf16x8 af[2][2], wf[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc) {
+            af[kc][i] = *reinterpret_cast<const bf16x8*>(sb + a_frag_off + i * 32 * ROWB + kc * 32);
+            wf[kc][i] = *reinterpret_cast<const bf16x8*>(sb + 2 * PLANE + w_frag_off + i * 32 * ROWB + kc * 32);
+          }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            if (ni >= nv) continue;
+            acc[mi][ni] = mma16<true>(af[0][mi], wf[0][ni], acc[mi][ni]);
+            acc[mi][ni] = mma16<true>(af[1][mi], wf[1][ni], acc[mi][ni]);
+          }
+      } else if constexpr (NSPLIT == 2) {
         // mixed mode (see gemm2.hip): 2 x (2x2) half MFMAs + (2x2) fp8 MFMAs of K = 64 per 32-deep tile; plane 1 of the
         // LDS image is the byte half of the line, [h8 x 32 | l8 x 32]
         bf16x8 af[2][2], wf[2][2];
@@ -201,17 +222,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
           }
       }
       }
-      if (more) store_stage(st, (kt + 1) & 1);
+      if (more) store_stage(st, (kt + 1) & 1, NPL{});
       __syncthreads();
     }
   };
 
   if constexpr (EPI == EPI_WAVENET) {
-    run_k(0, g.mid_kt);
-    wavenet_midgate<2, 2>(acc, g, z, row_base, col_base, l31, hi);
-    run_k(g.mid_kt, g.nkt);
+    if constexpr (NSPLIT == 2) {
+      if (g.p1_half) run_k(0, g.mid_kt, std::true_type{});
+      else run_k(0, g.mid_kt, std::false_type{});
+    } else {
+      run_k(0, g.mid_kt, std::false_type{});
+    }
+    // row_base % 64 == 0: with seq_len % 64 == 0 the wave tile lies inside one utterance (gamma / beta once per column)
+    wavenet_midgate<2, 2>(acc, g, z, row_base, col_base, l31, hi, g.seq_len > 0 && (g.seq_len & 63) == 0);
+    run_k(g.mid_kt, g.nkt, std::false_type{});
   } else {
-    run_k(0, g.nkt);
+    run_k(0, g.nkt, std::false_type{});
   }
 
   // Round 3: interior wave tiles of the fp32 epilogue (the SEANet codec's 16 ... 128-channel convolutions run here, 80 k blocks
@@ -250,6 +277,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         *reinterpret_cast<float4*>(g.out_f + z * g.out_f_zs + row * g.ldo_f + col_base + ch * 4) = v;
       }
       return;
+    }
+  }
+  // Round 4: interior wave tiles of the plane-writing epilogues take gemm_epi_fast.h's route too (the dim = 128 model's Wavenet
+  // blocks run here: 2048 blocks per launch whose generic epilogue -- a bounds test, a run-time format switch and a 2 ... 4 byte
+  // store per value -- cost more than their 16 K tiles)
+  if constexpr (EPI == EPI_WAVENET || EPI == EPI_SPLIT) {
+    if (row_base + 64 <= g.M && col_base + 64 <= g.N && (EPI == EPI_WAVENET || g.act == 0) &&
+        (reinterpret_cast<uintptr_t>(g.out_hi) & 15) == 0 && (g.ldo_s & 31) == 0) {
+      constexpr int WBUF = STAGE_BYTES / 2;
+      unsigned char* wbuf = smem + wave * WBUF;
+      auto go = [&](auto pf) __attribute__((always_inline)) {
+        epi_planes_fast<decltype(pf)::value, EPI == EPI_SPLIT, 2, WBUF>(acc, g, z, row_base, col_base, lane, wbuf);
+      };
+      if constexpr (F16) {
+        if (g.out_fmt == FMT_F16 && !g.out_lo) { go(std::integral_constant<int, PF_F16>{}); return; }
+        if (g.out_fmt == FMT_H8) { go(std::integral_constant<int, PF_H8>{}); return; }
+      } else {
+        if (g.out_fmt == FMT_BF16 && g.out_lo) { go(std::integral_constant<int, PF_BF16IL>{}); return; }
+        if constexpr (NSPLIT == 1) { if (g.out_fmt == FMT_BF16 && !g.out_lo) { go(std::integral_constant<int, PF_BF16>{}); return; } }
+      }
     }
   }
   gemm_epilogue<EPI, 2, 2>(acc, g, z, row_base, col_base, tn * 64 + wn * 32, lane);

@@ -102,12 +102,15 @@ NS2_DEVINL void lds_flush_rows(const unsigned char* wbuf, unsigned char* gbase, 
 }
 
 // ---- split planes: EPI_SPLIT (bias; calls with an activation keep the generic path), EPI_WAVENET (biases were applied mid-loop), the q / k part of EPI_QKV
-template <int PF, bool BIAS_ACT>
-NS2_DEVINL void epi_planes_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int z, int row_base, int col_base, int lane, unsigned char* wbuf) {
+// MI = 32-row accumulator tiles of the wave (4: gemm2.hip's 128 x 64 wave tile, 2: gemm.hip's 64 x 64), WBUF = bytes of the wave's
+// private LDS region: the tile leaves in passes of the most rows (a power of two, at least 32) that fit it.
+template <int PF, bool BIAS_ACT, int MI = 4, int WBUF = 18432>
+NS2_DEVINL void epi_planes_fast(f32x16 (&acc)[MI][2], const GemmArgs& g, int z, int row_base, int col_base, int lane, unsigned char* wbuf) {
   using G = PlaneGeom<PF>;
   constexpr int ROWB = 2 * G::bytes_per_col32;            // 64 columns of one row
-  constexpr int RPP = G::il ? 64 : 128;                   // rows per pass (the wave's 18 KiB region)
   constexpr int RS = ROWB + 16;
+  constexpr int RPP = (32 * MI * RS <= WBUF) ? 32 * MI : ((16 * MI * RS <= WBUF) ? 16 * MI : 32);   // rows per pass
+  static_assert(RPP * RS <= WBUF && RPP >= 32 && (32 * MI) % RPP == 0, "the wave's LDS region holds at least one 32-row pass");
   const int l31 = lane & 31, hi = lane >> 5;
   const bool odd = lane & 1;
   float bc[2] = {0.f, 0.f};
@@ -123,7 +126,7 @@ NS2_DEVINL void epi_planes_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int z, i
                          (long)(col_base >> 5) * G::bytes_per_col32;
   RangeTrack rt;
 #pragma unroll
-  for (int pass = 0; pass < 128 / RPP; ++pass) {
+  for (int pass = 0; pass < 32 * MI / RPP; ++pass) {
 #pragma unroll
     for (int mh = 0; mh < RPP / 32; ++mh) {
       const int mi = pass * (RPP / 32) + mh;

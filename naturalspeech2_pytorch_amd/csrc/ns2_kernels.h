@@ -55,7 +55,7 @@ struct GemmArgs {
   int dil; int dil_z;// dilation; if dil_z the effective dilation is dil << blockIdx-z
   int seq_len;       // tokens per utterance (rows never read across an utterance start); 0 = no sequence structure
   int mid_kt;        // EPI_WAVENET: K tile index at which the gate transform runs
-  int p1_half;       // EPI_WAVENET at precision 4, 256x256 kernel: the taps before mid_kt run as ONE half product (no fp8 correction terms)
+  int p1_half;       // EPI_WAVENET at precision 4: the taps before mid_kt run as ONE half product (no fp8 correction terms, the byte half of the lines is not fetched)
   int epi;
   // epilogue operands
   const float* bias; const float* bias2;
