@@ -148,7 +148,7 @@ __device__ __forceinline__ void skinny_body(const float* in, int ld_in, const fl
     for (int e = 0; e < 4; ++e) acc[b][e] = 0.f;
   for (int k0 = kbeg; k0 < kend; k0 += SK_KC) {
     __syncthreads();
-    for (int i = threadIdx.x; i < SK_KC * ROWS; i += 256) {
+    for (int i = threadIdx.x; i < SK_KC * ROWS; i += blockDim.x) {
       const int b = i / SK_KC, k = i - b * SK_KC;          // coalesced along k, conflict-free LDS writes
       float v = 0.f;
       if (b < nb && k0 + k < kend) v = in[(long)(b0 + b) * ld_in + k0 + k];
@@ -193,7 +193,7 @@ __device__ __forceinline__ void skinny_body(const float* in, int ld_in, const fl
   }
   if (j >= J) return;
 #pragma unroll
-  for (int b = 0; b < 32; ++b) {
+  for (int b = 0; b < (ROWS == 1 ? 32 : ROWS); ++b) {
     if (b >= nb) continue;
     float v[4];
 #pragma unroll
@@ -216,13 +216,18 @@ __device__ __forceinline__ void skinny_body(const float* in, int ld_in, const fl
   }
 }
 
+// Launch shapes: "wide" = 256 threads x 4 columns, 32 batch rows per block (the batched conditioning projections: tens of
+// thousands of columns); "narrow" = ONE wave x 4 columns = 256 columns, `rpb` = 8 batch rows per block, for products too small to
+// fill the chip with wide blocks (a single 2048 -> 1024 projection of a training step is 32 wide blocks on 256 CUs, each
+// VALU-bound for ~50 us; as 512 narrow blocks it is a quarter of the FMAs per wave on every CU).  The K split, and with it the
+// order of every sum, is the same in both shapes: results are bit-identical.
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* in, int ld_in, const float* wt, const float* bias,
                                                             float* out, int ld_out, int B, int K, int J, int act,
-                                                            int k_per_split, float* partial) {
+                                                            int k_per_split, float* partial, int rpb) {
   __shared__ __attribute__((aligned(16))) float s_in[32][SK_KC + 4];
-  const int j = blockIdx.x * SK_COLS + threadIdx.x * 4;
-  const int b0 = blockIdx.y * 32;
-  const int nb = min(32, B - b0);
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int b0 = blockIdx.y * rpb;
+  const int nb = min(rpb, B - b0);
   const bool jvec = (j + 3 < J) && ((J & 3) == 0);       // 16-B aligned full group
   const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
   // Round 3: are the batch rows of this block's K range all IDENTICAL?  (The sampler's time conditioning: every utterance of a
@@ -230,11 +235,12 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const float* in, int
   // 8 weight rows the per-row loop is VALU-bound at ~1.9 TB/s of weight streaming.  The FMA order per row is the same in both
   // bodies, so a uniform batch gives every row the single-row result bit for bit.  (NaN != NaN: a NaN row takes the per-row body.)
   int same = 1;
-  for (int i = threadIdx.x; i < (kend - kbeg) * (nb - 1); i += 256) {
+  for (int i = threadIdx.x; i < (kend - kbeg) * (nb - 1); i += blockDim.x) {
     const int b = 1 + i / (kend - kbeg), k = kbeg + i % (kend - kbeg);
     if (in[(long)(b0 + b) * ld_in + k] != in[(long)b0 * ld_in + k]) same = 0;
   }
   if (nb == 1 || __syncthreads_and(same)) skinny_body<1>(in, ld_in, wt, bias, out, ld_out, B, J, act, partial, j, b0, nb, jvec, kbeg, kend, s_in);
+  else if (rpb == 8) skinny_body<8>(in, ld_in, wt, bias, out, ld_out, B, J, act, partial, j, b0, nb, jvec, kbeg, kend, s_in);
   else skinny_body<32>(in, ld_in, wt, bias, out, ld_out, B, J, act, partial, j, b0, nb, jvec, kbeg, kend, s_in);
 }
 
@@ -278,8 +284,13 @@ hipError_t launch_skinny_linear(const float* in, int ld_in, const float* wt, con
   if (plan_B > 0 && nsplit > 1 && (!ws || ws_bytes < (size_t)nsplit * B * J * sizeof(float))) return hipErrorInvalidValue;   // a planned split must not degrade silently
   if (nsplit > 1 && (!ws || ws_bytes < (size_t)nsplit * B * J * sizeof(float))) { nsplit = 1; kps = (K + SK_KC - 1) / SK_KC * SK_KC; }
   float* partial = nsplit > 1 ? ws : nullptr;               // no scratch -> one pass over the whole K (slower, still correct)
-  hipLaunchKernelGGL(skinny_linear_kernel, dim3((J + SK_COLS - 1) / SK_COLS, (B + 31) / 32, nsplit), dim3(256), 0, s, in, ld_in,
-                     wt, bias, out, ld_out, B, K, J, act, kps, partial);
+  const long wide_blocks = (long)((J + SK_COLS - 1) / SK_COLS) * ((B + 31) / 32) * nsplit;
+  if (wide_blocks >= 256)
+    hipLaunchKernelGGL(skinny_linear_kernel, dim3((J + SK_COLS - 1) / SK_COLS, (B + 31) / 32, nsplit), dim3(256), 0, s, in, ld_in,
+                       wt, bias, out, ld_out, B, K, J, act, kps, partial, 32);
+  else
+    hipLaunchKernelGGL(skinny_linear_kernel, dim3((J + 255) / 256, (B + 7) / 8, nsplit), dim3(64), 0, s, in, ld_in,
+                       wt, bias, out, ld_out, B, K, J, act, kps, partial, 8);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || nsplit == 1) return e;
   const long n = (long)B * J;

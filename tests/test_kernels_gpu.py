@@ -404,8 +404,12 @@ def test_rmsnorm_zero_row():
     assert of.abs().max().item() == 0.0                            # F.normalize eps clamp, no NaN
 
 
-@pytest.mark.parametrize("B,K,J,act", [(32, 2048, 3000, 0), (4, 513, 2048, 1), (40, 100, 70, 1), (1, 4096, 1024, 0)])
+@pytest.mark.parametrize("B,K,J,act", [(32, 2048, 3000, 0), (4, 513, 2048, 1), (40, 100, 70, 1), (1, 4096, 1024, 0),
+                                       (32, 2048, 40000, 0),                       # the "wide" launch shape (>= 256 blocks of 1024 columns)
+                                       (32, 2048, 1024, 0), (32, 1024, 2048, 0), (1024, 32, 2048, 0), (13, 64, 260, 1)])   # training roles: y, dx, dW
 def test_skinny_linear(B, K, J, act):
+    """elementwise.hip: wide blocks (256 threads x 4 columns x 32 rows) when they fill the chip, else one-wave blocks of 256
+    columns x 8 rows; the K split (so every sum's order) is the same in both."""
     x = rnd(B, K, seed=29)
     w = rnd(J, K, seed=30, scale=1 / math.sqrt(K))
     b = rnd(J, seed=31)
