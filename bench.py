@@ -523,6 +523,52 @@ def main():
                                     roofline=dict(frac=r2["frac"], achieved=r2["achieved"], unit="TFLOP/s", kernel=r2["kernel"]) if r2 else None)
         del m2, sd2
         torch.cuda.empty_cache()
+        # --- small batches (BASELINE config 3 is stated at b = 4, config 1 samples b = 1): a step of 1 / 4 utterances has 8 ... 100
+        #     output tiles per GEMM on 256 CUs; the executor lends workspace scratch and the long-K products run split-K (gemm.hip
+        #     launch_gemm_splitk).  The same steps with the split switched off (ns2_debug_force_gemm(3)) are timed beside it.
+        def small_batch(model, b, conditioned):
+            model.precision = args.precision
+            g = torch.Generator().manual_seed(300)
+            audio = torch.randn(b, N, 512, generator=g).to(dev)
+            kw = dict(prompt=torch.randn(b, 103, 512, generator=g).to(dev), cond=torch.randn(b, 512, N, generator=g).to(dev)) if conditioned else {}
+            ts = torch.linspace(1.0, 0.0, 31)
+            out = {}
+            with torch.no_grad():
+                tab = model.time_table(ts[:30].to(dev), b)
+                tcur = [ts[i].expand(b).contiguous().to(dev) for i in range(31)]
+                for label, force in (("ms_per_step", 0), ("ms_per_step_without_split_k", 3)):
+                    lib.ns2_debug_force_gemm(force)
+                    try:
+                        x = audio.clone()
+                        for i in range(30):
+                            if i == 10:
+                                torch.cuda.synchronize()
+                                t0 = time.perf_counter()
+                            o = model.forward_with_cond_scale(x, None, cond_scale=1.0, cond_row=tab[i], **kw)
+                            ops.ddim_step(x, o, tcur[i], tcur[i + 1], "v", "sigmoid", 1.0, out=x)
+                        torch.cuda.synchronize()
+                        out[label] = round(1e3 * (time.perf_counter() - t0) / 20, 3)
+                    finally:
+                        lib.ns2_debug_force_gemm(0)
+            out["utterance_steps_per_s"] = round(b * 1e3 / out["ms_per_step"], 1)
+            return out
+
+        try:
+            sb = {}
+            mu = make_model(512, 12, False)
+            sdu = {k: v.detach().cpu() for k, v in mu.state_dict().items()}
+            sb["d512_L12_b1x1024"] = small_batch(mu, 1, False)
+            sb["d512_L12_b4x1024"] = small_batch(mu, 4, False)
+            sb["live_rel_err_vs_fp32_oracle_b1x256"] = live_parity(mu, sdu, args.precision)      # a split-K forward
+            del mu, sdu
+            mc = make_model(512, 12, True)
+            sb["config3_conditioned_b4x1024"] = small_batch(mc, 4, True)
+            del mc
+            sb["precision"] = args.precision
+            side["small_batch"] = sb
+        except Exception as e:                                        # report, do not fail the line
+            side["small_batch"] = dict(skipped=f"{type(e).__name__}: {e}")
+        torch.cuda.empty_cache()
         # --- one WARM training step (NaturalSpeech2.forward loss, NS2:1635-1666 + loss.backward(), NS2:1886 + Adam) on the
         #     HIP training path (training.py: forward and backward kernels of libns2hip, bf16 x3 arithmetic) at BASELINE config 1's
         #     training shape and at the headline shape; the PyTorch composite (fp32 torch ops on the same GPU) timed beside it

@@ -48,8 +48,17 @@ extern "C" {
 
 const char* ns2_last_error(void);
 int ns2_version(void);
-/* test hook: force the GEMM kernel variant (0 = dispatch by shape, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA) */
+/* test hook: force the GEMM kernel variant (0 = dispatch by shape, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA,
+ * 3 = dispatch by shape but never split K) */
 int ns2_debug_force_gemm(int kernel);
+/* Split-K of small products.  ns2_model_forward* lend a region of their workspace to every GEMM of the pass: a product with too
+ * few output tiles to fill the chip runs as K slices into fixed slots plus a second launch that adds the slots in order and
+ * applies the epilogue (deterministic).  The stand-alone GEMM entry points below have no workspace argument and never split --
+ * unless a test lends scratch to the calling host thread here: `scratch` = device memory of at least
+ * ns2_splitk_scratch_bytes() bytes, used by every following stand-alone GEMM call of this thread until cleared with
+ * (NULL, 0).  Test hook: the caller keeps the memory alive and the calls stream-ordered. */
+int64_t ns2_splitk_scratch_bytes(void);
+int ns2_debug_lend_splitk_scratch(void* scratch, int64_t bytes);
 
 /* ------------------------------------------------------------------ packed weights (library-owned) */
 typedef struct ns2_weight ns2_weight;

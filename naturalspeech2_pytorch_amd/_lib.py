@@ -48,6 +48,8 @@ SIGNATURES = {
     "ns2_last_error": (c_char_p, []),
     "ns2_version": (I, []),
     "ns2_debug_force_gemm": (I, [I]),
+    "ns2_splitk_scratch_bytes": (L, []),
+    "ns2_debug_lend_splitk_scratch": (I, [P, L]),
     "ns2_weight_pack": (I, [P, I, I, I, I, P, I, POINTER(c_void_p), P]),
     "ns2_weight_free": (None, [P]),
     "ns2_split_f32": (I, [P, I, I, I, P, P, I, I, P]),

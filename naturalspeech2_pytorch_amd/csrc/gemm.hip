@@ -65,6 +65,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   const bf16_t* a_pl[2] = {g.a_hi + azo, g.a_lo + azo};
   const bf16_t* w_pl[2] = {g.w_hi + wzo, g.w_lo + wzo};
   const int dil = g.dil_z ? (g.dil << z) : g.dil;
+  // split-K slice (GemmArgs::ksplit; operands are not offset per z then): K tiles [kin0, kin0 + kpt) of every tap
+  const int kin0 = g.ksplit > 0 ? z * g.ksplit : 0;
+  const int kpt = g.ksplit > 0 ? min(g.ksplit, g.kt_per_tap - kin0) : g.kt_per_tap;
+  const int nkt = g.ksplit > 0 ? (g.nkt / g.kt_per_tap) * kpt : g.nkt;
 
   // ---- staging coordinates (2 chunks of 16 B per plane per thread)
   int srow[2], skc[2], nseq[2];
@@ -82,8 +86,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   auto load_stage = [&](Stage<NSPLIT>& st, int kt, auto npl) {      // npl: planes staged (1 = the half plane only, p1_half)
     // same K order as gemm2.hip: shifted conv taps tap-minor (L2 reuse of the shifted A rows), then the unshifted taps
     int tap, kin;
-    if (kt < g.conv_taps * g.kt_per_tap) { kin = kt / g.conv_taps; tap = kt - kin * g.conv_taps; }
-    else { tap = kt / g.kt_per_tap; kin = kt - tap * g.kt_per_tap; }
+    if (kt < g.conv_taps * kpt) { kin = kt / g.conv_taps; tap = kt - kin * g.conv_taps; }
+    else { tap = kt / kpt; kin = kt - tap * kpt; }
+    kin += kin0;
     const int kcol = kin * BK;
     const int pl = g.pad_left < 0 ? g.conv_taps - 1 : g.pad_left;        // causal: all padding on the left (NS2:583-595)
     const int shift = (tap < g.conv_taps) ? (pl - tap) * dil : 0;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     wavenet_midgate<2, 2>(acc, g, z, row_base, col_base, l31, hi, g.seq_len > 0 && (g.seq_len & 63) == 0);
     run_k(g.mid_kt, g.nkt, std::false_type{});
   } else {
-    run_k(0, g.nkt, std::false_type{});
+    run_k(0, nkt, std::false_type{});
   }
 
   // Round 3: interior wave tiles of the fp32 epilogue (the SEANet codec's 16 ... 128-channel convolutions run here, 80 k blocks
@@ -326,6 +331,115 @@ static hipError_t launch_epi(const GemmArgs& g, hipStream_t s) {
     case EPI_WAVENET: return launch_one<NSPLIT, EPI_WAVENET, F16>(g, s);
   }
   return hipErrorInvalidValue;
+}
+
+// ---- split-K, second launch: the slots of the first launch (raw fp32 partial sums, [S][M][ldp]) are added in slot order in
+// the accumulator layout of a 64 x 64 wave tile, then the REQUESTED epilogue runs on the sums -- the same device code the
+// one-launch product would have run (gemm_epi.h), so every format, bias, residual, V^T and range-guard rule holds unchanged.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmArgs g, const float* part, int S, long slot, int ldp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+  const int ntn = (g.N + BN - 1) / BN;
+  const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
+  const int row_base = tm * BM + wm * 64, col_base = tn * BN + wn * 64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      // unconditional loads from clamped addresses: the 16 loads of a slot are in flight together (a bounds branch per value
+      // serialised them: 64 x S dependent round trips, 85-200 us per launch); invalid positions are zeroed afterwards
+      const int col = col_base + ni * 32 + l31;
+      const bool cok = col < g.N;
+      const float* pc = part + min(col, g.N - 1);
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = 0.f;
+      for (int sl = 0; sl < S; ++sl) {
+        float l[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.M - 1);
+          l[r] = pc[sl * slot + (long)row * ldp];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] += l[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        acc[mi][ni][r] = (cok && row < g.M) ? t[r] : 0.f;
+      }
+    }
+  if constexpr (EPI == EPI_SPLIT) {
+    // interior wave tiles: the LDS-staged plane epilogue (gemm_epi_fast.h), as in the one-launch kernel
+    __shared__ __attribute__((aligned(16))) unsigned char fin_lds[4 * 9216];              // 32-row passes
+    if (row_base + 64 <= g.M && col_base + 64 <= g.N && g.act == 0 && (reinterpret_cast<uintptr_t>(g.out_hi) & 15) == 0 &&
+        (g.ldo_s & 31) == 0) {
+      unsigned char* wbuf = fin_lds + wave * 9216;
+      if (g.out_fmt == FMT_F16 && !g.out_lo) { epi_planes_fast<PF_F16, true, 2, 9216>(acc, g, 0, row_base, col_base, lane, wbuf); return; }
+      if (g.out_fmt == FMT_H8) { epi_planes_fast<PF_H8, true, 2, 9216>(acc, g, 0, row_base, col_base, lane, wbuf); return; }
+      if (g.out_fmt == FMT_BF16 && g.out_lo) { epi_planes_fast<PF_BF16IL, true, 2, 9216>(acc, g, 0, row_base, col_base, lane, wbuf); return; }
+    }
+  }
+  gemm_epilogue<EPI, 2, 2>(acc, g, 0, row_base, col_base, tn * 64 + wn * 32, lane);
+}
+
+// EPI_F32 needs no accumulator layout: one thread per 4 adjacent columns, 16-byte loads of every slot / the residual, 16-byte
+// store.  The same operation order per value as gemm_epilogue<EPI_F32>: (sum + bias) -> activation -> + residual.
+__global__ __launch_bounds__(256) void splitk_finish_f32_kernel(const float* part, int S, long slot, int ldp, int M, int N, const float* bias,
+                                                                const float* resid, int ldr, int act, float* out, int ldo) {
+  const int n4 = N >> 2;                                       // N % 4 == 0 (checked by the launcher)
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)M * n4) return;
+  const int row = (int)(idx / n4), c = (int)(idx - (long)row * n4) * 4;
+  const float* p = part + (long)row * ldp + c;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sl = 0; sl < S; ++sl) {
+    const float4 t = *reinterpret_cast<const float4*>(p + sl * slot);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  if (bias) { v.x += bias[c]; v.y += bias[c + 1]; v.z += bias[c + 2]; v.w += bias[c + 3]; }
+  if (act) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
+  if (resid) {
+    const float4 r = *reinterpret_cast<const float4*>(resid + (long)row * ldr + c);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  *reinterpret_cast<float4*>(out + (long)row * ldo + c) = v;
+}
+
+hipError_t launch_gemm1(const GemmArgs& g, int precision, hipStream_t s);
+// g: validated by launch_gemm, formats resolved; S slices of c K tiles per tap
+hipError_t launch_gemm_splitk(const GemmArgs& g, int precision, int S, int c, hipStream_t s) {
+  const int ldp = (g.N + 63) & ~63;
+  const long slot = (long)g.M * ldp;
+  if (!g.sk_ws || S < 2 || c < 1 || S * slot > g.sk_ws_floats || g.epi == EPI_WAVENET || g.nz > 1) return hipErrorInvalidValue;
+  GemmArgs p = g;
+  p.epi = EPI_F32; p.bias = nullptr; p.bias2 = nullptr; p.resid = nullptr; p.act = 0; p.film = nullptr;
+  p.out_f = g.sk_ws; p.ldo_f = ldp; p.out_f_zs = slot;
+  p.out_hi = nullptr; p.out_lo = nullptr; p.vt_hi = nullptr; p.vt_lo = nullptr;
+  p.nz = S; p.a_zs = 0; p.w_zs = 0; p.dil_z = 0; p.ksplit = c;
+  hipError_t e = launch_gemm1(p, precision, s);
+  if (e != hipSuccess) return e;
+  const int grid = ((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM);
+  switch (g.epi) {
+    case EPI_F32:
+      if ((g.N & 3) == 0 && (g.ldo_f & 3) == 0 && (reinterpret_cast<uintptr_t>(g.out_f) & 15) == 0 &&
+          (!g.resid || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.resid) & 15) == 0))) {
+        const long n = (long)g.M * (g.N >> 2);
+        hipLaunchKernelGGL(splitk_finish_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g.sk_ws, S, slot, ldp, g.M, g.N,
+                           g.bias, g.resid, g.ldr, g.act, g.out_f, g.ldo_f);
+      } else {
+        hipLaunchKernelGGL(splitk_finish_kernel<EPI_F32>, dim3(grid), dim3(256), 0, s, g, g.sk_ws, S, slot, ldp);
+      }
+      break;
+    case EPI_SPLIT: hipLaunchKernelGGL(splitk_finish_kernel<EPI_SPLIT>, dim3(grid), dim3(256), 0, s, g, g.sk_ws, S, slot, ldp); break;
+    case EPI_QKV: hipLaunchKernelGGL(splitk_finish_kernel<EPI_QKV>, dim3(grid), dim3(256), 0, s, g, g.sk_ws, S, slot, ldp); break;
+    case EPI_GEGLU: hipLaunchKernelGGL(splitk_finish_kernel<EPI_GEGLU>, dim3(grid), dim3(256), 0, s, g, g.sk_ws, S, slot, ldp); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_gemm1(const GemmArgs& g, int precision, hipStream_t s) {      // formats already validated by launch_gemm

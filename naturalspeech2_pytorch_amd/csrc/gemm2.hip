@@ -891,6 +891,7 @@ static hipError_t launch2_epi(const GemmArgs& g, hipStream_t s) {
 }
 
 hipError_t launch_gemm1(const GemmArgs& g, int precision, hipStream_t s);   // gemm.hip (128x128 register-staged kernel)
+hipError_t launch_gemm_splitk(const GemmArgs& g, int precision, int S, int c, hipStream_t s);   // gemm.hip: K slices + finish launch
 
 // Test hook (ns2_debug_force_gemm / NS2_GEMM): the only switch of the GEMM family, process-wide by design, atomic so that two
 // host threads (one per device) may read it while a test flips it.  -1: read NS2_GEMM once; 0 auto; 1 / 2 force a kernel.
@@ -926,7 +927,25 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
       !planes_ok(g.vt_hi, g.vt_lo))
     return hipErrorInvalidValue;
   const int f = forced_kernel();
-  const bool big = (f == 2) || (f != 1 && g.N > 128);
+  // Small products (a batch of 1 ... 4 utterances): a handful of output tiles, each a long serial K loop on one CU while the
+  // other CUs idle.  With scratch lent by the caller, split K over enough slices for ~2-4 blocks per CU (at least 4 K tiles of
+  // every tap per slice); fixed slots, fixed order of the sums.  (f == 3: automatic kernel choice, never split -- A/B hook.)
+  if (f == 0 && g.sk_ws && g.epi != EPI_WAVENET && g.nz <= 1 && !g.dil_z && g.ksplit == 0) {
+    const long tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    // ... and a K loop long enough to pay for the second launch: K >= 768.  Measured at 1 x 1024 frames (tools/exp_small_m_kernel.py):
+    // the FF causal conv (K = 4128) 114 -> 67 us, FF-out (K = 1376) 71 -> 26 us; K = 512 products break even or lose.
+    if (tiles < 256 && g.kt_per_tap >= 8 && g.nkt >= 24) {   // fewer 128 x 128 tiles than CUs
+      const int want = (int)std::min<long>(512 / tiles, g.kt_per_tap / 4);
+      if (want >= 2) {
+        const int c = (g.kt_per_tap + want - 1) / want, S = (g.kt_per_tap + c - 1) / c;
+        if (S >= 2 && (long)S * g.M * ((g.N + 63) & ~63) <= g.sk_ws_floats) return launch_gemm_splitk(g, precision, S, c, s);
+      }
+    }
+  }
+  // a product that would put at most 64 blocks of 256 x 256 on the 256 CUs runs on the 128 x 128 kernel (4 x the blocks, a
+  // quarter of the serial work each): 1 x 1024-frame steps measured 4 % faster with it, 4 x 1024 slower (exp_small_m_kernel.py)
+  const long blocks256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.nz > 0 ? g.nz : 1);
+  const bool big = (f == 2) || (f != 1 && g.N > 128 && !((f == 0 || f == 3) && blocks256 <= 64));
   if (!big) return launch_gemm1(g, precision, s);
   switch (precision) {
     case 3: return launch2_epi<3, false>(g, s);

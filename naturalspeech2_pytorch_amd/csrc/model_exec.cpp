@@ -215,9 +215,26 @@ int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, 
 }
 
 // ------------------------------------------------------------------------------------------------ GEMM call helpers
+// Split-K scratch of the forward that is being enqueued on THIS host thread (ns2_kernels.h GemmArgs::sk_ws): a region of the
+// caller's workspace, lent to every product of the pass by SplitKScope and gone when the entry point returns -- not library state.
+static thread_local float* tl_sk_ws = nullptr;
+struct SplitKScope {
+  float* prev;
+  explicit SplitKScope(float* ws) : prev(tl_sk_ws) { tl_sk_ws = ws; }
+  ~SplitKScope() { tl_sk_ws = prev; }
+  SplitKScope(const SplitKScope&) = delete;
+  SplitKScope& operator=(const SplitKScope&) = delete;
+};
+extern "C" int64_t ns2_splitk_scratch_bytes(void) { return SPLITK_SCRATCH_FLOATS * (int64_t)sizeof(float); }
+extern "C" int ns2_debug_lend_splitk_scratch(void* scratch, int64_t bytes) {
+  if (scratch && bytes < ns2_splitk_scratch_bytes()) { set_error("ns2_debug_lend_splitk_scratch: scratch smaller than ns2_splitk_scratch_bytes()"); return NS2_ERR_ARG; }
+  tl_sk_ws = static_cast<float*>(scratch);
+  return NS2_OK;
+}
 static GemmArgs base_args(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  g.sk_ws = tl_sk_ws; g.sk_ws_floats = tl_sk_ws ? SPLITK_SCRATCH_FLOATS : 0;
   g.a_hi = a_hi; g.a_lo = a_lo; g.lda = lda;
   g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk;
   g.M = M; g.N = w.N; g.nkt = w.nkt; g.kt_per_tap = w.nkt; g.conv_taps = 0; g.dil = 1; g.mid_kt = -1;
@@ -550,6 +567,7 @@ static Planes take_planes(Carver& c, int64_t n, bool il, int fmt) {
 struct Work {
   float *tfeat, *t, *condall, *xres, *tmp_f;
   float* skinny_ws; size_t skinny_ws_bytes;     // split-K partial sums of the conditioning projections (caller-owned)
+  float* sk_ws;                                 // split-K slots of the small-batch GEMMs (SPLITK_SCRATCH_FLOATS, ns2_kernels.h)
   Planes xs, h0, wA, wB, ssum, xn, qk, vt, o, ffh, ffc;
   Planes xq;               // cross-attention queries [M, a] in the cross-attention operand format: a view of qk's memory
   Planes ffh_conv;         // the FF conv's input: ffh itself, or (precision 5) a dense IEEE-half view of the same memory
@@ -578,6 +596,7 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
                                 std::max(skinny_linear_workspace_bytes(B, dim + 1, m->dt),
                                          skinny_linear_workspace_bytes(B, std::max(m->cfg.dim_prompt, 1), m->dt)));
   w->skinny_ws = c.take<float>((int64_t)(w->skinny_ws_bytes / sizeof(float)));
+  w->sk_ws = c.take<float>(SPLITK_SCRATCH_FLOATS);
   w->xres = c.take<float>(M * dim);
   w->xs = take_planes(c, M * dp, il, f16);
   w->h0 = take_planes(c, M * dp, il, f16);
@@ -709,6 +728,7 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
   hipStream_t s = (hipStream_t)stream;
   Work w;
   if (carve_work(m, &w, workspace, workspace_bytes, B, N, n_prompt, n_cond) > workspace_bytes) { set_error("workspace too small"); return NS2_ERR_ARG; }
+  SplitKScope sk_scope(w.sk_ws);
   CondState cs;
   carve_cond(m, &cs, cond_state, 0, B, N, n_cond);
   const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, Lm = m->Lm, H = m->cfg.heads;
@@ -840,6 +860,7 @@ static int forward_impl(ns2_model* m, const float* x, const float* times, const 
   hipStream_t s = (hipStream_t)stream;
   Work w;
   if (carve_work(m, &w, workspace, workspace_bytes, B, N, 0, 0) > workspace_bytes) { set_error("workspace too small"); return NS2_ERR_ARG; }
+  SplitKScope sk_scope(w.sk_ws);
   CondState cs;
   if (cond) carve_cond(m, &cs, const_cast<void*>(cond_state), 0, B, N, n_cond);
   const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, L = m->L, S = m->S, H = m->cfg.heads, prec = op_precision(m->cfg.precision);

@@ -73,12 +73,20 @@ struct GemmArgs {
                      // bf16 planes for 1 / 3, dense IEEE half for 2, FMT_H8 for 4.  Attention operands (q, k: EPI_QKV
                      // columns < split_col, the cross-attention q projection) are IEEE half also at precision 4.
   int vt_fmt;        // PlaneFmt of the transposed value planes (FMT_BF16 or FMT_F16); -1 = the attention format of the precision
+  // Split-K for products too small to fill the chip (a batch of 1 ... 4 utterances: 8 ... 100 output tiles on 256 CUs, each a
+  // serial K loop).  The caller lends scratch (sk_ws: fp32, sk_ws_floats elements; null = never split); launch_gemm then runs
+  // the 128x128 kernel over grid-z K slices writing raw fp32 partial sums into fixed slots and a second launch that adds the
+  // slots in slot order and applies the requested epilogue -- deterministic.  ksplit is set by launch_gemm: K tiles of EVERY tap
+  // one slice covers (slice z: input columns [z * ksplit * 32, ...) of each tap); 0 = the plain launch.
+  float* sk_ws; long sk_ws_floats;
+  int ksplit;
 };
 
 // precision: 3 = bf16 x3 ("exact"), 1 = bf16 ("fast"), 2 = one IEEE-half product ("half"), 4 = half product + both
 // first-order correction terms on the fp8 MFMA ("mixed", FMT_H8 operands).  Dispatches gemm.hip / gemm2.hip by shape.
 hipError_t launch_gemm(const GemmArgs& g, int precision, hipStream_t s);
-void force_gemm_kernel(int k);                                          // 0 auto, 1 = 128x128, 2 = 256x256 (test hook)
+void force_gemm_kernel(int k);                                          // 0 auto, 1 = 128x128, 2 = 256x256, 3 = auto without split-K (test hook); a forced kernel never splits K
+constexpr long SPLITK_SCRATCH_FLOATS = 512L * 128 * 128;                // what any split needs at most: slices x output tiles <= 512 tiles of 128 x 128 (32 MiB)
 
 // flash attention forward, head dim 64, non-causal (ATT:77-155 hot path)
 struct AttnArgs {

@@ -45,13 +45,24 @@ def asplit(x, prec, ldo=None):
     return ops.split(x, ldo=ldo, precision=2 if prec == 4 else prec)
 
 
-@pytest.fixture(params=[1, 2], ids=["gemm128", "gemm256"])
+@pytest.fixture(params=[1, 2, 0], ids=["gemm128", "gemm256", "splitk"])
 def gemm_kernel(request):
-    """run every GEMM-family test on both kernels (gemm.hip 128x128 register-staged, gemm2.hip 256x256 LDS-DMA)."""
+    """run every GEMM-family test on both kernels (gemm.hip 128x128 register-staged, gemm2.hip 256x256 LDS-DMA) and, third, with
+    the automatic dispatch plus split-K scratch lent to this thread (ns2_debug_lend_splitk_scratch): these shapes are all "small
+    products", so whatever has >= 8 K tiles per tap runs as K slices + the finishing launch (gemm.hip launch_gemm_splitk)."""
     from naturalspeech2_pytorch_amd import _lib
-    _lib.check(_lib.load().ns2_debug_force_gemm(request.param))
+    lib = _lib.load()
+    _lib.check(lib.ns2_debug_force_gemm(request.param))
+    scratch = None
+    if request.param == 0:
+        n = int(lib.ns2_splitk_scratch_bytes())
+        scratch = torch.full((n // 4,), float("nan"), device=DEV)                    # a slot read before it is written shows
+        _lib.check(lib.ns2_debug_lend_splitk_scratch(scratch.data_ptr(), n))
     yield request.param
-    _lib.load().ns2_debug_force_gemm(0)
+    torch.cuda.synchronize()
+    lib.ns2_debug_lend_splitk_scratch(None, 0)
+    lib.ns2_debug_force_gemm(0)
+    del scratch
 
 
 def test_split_join_roundtrip():
@@ -113,7 +124,9 @@ def conv_ref(x_bnc, w, b, dil):
 @pytest.mark.parametrize("B,N,Cin,Cout,dil", [(3, 200, 96, 80, 1), (2, 300, 100, 100, 4), (2, 1024, 64, 64, 128), (1, 50, 170, 170, 1),
                                               # utterances aligned to the 256-row tile, dilation 1: the tap-shared path of the 256x256
                                               # kernel (split epilogue), incl. an odd number of 32-blocks per tap and several column tiles
-                                              (2, 512, 170, 200, 1), (3, 256, 96, 300, 1), (1, 768, 100, 100, 1)])
+                                              (2, 512, 170, 200, 1), (3, 256, 96, 300, 1), (1, 768, 100, 100, 1),
+                                              # >= 8 K tiles per tap: split-K candidates (uneven slices: 11 tiles as 6 + 5)
+                                              (2, 384, 352, 341, 1), (1, 300, 512, 200, 2)])
 def test_causal_conv(B, N, Cin, Cout, dil, prec, gemm_kernel):
     x = rnd(B * N, Cin, seed=6)
     w = rnd(Cout, Cin, 3, seed=7, scale=1 / math.sqrt(3 * Cin))
@@ -217,7 +230,7 @@ def test_embedding_padding_ids():
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("M,K,f", [(256, 64, 170), (500, 128, 341), (1024, 512, 1365)])
+@pytest.mark.parametrize("M,K,f", [(256, 64, 170), (500, 128, 341), (1024, 512, 1365), (300, 1024, 170)])      # K = 1024: a split-K candidate
 def test_geglu(M, K, f, prec, gemm_kernel):
     x = rnd(M, K, seed=9)
     w = rnd(2 * f, K, seed=10, scale=1 / math.sqrt(K))
@@ -235,7 +248,7 @@ def test_geglu(M, K, f, prec, gemm_kernel):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("B,N,K", [(2, 200, 64), (3, 135, 128), (2, 1024, 512)])
+@pytest.mark.parametrize("B,N,K", [(2, 200, 64), (3, 135, 128), (2, 1024, 512), (2, 256, 1024), (1, 200, 1024)])   # K = 1024: split-K candidates (fast / generic V^T)
 def test_qkv(B, N, K, prec, gemm_kernel):
     a_dim = 512
     x = rnd(B * N, K, seed=12)

@@ -209,3 +209,38 @@ def test_baseline_config1_waveform_is_pinned_numerically():
         assert res[precision] < ceil, res
         del m, d
     record("config1_readme_at_size/waveform_vs_oracle_ddim_plus_hf_decoder", res)
+
+
+@pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("hybrid", 2e-4)])
+@pytest.mark.parametrize("kw,b,n", [(dict(dim=512, depth=2), 1, 256), (dict(dim=512, depth=1), 2, 300), (dict(dim=128, depth=2), 1, 1024),
+                                    (dict(dim=512, depth=1, dim_prompt=512, condition_on_prompt=True), 2, 200)])
+def test_small_batches_split_k(kw, b, n, precision, tol):
+    """A forward of 1 ... 4 utterances has 8 ... 100 output tiles per GEMM on 256 CUs.  ns2_model_forward lends a region of its
+    workspace to the GEMMs, which then run as K slices into fixed slots + a finishing launch that adds the slots in order and
+    applies the epilogue (gemm.hip launch_gemm_splitk).  Against the same forward with the split switched off
+    (ns2_debug_force_gemm(3)): same values up to the order of the fp32 sums; against the oracle: the mode's tolerance; twice:
+    the same bits."""
+    from naturalspeech2_pytorch_amd import _lib
+    lib = _lib.load()
+    m, sd = _model(kw, 91, precision)
+    d = kw["dim"]
+    x = make_input("x", (b, n, d), seed=92).to(DEV)
+    t = make_input("times", (b,), seed=93).to(DEV)
+    extra = {}
+    if kw.get("condition_on_prompt"):
+        extra = dict(prompt=make_input("prompt", (b, 40, d), seed=94).to(DEV), cond=make_input("cond", (b, d, n), seed=95).to(DEV))
+    with torch.no_grad():
+        y = m(x, t, **extra)
+        y_again = m(x, t, **extra)
+        try:
+            _lib.check(lib.ns2_debug_force_gemm(3))
+            y_plain = m(x, t, **extra)
+        finally:
+            lib.ns2_debug_force_gemm(0)
+    assert torch.equal(y, y_again)
+    assert not torch.equal(y, y_plain), "the split path was not taken"
+    assert rel(y, y_plain) < tol, rel(y, y_plain)
+    ref = O.model_forward(sd, x.cpu(), t.cpu(), **{k: v.cpu() for k, v in extra.items()})
+    e = rel(y, ref)
+    record(f"small_batch_split_k/{precision}/d{d}_L{kw['depth']}_b{b}_n{n}{'_cond' if extra else ''}", e)
+    assert e < (2e-5 if precision == "exact" else 5e-4)

@@ -1,10 +1,6 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-.}"
-O=gpurun_out/r4n; mkdir -p $O
-L=$PWD/naturalspeech2_pytorch_amd/libns2hip_noslp.so
-for rep in 1 2 3; do
-  NS2_LIB=$L python tools/bench_attention.py >> $O/att_noslp.txt 2>/dev/null
-  python tools/bench_attention.py >> $O/att_slp.txt 2>/dev/null
-done
-NS2_LIB=$L timeout 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k attention > $O/t.txt 2>&1; tail -1 $O/t.txt
-echo NOSLP; cat $O/att_noslp.txt; echo SLP; cat $O/att_slp.txt
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r4n; rm -rf $O; mkdir -p $O
+cd $R
+python tools/exp_small_m_kernel.py 2>/dev/null | tee $O/small_batch.json
+timeout 900 python -m pytest tests/test_model_gpu.py tests/test_round4_gpu.py -q -m gpu --tb=short -x 2>&1 | tail -4
