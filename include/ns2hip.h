@@ -21,7 +21,9 @@
  *     (ns2_*_workspace_bytes), constants live in per-device __device__ storage, so one host thread per device (or one
  *     process per device) may drive several devices concurrently, also under stream capture.  What it does keep, all of it
  *     write-once or atomic: per-device "attribute raised" / occupancy answers, the environment switches NS2_GEMM,
- *     NS2_LSTM_PERSISTENT and NS2_LSTM_FUSED (read once per process), and the test hooks ns2_debug_*.
+ *     NS2_LSTM_PERSISTENT and NS2_LSTM_FUSED (read once per process), and the test hooks ns2_debug_*.  One thread-local
+ *     pointer exists for the duration of a ns2_model_forward* / ns2_model_prepare_cond call: the split-K region of the
+ *     workspace that call was given (set on entry, restored on return).
  *   - layout of a split-plane matrix (x_hi, x_lo, ld): `ld` is the LOGICAL column count, a multiple of 32.
  *     x_lo != NULL: ONE bf16 buffer [rows, 2*ld]; every 32 logical columns occupy a 128-byte line [hi(32) | lo(32)],
  *       i.e. element (r, c) has hi at r*2*ld + ((c & ~31) << 1) + (c & 31) and lo 32 elements further; the caller
