@@ -39,6 +39,55 @@ struct Stage {                                // registers holding one prefetche
 NS2_DEVINL uint4 ld16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 NS2_DEVINL uint4 zero16() { return make_uint4(0u, 0u, 0u, 0u); }
 
+// Interior 64 x 64 wave tile (every row and column valid): the streamlined epilogues of gemm_epi_fast.h through `wbuf`, the wave's
+// private LDS region of WBUF bytes.  Returns false when the tile, the alignment or the format asks for the generic path.
+// HALF / BF: which plane formats this caller can be asked for (a kernel on IEEE-half operands writes F16 / H8, one on bf16 operands
+// bf16 planes; the split-K finishing kernel serves both).
+template <int EPI, int WBUF, bool HALF, bool BF, bool BF_DENSE>
+NS2_DEVINL bool small_tile_fast_epilogue(f32x16 (&acc)[2][2], const GemmArgs& g, int z, int row_base, int col_base, int ocol_base, int lane,
+                                         unsigned char* wbuf) {
+  if constexpr (EPI == EPI_F32) return false;
+  if (row_base + 64 > g.M) return false;
+  const bool al = (reinterpret_cast<uintptr_t>(g.out_hi) & 15) == 0 && (g.ldo_s & 31) == 0;
+  auto planes = [&](auto&& fn) __attribute__((always_inline)) {
+    if (!al) return false;
+    if constexpr (HALF) {
+      if (g.out_fmt == FMT_F16 && !g.out_lo) { fn(std::integral_constant<int, PF_F16>{}); return true; }
+      if (g.out_fmt == FMT_H8) { fn(std::integral_constant<int, PF_H8>{}); return true; }
+    }
+    if constexpr (BF) {
+      if (g.out_fmt == FMT_BF16 && g.out_lo) { fn(std::integral_constant<int, PF_BF16IL>{}); return true; }
+    }
+    if constexpr (BF_DENSE) {
+      if (g.out_fmt == FMT_BF16 && !g.out_lo) { fn(std::integral_constant<int, PF_BF16>{}); return true; }
+    }
+    return false;
+  };
+  if constexpr (EPI == EPI_SPLIT) {
+    if (col_base + 64 <= g.N && g.act == 0)
+      return planes([&](auto pf) __attribute__((always_inline)) { epi_planes_fast<decltype(pf)::value, true, 2, WBUF>(acc, g, z, row_base, col_base, lane, wbuf); });
+  } else if constexpr (EPI == EPI_WAVENET) {
+    if (col_base + 64 <= g.N)
+      return planes([&](auto pf) __attribute__((always_inline)) { epi_planes_fast<decltype(pf)::value, false, 2, WBUF>(acc, g, z, row_base, col_base, lane, wbuf); });
+  } else if constexpr (EPI == EPI_GEGLU) {
+    static_assert(EPI != EPI_GEGLU || WBUF >= 9216, "64 staged rows of a 128-byte output line + pad");
+    if (ocol_base + 32 <= g.out_ncols)
+      return planes([&](auto pf) __attribute__((always_inline)) { epi_geglu_fast<decltype(pf)::value, 2>(acc, g, row_base, col_base, ocol_base, lane, wbuf); });
+  } else if constexpr (EPI == EPI_QKV) {
+    static_assert(EPI != EPI_QKV || WBUF >= 9216, "64 feature rows of 64 tokens + pad");
+    if (col_base + 64 <= g.N && !g.bias) {
+      if (col_base + 64 <= g.split_col)
+        return planes([&](auto pf) __attribute__((always_inline)) { epi_planes_fast<decltype(pf)::value, false, 2, WBUF>(acc, g, 0, row_base, col_base, lane, wbuf); });
+      if (col_base >= g.split_col && !g.vt_lo && g.seq_len > 0 && (g.seq_len & 63) == 0 && (g.vt_ld & 7) == 0 &&
+          (reinterpret_cast<uintptr_t>(g.vt_hi) & 15) == 0) {
+        if (HALF && g.vt_fmt == FMT_F16) { epi_vt_fast<true, 2>(acc, g, row_base, col_base, lane, wbuf); return true; }
+        if ((BF || BF_DENSE) && g.vt_fmt == FMT_BF16) { epi_vt_fast<false, 2>(acc, g, row_base, col_base, lane, wbuf); return true; }
+      }
+    }
+  }
+  return false;
+}
+
 template <int NSPLIT, int EPI, bool F16>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   static_assert(NSPLIT != 2 || F16, "the mixed mode multiplies IEEE-half operands");
@@ -286,23 +335,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   }
   // Round 4: interior wave tiles of the plane-writing epilogues take gemm_epi_fast.h's route too (the dim = 128 model's Wavenet
   // blocks run here: 2048 blocks per launch whose generic epilogue -- a bounds test, a run-time format switch and a 2 ... 4 byte
-  // store per value -- cost more than their 16 K tiles)
-  if constexpr (EPI == EPI_WAVENET || EPI == EPI_SPLIT) {
-    if (row_base + 64 <= g.M && col_base + 64 <= g.N && (EPI == EPI_WAVENET || g.act == 0) &&
-        (reinterpret_cast<uintptr_t>(g.out_hi) & 15) == 0 && (g.ldo_s & 31) == 0) {
-      constexpr int WBUF = STAGE_BYTES / 2;
-      unsigned char* wbuf = smem + wave * WBUF;
-      auto go = [&](auto pf) __attribute__((always_inline)) {
-        epi_planes_fast<decltype(pf)::value, EPI == EPI_SPLIT, 2, WBUF>(acc, g, z, row_base, col_base, lane, wbuf);
-      };
-      if constexpr (F16) {
-        if (g.out_fmt == FMT_F16 && !g.out_lo) { go(std::integral_constant<int, PF_F16>{}); return; }
-        if (g.out_fmt == FMT_H8) { go(std::integral_constant<int, PF_H8>{}); return; }
-      } else {
-        if (g.out_fmt == FMT_BF16 && g.out_lo) { go(std::integral_constant<int, PF_BF16IL>{}); return; }
-        if constexpr (NSPLIT == 1) { if (g.out_fmt == FMT_BF16 && !g.out_lo) { go(std::integral_constant<int, PF_BF16>{}); return; } }
-      }
-    }
+  // store per value -- cost more than their 16 K tiles; small batches put QKV / GEGLU here as well)
+  if constexpr (EPI != EPI_F32) {
+    constexpr int WBUF = STAGE_BYTES / 2;
+    if (small_tile_fast_epilogue<EPI, WBUF, F16, !F16, (!F16 && NSPLIT == 1)>(acc, g, z, row_base, col_base, tn * 64 + wn * 32, lane, smem + wave * WBUF))
+      return;
   }
   gemm_epilogue<EPI, 2, 2>(acc, g, z, row_base, col_base, tn * 64 + wn * 32, lane);
 }
@@ -372,16 +409,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmArgs g, co
         acc[mi][ni][r] = (cok && row < g.M) ? t[r] : 0.f;
       }
     }
-  if constexpr (EPI == EPI_SPLIT) {
-    // interior wave tiles: the LDS-staged plane epilogue (gemm_epi_fast.h), as in the one-launch kernel
-    __shared__ __attribute__((aligned(16))) unsigned char fin_lds[4 * 9216];              // 32-row passes
-    if (row_base + 64 <= g.M && col_base + 64 <= g.N && g.act == 0 && (reinterpret_cast<uintptr_t>(g.out_hi) & 15) == 0 &&
-        (g.ldo_s & 31) == 0) {
-      unsigned char* wbuf = fin_lds + wave * 9216;
-      if (g.out_fmt == FMT_F16 && !g.out_lo) { epi_planes_fast<PF_F16, true, 2, 9216>(acc, g, 0, row_base, col_base, lane, wbuf); return; }
-      if (g.out_fmt == FMT_H8) { epi_planes_fast<PF_H8, true, 2, 9216>(acc, g, 0, row_base, col_base, lane, wbuf); return; }
-      if (g.out_fmt == FMT_BF16 && g.out_lo) { epi_planes_fast<PF_BF16IL, true, 2, 9216>(acc, g, 0, row_base, col_base, lane, wbuf); return; }
-    }
+  if constexpr (EPI != EPI_F32) {
+    // interior wave tiles: the LDS-staged epilogues (gemm_epi_fast.h), as in the one-launch kernel
+    __shared__ __attribute__((aligned(16))) unsigned char fin_lds[4 * 9216];
+    if (small_tile_fast_epilogue<EPI, 9216, true, true, true>(acc, g, 0, row_base, col_base, tn * 64 + wn * 32, lane, fin_lds + wave * 9216)) return;
   }
   gemm_epilogue<EPI, 2, 2>(acc, g, 0, row_base, col_base, tn * 64 + wn * 32, lane);
 }

@@ -932,9 +932,10 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
   // every tap per slice); fixed slots, fixed order of the sums.  (f == 3: automatic kernel choice, never split -- A/B hook.)
   if (f == 0 && g.sk_ws && g.epi != EPI_WAVENET && g.nz <= 1 && !g.dil_z && g.ksplit == 0) {
     const long tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    // ... and a K loop long enough to pay for the second launch: K >= 768.  Measured at 1 x 1024 frames (tools/exp_small_m_kernel.py):
-    // the FF causal conv (K = 4128) 114 -> 67 us, FF-out (K = 1376) 71 -> 26 us; K = 512 products break even or lose.
-    if (tiles < 256 && g.kt_per_tap >= 8 && g.nkt >= 24) {   // fewer 128 x 128 tiles than CUs
+    // ... and a K loop long enough to pay for the second launch: K >= 512, or K >= 352 when the epilogue is fp32 (a flat
+    // 16-byte-vector finishing kernel of ~5 us).  Measured at 1 x 1024 frames (tools/exp_small_m_kernel.py): the FF causal conv
+    // (K = 4128) 114 -> 65 us, FF-out (K = 1376) 71 -> 22 us; the K = 512 products are neutral to slightly ahead.
+    if (tiles < 256 && g.kt_per_tap >= 8 && g.nkt >= (g.epi == EPI_F32 ? 11 : 16)) {   // fewer 128 x 128 tiles than CUs
       const int want = (int)std::min<long>(512 / tiles, g.kt_per_tap / 4);
       if (want >= 2) {
         const int c = (g.kt_per_tap + want - 1) / want, S = (g.kt_per_tap + c - 1) / c;

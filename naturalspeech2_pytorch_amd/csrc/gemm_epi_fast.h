@@ -153,15 +153,17 @@ NS2_DEVINL void epi_planes_fast(f32x16 (&acc)[MI][2], const GemmArgs& g, int z, 
 
 // ---- V^T of EPI_QKV: the wave tile's 64 value features x 128 tokens, transposed in LDS, 256 contiguous bytes per feature row.
 // Dense 16-bit formats only (F16: IEEE half with the range guard, else bf16); needs seq_len % 128 == 0 (one utterance per tile).
-template <bool F16>
-NS2_DEVINL void epi_vt_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_base, int col_base, int lane, unsigned char* wbuf) {
-  constexpr int RS = 256 + 16;
+// (MI = 32-token accumulator tiles of the wave: 4 in gemm2.hip, needs seq_len % 128 == 0; 2 in gemm.hip, seq_len % 64 == 0)
+template <bool F16, int MI = 4>
+NS2_DEVINL void epi_vt_fast(f32x16 (&acc)[MI][2], const GemmArgs& g, int row_base, int col_base, int lane, unsigned char* wbuf) {
+  constexpr int TOKB = 64 * MI;                      // bytes of the wave tile's 32 * MI tokens in one feature row
+  constexpr int RS = TOKB + 16;
   const int l31 = lane & 31, hi = lane >> 5;
   const int b = row_base / g.seq_len, n0 = row_base - b * g.seq_len;
   const int feat0 = col_base - g.split_col;
   RangeTrack rt;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -176,14 +178,14 @@ NS2_DEVINL void epi_vt_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_base
       }
   __builtin_amdgcn_wave_barrier();
   unsigned char* gbase = reinterpret_cast<unsigned char*>(g.vt_hi + ((long)b * g.vt_rows + feat0) * g.vt_ld + n0);
-  lds_flush_rows<256, 64>(wbuf, gbase, (long)g.vt_ld * 2, lane);
+  lds_flush_rows<TOKB, 64>(wbuf, gbase, (long)g.vt_ld * 2, lane);
   __builtin_amdgcn_wave_barrier();
   if constexpr (F16) rt.flush(65504.f);
 }
 
 // ---- GEGLU: wave tile = [x(32 cols) | gate(32 cols)] -> 32 output columns gelu(gate) * x
-template <int PF>
-NS2_DEVINL void epi_geglu_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_base, int col_base, int ocol_base, int lane, unsigned char* wbuf) {
+template <int PF, int MI = 4>
+NS2_DEVINL void epi_geglu_fast(f32x16 (&acc)[MI][2], const GemmArgs& g, int row_base, int col_base, int ocol_base, int lane, unsigned char* wbuf) {
   using G = PlaneGeom<PF>;
   constexpr int ROWB = G::bytes_per_col32;
   constexpr int RS = ROWB + 16;
@@ -194,7 +196,7 @@ NS2_DEVINL void epi_geglu_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_b
   unsigned char* gbase = reinterpret_cast<unsigned char*>(g.out_hi) + (long)row_base * rsb + (long)(ocol_base >> 5) * G::bytes_per_col32;
   RangeTrack rt;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int rp = 0; rp < 8; ++rp) {
       float v0 = gelu_erf(acc[mi][1][2 * rp] + bg) * (acc[mi][0][2 * rp] + bx);
@@ -208,7 +210,7 @@ NS2_DEVINL void epi_geglu_fast(f32x16 (&acc)[4][2], const GemmArgs& g, int row_b
       if ((rp & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   __builtin_amdgcn_wave_barrier();
-  lds_flush_rows<ROWB, 128>(wbuf, gbase, rsb, lane);
+  lds_flush_rows<ROWB, 32 * MI>(wbuf, gbase, rsb, lane);
   __builtin_amdgcn_wave_barrier();
   if constexpr (G::guarded) rt.flush(G::limit);
 }
