@@ -298,37 +298,41 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   // Round 3: interior wave tiles of the fp32 epilogue (the SEANet codec's 16 ... 128-channel convolutions run here, 80 k blocks
   // per launch on the early layers) leave through the wave's share of the now idle LDS ring as 16-byte stores of whole row
   // segments, with the bounds tested once per wave -- the generic epilogue below tests and branches per stored value.
-  if constexpr (EPI == EPI_F32 && NP == 2) {
+  if constexpr (EPI == EPI_F32) {
     const int nvc = min(64, g.N - col_base);                     // valid columns of this wave tile
     if (nvc <= 0) return;
     if (row_base + 64 <= g.M && nvc >= 16 && (nvc & (nvc - 1)) == 0 && g.act == 0 && (g.ldo_f & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(g.out_f) & 15) == 0 &&
         (!g.resid || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.resid) & 15) == 0))) {
-      constexpr int RS = 272;                                     // 64 fp32 + 16 B pad per staged row: 64 rows = 17 KiB of the wave's 20 KiB
+      // two passes of 32 rows: 32 x (64 fp32 + 16 B pad) = 8.5 KiB fits the wave's share of the ring in every arithmetic mode
+      // (10 KiB with one operand plane staged, 20 KiB with two; round 4: the single-plane kernels took the per-value path before)
+      constexpr int RS = 272;
       unsigned char* wbuf = smem + wave * (STAGE_BYTES / 2);
       const float bc0 = (g.bias && col_base + l31 < g.N) ? g.bias[col_base + l31] : 0.f;
       const float bc1 = (g.bias && col_base + 32 + l31 < g.N) ? g.bias[col_base + 32 + l31] : 0.f;
+      const int lcpr = 31 - __builtin_clz(nvc >> 2);              // log2(16-byte chunks per row): 2, 3 or 4
+      const int lr0 = lane >> lcpr, ch = lane & ((1 << lcpr) - 1), rpi = 64 >> lcpr;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int lr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
             *reinterpret_cast<float*>(wbuf + lr * RS + (ni * 32 + l31) * 4) = acc[mi][ni][r] + (ni ? bc1 : bc0);
           }
-      __builtin_amdgcn_wave_barrier();
-      const int lcpr = 31 - __builtin_clz(nvc >> 2);              // log2(16-byte chunks per row): 2, 3 or 4
-      const int lr0 = lane >> lcpr, ch = lane & ((1 << lcpr) - 1), rpi = 64 >> lcpr;
-      for (int it = 0; it < (1 << lcpr); ++it) {
-        const int lr = it * rpi + lr0;
-        float4 v = *reinterpret_cast<const float4*>(wbuf + lr * RS + ch * 16);
-        const long row = row_base + lr;
-        if (g.resid) {
-          const float4 rr = *reinterpret_cast<const float4*>(g.resid + row * g.ldr + col_base + ch * 4);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        __builtin_amdgcn_wave_barrier();
+        for (int it = 0; it < (32 >> (6 - lcpr)); ++it) {         // 32 rows / rpi
+          const int lr = it * rpi + lr0;
+          float4 v = *reinterpret_cast<const float4*>(wbuf + lr * RS + ch * 16);
+          const long row = row_base + mi * 32 + lr;
+          if (g.resid) {
+            const float4 rr = *reinterpret_cast<const float4*>(g.resid + row * g.ldr + col_base + ch * 4);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          *reinterpret_cast<float4*>(g.out_f + z * g.out_f_zs + row * g.ldo_f + col_base + ch * 4) = v;
         }
-        *reinterpret_cast<float4*>(g.out_f + z * g.out_f_zs + row * g.ldo_f + col_base + ch * 4) = v;
+        __builtin_amdgcn_wave_barrier();
       }
       return;
     }
@@ -380,34 +384,47 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmArgs g, co
   const int ntn = (g.N + BN - 1) / BN;
   const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
   const int row_base = tm * BM + wm * 64, col_base = tn * BN + wn * 64;
+  // Unconditional loads from clamped addresses, all 64 of a slot in flight together (a bounds branch per value serialised them:
+  // 64 x S dependent round trips, 85-200 us per launch; one (mi, ni) quarter at a time still left 4 x S dependent batches);
+  // invalid positions are zeroed afterwards.  Slot order per value is fixed: s = 0, 1, ...
   f32x16 acc[2][2];
+  int off[2][2][16];                      // < 2^31: a slot is at most SPLITK_SCRATCH_FLOATS / 2 elements
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-      // unconditional loads from clamped addresses: the 16 loads of a slot are in flight together (a bounds branch per value
-      // serialised them: 64 x S dependent round trips, 85-200 us per launch); invalid positions are zeroed afterwards
-      const int col = col_base + ni * 32 + l31;
-      const bool cok = col < g.N;
-      const float* pc = part + min(col, g.N - 1);
-      float t[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = 0.f;
-      for (int sl = 0; sl < S; ++sl) {
-        float l[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = min(row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.M - 1);
-          l[r] = pc[sl * slot + (long)row * ldp];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t[r] += l[r];
-      }
+      const int col = min(col_base + ni * 32 + l31, g.N - 1);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        acc[mi][ni][r] = (cok && row < g.M) ? t[r] : 0.f;
+        const int row = min(row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.M - 1);
+        off[mi][ni][r] = row * ldp + col;
+        acc[mi][ni][r] = 0.f;
       }
+    }
+  for (int sl = 0; sl < S; ++sl) {
+    const float* ps = part + sl * slot;
+    f32x16 l[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) l[mi][ni][r] = ps[off[mi][ni][r]];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += l[mi][ni][r];
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const bool cok = col_base + ni * 32 + l31 < g.N;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (!(cok && row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi < g.M)) acc[mi][ni][r] = 0.f;
     }
   if constexpr (EPI != EPI_F32) {
     // interior wave tiles: the LDS-staged epilogues (gemm_epi_fast.h), as in the one-launch kernel
@@ -451,6 +468,9 @@ hipError_t launch_gemm_splitk(const GemmArgs& g, int precision, int S, int c, hi
   p.out_f = g.sk_ws; p.ldo_f = ldp; p.out_f_zs = slot;
   p.out_hi = nullptr; p.out_lo = nullptr; p.vt_hi = nullptr; p.vt_lo = nullptr;
   p.nz = S; p.a_zs = 0; p.w_zs = 0; p.dil_z = 0; p.ksplit = c;
+  // the slots are ldp = round_up(N, 64) wide and the packed weight's padding rows are zeros: let the slices write whole 64-column
+  // wave tiles (the vectorised fp32 epilogue; a ragged last tile took the per-value one: 41 us instead of ~25 for the FF conv's slices)
+  p.N = ldp;
   hipError_t e = launch_gemm1(p, precision, s);
   if (e != hipSuccess) return e;
   const int grid = ((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM);

@@ -20,7 +20,11 @@ for shp in d512 d128; do
   cp $(ls $OUT/prof_train_$shp/*/*kernel_stats.csv | head -1) $OUT/train_${shp}_kernel_stats.csv
   rm -rf $OUT/prof_train_$shp
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_b1 -- python $R/bench.py --batch 1 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-side --no-parity > $OUT/prof_b1.log 2>&1
+cp $(ls $OUT/prof_b1/*/*kernel_stats.csv | head -1) $OUT/bench_b1_hybrid_kernel_stats.csv; rm -rf $OUT/prof_b1
 cd $R
+python tools/time_config1.py > $OUT/time_config1.json 2> $OUT/time_config1.err
+python tools/exp_small_m_kernel.py > $OUT/small_batch.json 2> /dev/null
 for P in hybrid; do tools/pmc_bench.sh $P > $OUT/pmc_$P.log 2>&1; cp gpurun_out/pmc_traffic_$P.json $OUT/; done
 rm -rf gpurun_out/pmc_bench_hybrid
 head -c 3000 $OUT/bench_default.json; echo
