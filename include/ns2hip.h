@@ -60,6 +60,9 @@ int ns2_debug_force_gemm(int kernel);
  * ns2_splitk_scratch_bytes() bytes, used by every following stand-alone GEMM call of this thread until cleared with
  * (NULL, 0).  Test hook: the caller keeps the memory alive and the calls stream-ordered. */
 int64_t ns2_splitk_scratch_bytes(void);
+/* host arithmetic only (no device needed): the plan a product of M x N over k_tiles K tiles of 32 (k_tiles_per_tap per conv tap)
+ * gets when scratch is lent -- `slices` (1 = not split) of `k_tiles_per_slice` K tiles of every tap */
+int ns2_debug_splitk_plan(int M, int N, int k_tiles, int k_tiles_per_tap, int fp32_epilogue, int* slices, int* k_tiles_per_slice);
 int ns2_debug_lend_splitk_scratch(void* scratch, int64_t bytes);
 
 /* ------------------------------------------------------------------ packed weights (library-owned) */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "ns2_version": (I, []),
     "ns2_debug_force_gemm": (I, [I]),
     "ns2_splitk_scratch_bytes": (L, []),
+    "ns2_debug_splitk_plan": (I, [I, I, I, I, I, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "ns2_debug_lend_splitk_scratch": (I, [P, L]),
     "ns2_weight_pack": (I, [P, I, I, I, I, P, I, POINTER(c_void_p), P]),
     "ns2_weight_free": (None, [P]),

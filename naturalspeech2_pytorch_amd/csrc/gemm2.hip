@@ -907,6 +907,25 @@ static int forced_kernel() {
   return f;
 }
 
+// Split-K plan of a product M x N over nkt K tiles of 32 (kt_per_tap per tap): S slices of c K tiles of EVERY tap, S = 1 = do not
+// split.  A product is split when it has fewer 128 x 128 output tiles than the chip has CUs -- a handful of tiles, each a long
+// serial K loop on one CU while the others idle -- and a K loop long enough to pay for the second launch: K >= 512, or K >= 352
+// when the epilogue is fp32 (a flat 16-byte-vector finishing kernel of ~5 us).  Measured at 1 x 1024 frames
+// (tools/exp_small_m_kernel.py): the FF causal conv (K = 4128) 114 -> 55 us, FF-out (K = 1376) 71 -> 22 us; the K = 512 products are
+// neutral to slightly ahead.  Slices: enough for ~2 blocks per CU, at least 4 K tiles of every tap each, never an empty one, and
+// all slots inside the lent scratch.  Pure host arithmetic (ns2_debug_splitk_plan exposes it to the CPU tests).
+void splitk_plan(int M, int N, int nkt, int kt_per_tap, bool epi_f32, long scratch_floats, int* S_out, int* c_out) {
+  *S_out = 1; *c_out = kt_per_tap;
+  if (M <= 0 || N <= 0 || kt_per_tap <= 0 || nkt < kt_per_tap) return;
+  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles >= 256 || kt_per_tap < 8 || nkt < (epi_f32 ? 11 : 16)) return;
+  const int want = (int)std::min<long>(512 / tiles, kt_per_tap / 4);
+  if (want < 2) return;
+  const int c = (kt_per_tap + want - 1) / want, S = (kt_per_tap + c - 1) / c;
+  if (S < 2 || (long)S * M * ((N + 63) & ~63) > scratch_floats) return;
+  *S_out = S; *c_out = c;
+}
+
 // Dispatch: the 256x256 LDS-DMA kernel for wide outputs, the 128x128 kernel when N <= 128 (half of a 256-wide tile
 // would be padding, e.g. the dim=128 model's d x d projections).  W rows are padded to 256 by the packers.
 hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
@@ -927,21 +946,12 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
       !planes_ok(g.vt_hi, g.vt_lo))
     return hipErrorInvalidValue;
   const int f = forced_kernel();
-  // Small products (a batch of 1 ... 4 utterances): a handful of output tiles, each a long serial K loop on one CU while the
-  // other CUs idle.  With scratch lent by the caller, split K over enough slices for ~2-4 blocks per CU (at least 4 K tiles of
-  // every tap per slice); fixed slots, fixed order of the sums.  (f == 3: automatic kernel choice, never split -- A/B hook.)
+  // Small products (a batch of 1 ... 4 utterances) split K when the caller lent scratch (splitk_plan above).
+  // (f == 3: automatic kernel choice, never split -- A/B hook.)
   if (f == 0 && g.sk_ws && g.epi != EPI_WAVENET && g.nz <= 1 && !g.dil_z && g.ksplit == 0) {
-    const long tiles = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    // ... and a K loop long enough to pay for the second launch: K >= 512, or K >= 352 when the epilogue is fp32 (a flat
-    // 16-byte-vector finishing kernel of ~5 us).  Measured at 1 x 1024 frames (tools/exp_small_m_kernel.py): the FF causal conv
-    // (K = 4128) 114 -> 65 us, FF-out (K = 1376) 71 -> 22 us; the K = 512 products are neutral to slightly ahead.
-    if (tiles < 256 && g.kt_per_tap >= 8 && g.nkt >= (g.epi == EPI_F32 ? 11 : 16)) {   // fewer 128 x 128 tiles than CUs
-      const int want = (int)std::min<long>(512 / tiles, g.kt_per_tap / 4);
-      if (want >= 2) {
-        const int c = (g.kt_per_tap + want - 1) / want, S = (g.kt_per_tap + c - 1) / c;
-        if (S >= 2 && (long)S * g.M * ((g.N + 63) & ~63) <= g.sk_ws_floats) return launch_gemm_splitk(g, precision, S, c, s);
-      }
-    }
+    int S, c;
+    splitk_plan(g.M, g.N, g.nkt, g.kt_per_tap, g.epi == EPI_F32, g.sk_ws_floats, &S, &c);
+    if (S >= 2) return launch_gemm_splitk(g, precision, S, c, s);
   }
   // a product that would put at most 64 blocks of 256 x 256 on the 256 CUs runs on the 128 x 128 kernel (4 x the blocks, a
   // quarter of the serial work each): 1 x 1024-frame steps measured 4 % faster with it, 4 x 1024 slower (exp_small_m_kernel.py)

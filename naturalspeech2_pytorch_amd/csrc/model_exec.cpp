@@ -226,6 +226,11 @@ struct SplitKScope {
   SplitKScope& operator=(const SplitKScope&) = delete;
 };
 extern "C" int64_t ns2_splitk_scratch_bytes(void) { return SPLITK_SCRATCH_FLOATS * (int64_t)sizeof(float); }
+extern "C" int ns2_debug_splitk_plan(int M, int N, int k_tiles, int k_tiles_per_tap, int fp32_epilogue, int* slices, int* k_tiles_per_slice) {
+  if (!slices || !k_tiles_per_slice) { set_error("ns2_debug_splitk_plan: null pointer"); return NS2_ERR_ARG; }
+  splitk_plan(M, N, k_tiles, k_tiles_per_tap, fp32_epilogue != 0, SPLITK_SCRATCH_FLOATS, slices, k_tiles_per_slice);
+  return NS2_OK;
+}
 extern "C" int ns2_debug_lend_splitk_scratch(void* scratch, int64_t bytes) {
   if (scratch && bytes < ns2_splitk_scratch_bytes()) { set_error("ns2_debug_lend_splitk_scratch: scratch smaller than ns2_splitk_scratch_bytes()"); return NS2_ERR_ARG; }
   tl_sk_ws = static_cast<float*>(scratch);

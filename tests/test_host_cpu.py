@@ -27,6 +27,44 @@ def test_library_exports_whole_abi():
     assert set(_lib.header_symbols()) <= exported
 
 
+def test_split_k_plan_host_arithmetic():
+    """gemm2.hip splitk_plan through ns2_debug_splitk_plan (host arithmetic, no device): which products of a small batch are cut
+    into K slices, and the invariants the kernels rely on -- no empty slice, every K tile covered once, at least 4 K tiles of a tap
+    per slice, slices x output tiles <= 512 (so every slot fits the 32 MiB the forward lends), nothing split once the 128 x 128
+    output tiles fill the chip."""
+    import ctypes
+    lib = _lib.load()
+
+    def plan(M, N, K, taps=1, f32=False):
+        kpt = (K + 31) // 32
+        S, c = ctypes.c_int(-1), ctypes.c_int(-1)
+        _lib.check(lib.ns2_debug_splitk_plan(M, N, kpt * taps, kpt, int(f32), ctypes.byref(S), ctypes.byref(c)), "plan")
+        return S.value, c.value, kpt
+
+    scratch = int(lib.ns2_splitk_scratch_bytes()) // 4
+    # the d512 / L12 model at 1 x 1024 frames (DESIGN section 4, small batches)
+    assert plan(1024, 1365, 1376, taps=3)[:2] == (5, 9)              # FF causal conv: 43 K tiles per tap as 9 + 9 + 9 + 9 + 7
+    assert plan(1024, 512, 1376, f32=True)[:2] == (9, 5)             # FF-out
+    assert plan(1024, 512, 512, f32=True)[:2] == (4, 4)              # out-proj
+    assert plan(1024, 1536, 512)[:2] == (4, 4)                       # QKV
+    assert plan(1024, 128, 352, f32=True)[0] == 2                    # dim = 128 FF-out: 11 K tiles as 6 + 5
+    assert plan(1024, 128, 128)[0] == 1                              # K = 128: nothing to split
+    assert plan(32768, 512, 1376, f32=True)[0] == 1                  # the headline batch fills the chip
+    assert plan(32768, 128, 512, f32=True)[0] == 1                   # ... also with one column tile (256 row tiles)
+    for M in (1, 77, 256, 1000, 1024, 2048, 4096, 8192, 16384):
+        for N in (1, 64, 128, 341, 512, 1365, 1536, 2752):
+            for K in (32, 224, 256, 352, 512, 1024, 1376, 4096):
+                for taps in (1, 3):
+                    for f32 in (False, True):
+                        S, c, kpt = plan(M, N, K, taps, f32)
+                        if S == 1:
+                            continue
+                        tiles = -(-M // 128) * -(-N // 128)
+                        assert tiles < 256 and kpt * taps >= (11 if f32 else 16) and kpt >= 8
+                        assert S >= 2 and c >= 4 and (S - 1) * c < kpt <= S * c          # no empty slice, all tiles covered
+                        assert S * tiles <= 512 and S * M * (-(-N // 64) * 64) <= scratch
+
+
 def test_no_cpu_fallback():
     m = Model(dim=64, depth=1).eval()
     with torch.no_grad(), pytest.raises(_lib.Ns2Error):
