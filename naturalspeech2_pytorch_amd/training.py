@@ -551,6 +551,41 @@ def _lin(lin, x):
     return SkinnyLinearFn.apply(x if x.is_contiguous() else x.contiguous(), lin.weight, lin.bias)
 
 
+class CondProjectionsFn(torch.autograd.Function):
+    """EVERY FiLM / adaptive-norm projection of one forward (the 32 Wavenet `to_time_cond`, the 24-36 `to_gamma_beta` Linears:
+    NS2:623, 744) as ONE weight-streaming product, the way the sampler's executor runs them (model_exec.cpp: one [K, Jtot] matrix).
+    They all read the same conditioning rows t [B, K]; per module the kernel had 32 workgroups on 256 CUs and the step paid
+    171 launches of ~40 us.  y_all = t W_all^T + b_all;  dt = dy_all W_all;  dW_all = dy_all^T t, whose row blocks ARE the
+    parameters' gradients (returned as views);  db_all = column sums.  Same fp32 FMAs per output as the per-module product, in
+    another K split (the split follows the column count)."""
+
+    @staticmethod
+    def forward(ctx, t, *wb):
+        bk = backend()
+        ws, bs = wb[0::2], wb[1::2]
+        sizes = [int(w.shape[0]) for w in ws]
+        W = torch.cat([w.detach() for w in ws], 0)                           # [Jtot, K]
+        bias = torch.cat([b.detach() for b in bs], 0)
+        y = bk.skinny(t.detach(), bk.transpose_f32(W), bias)                 # [B, Jtot]
+        ctx.save_for_backward(t, W)
+        ctx.sizes = sizes
+        return tuple(o.contiguous() for o in y.split(sizes, dim=1))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        bk = backend()
+        t, W = ctx.saved_tensors
+        B = t.shape[0]
+        dy = torch.cat([d if d is not None else torch.zeros(B, n, dtype=t.dtype, device=t.device) for d, n in zip(dys, ctx.sizes)], 1)
+        dt = bk.skinny(dy, W) if ctx.needs_input_grad[0] else None           # [B, Jtot] @ [Jtot, K]
+        dW = bk.skinny(bk.transpose_f32(dy), t.detach())                     # [Jtot, B] @ [B, K]
+        db = bk.colsum_rows(dy)
+        grads = []
+        for gw, gb in zip(dW.split(ctx.sizes, 0), db.split(ctx.sizes, 0)):
+            grads += [gw, gb]
+        return (dt, *grads)
+
+
 # =============================================================================================== Model.forward under autograd
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
@@ -605,9 +640,18 @@ def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None
         h = h + _c(cm).reshape(M, d)
         c2 = _c(c.float()).reshape(b * c.shape[1], d)
     t = _c(t)
+    # every conditioning projection of the pass at once (CondProjectionsFn), in the order the graph below consumes them
+    lins = [blk.to_time_cond for st in m.wavenet.stacks for blk in st.blocks]
+    for layer in m.transformer.layers:
+        lins += [getattr(layer, str(i)).to_gamma_beta for i in ((0, 2, 4) if m.condition_on_prompt else (0, 4))]
+    if all(l.bias is not None for l in lins):
+        films = dict(zip(map(id, lins), CondProjectionsFn.apply(t, *[q for l in lins for q in (l.weight, l.bias)])))
+    else:                                                                    # (the reference's Linears all carry a bias)
+        films = {}
 
     def film_of(lin):
-        return _lin(lin, t)
+        f = films.get(id(lin))
+        return f if f is not None else _lin(lin, t)
 
     wn = m.wavenet
     h0 = GemmFn.apply(h, wn.init_conv.weight, wn.init_conv.bias, None, n, 1)
