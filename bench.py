@@ -345,6 +345,8 @@ def main():
         if os.path.exists(pj) and (dim, depth) == (512, 12):
             tj = json.load(open(pj))
             traffic = tj.get("hbm_bytes_per_launch_by_precision", {}).get(precision)
+            if traffic is None and tj.get("precision") == precision:         # the raw output of tools/pmc_bench.sh (one precision)
+                traffic = tj.get("hbm_bytes_per_launch")
             if traffic is not None:
                 tsrc = (f"profiles/{PMC_TRAFFIC}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command "
                         "(tools/pmc_bench.sh), read side doubled per MI355X_MICROARCH.md; a committed profile, NOT measured in this run")
