@@ -88,3 +88,31 @@ def test_packed_cache_refreshes_in_place_and_never_serves_a_dead_parameter():
         assert b is not a and len(made) == 2
     finally:
         T.ops.PackedWeight = orig
+
+
+def test_cond_projections_fn_unused_outputs_and_views(emu):
+    """CondProjectionsFn alone against torch autograd: several Linears of different widths on the same rows, one output unused (its
+    gradient arrives as None and must count as zeros), parameter gradients returned as row blocks of ONE product."""
+    from naturalspeech2_pytorch_amd.training import CondProjectionsFn
+    torch.manual_seed(3)
+    B, K = 5, 24
+    sizes = (16, 8, 40)
+    t = torch.randn(B, K, requires_grad=True)
+    ws = [torch.randn(n, K, requires_grad=True) for n in sizes]
+    bs = [torch.randn(n, requires_grad=True) for n in sizes]
+    outs = CondProjectionsFn.apply(t, *[q for w, b in zip(ws, bs) for q in (w, b)])
+    assert [tuple(o.shape) for o in outs] == [(B, n) for n in sizes] and all(o.is_contiguous() for o in outs)
+    gw = [torch.randn(B, n) for n in sizes]
+    (outs[0] * gw[0]).sum().add((outs[2] * gw[2]).sum()).backward()          # outs[1] is never used
+    got = [t.grad.clone()] + [w.grad.clone() for w in ws] + [b.grad.clone() for b in bs]
+    t.grad = None
+    for q in ws + bs:
+        q.grad = None
+    ref_outs = [t @ w.t() + b for w, b in zip(ws, bs)]
+    for o, r in zip(outs, ref_outs):
+        assert torch.allclose(o, r, atol=1e-5)
+    (ref_outs[0] * gw[0]).sum().add((ref_outs[2] * gw[2]).sum()).backward()
+    want = [t.grad] + [w.grad if w.grad is not None else torch.zeros_like(w) for w in ws] + \
+           [b.grad if b.grad is not None else torch.zeros_like(b) for b in bs]
+    for g, r in zip(got, want):
+        assert torch.allclose(g, r, atol=1e-4), (g - r).abs().max()
