@@ -171,7 +171,46 @@ def gen_encoders(ns2):
     print("encoders ok")
 
 
+GRAD_CASES = {
+    # name: (ctor kwargs, batch, n, n_prompt, n_cond)  -- small on purpose: the fixture holds EVERY parameter's gradient
+    "uncond_d64": (dict(dim=64, depth=1, heads=2, wavenet_layers=2, wavenet_stacks=2), 2, 40, None, None),
+    "cond_d64": (dict(dim=64, depth=1, heads=2, wavenet_layers=2, wavenet_stacks=2, dim_prompt=32, condition_on_prompt=True,
+                      num_latents_m=8, resampler_depth=1), 2, 40, 11, 33),
+}
+
+
+def gen_grad_case(ns2, name, spec):
+    """the reference's OWN autograd (NS2:1635 `pred = self.model(...)` under grad, NS2:1886 backward) through the unmodified
+    `Model.forward` in train mode with cond_drop_prob 0: L = sum(pred * w) for a seeded w; every parameter's gradient, dL/dx, pred"""
+    kw, b, n, n_p, n_c = spec
+    torch.manual_seed(0)
+    m = ns2.Model(**kw).train()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(make_weights(shapes, seed=41))
+    dim = kw["dim"]
+    x = make_input("x", (b, n, dim), seed=42).requires_grad_(True)
+    times = make_input("times", (b,), seed=42, uniform=True)
+    kws = {}
+    if kw.get("condition_on_prompt"):
+        kws = dict(prompt=make_input("prompt", (b, n_p, kw["dim_prompt"]), seed=42), cond=make_input("cond", (b, kw["dim_prompt"], n_c), seed=42),
+                   cond_drop_prob=0.)
+    y = m(x, times, **kws)
+    w = make_input("gw", tuple(y.shape), seed=43)
+    (y * w).sum().backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+    fix = dict(kind="grads", kwargs=kw, shapes=shapes, weight_seed=41, input_seed=42, loss_weight_seed=43, batch=b, n=n, n_prompt=n_p, n_cond=n_c,
+               output=y.detach().clone(), x_grad=x.grad.detach().clone(), grads=grads, torch_version=torch.__version__)
+    torch.save(fix, os.path.join(OUT, f"grads_{name}.pt"))
+    print("grads", name, len(grads), "tensors,", sum(g.numel() for g in grads.values() if g is not None), "values; without gradient:",
+          [k for k, g in grads.items() if g is None])
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["grads"]:                 # only the gradient fixtures (added in round 4)
+        ns2 = load_reference()
+        for name, spec in GRAD_CASES.items():
+            gen_grad_case(ns2, name, spec)
+        sys.exit(0)
     gen_rvq()                     # before the reference stubs shadow torchaudio (transformers probes it)
     ns2 = load_reference()
     for name, spec in MODEL_CASES.items():
@@ -179,3 +218,5 @@ if __name__ == "__main__":
     gen_ddim(ns2)
     gen_transformer(ns2)
     gen_encoders(ns2)
+    for name, spec in GRAD_CASES.items():
+        gen_grad_case(ns2, name, spec)
