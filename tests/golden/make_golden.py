@@ -205,11 +205,42 @@ def gen_grad_case(ns2, name, spec):
           [k for k, g in grads.items() if g is None])
 
 
+def gen_loss(ns2):
+    """`NaturalSpeech2.forward(latents)` (NS2:1503-1684): the training loss of the unmodified reference for the three objectives,
+    with and without the min-SNR weight, the random times (NS2:1621) and noise (NS2:1625) injected through the two RNG calls it
+    makes.  Scalars only: the weights / inputs are rebuilt from seeds."""
+    kw = dict(dim=64, depth=1, heads=2, wavenet_layers=2, wavenet_stacks=2)
+    m = ns2.Model(**kw).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(make_weights(shapes, seed=51))
+    b, n = 3, 40
+    audio = make_input("audio", (b, n, 64), seed=52)
+    times = make_input("times", (b,), seed=52, uniform=True)
+    noise = make_input("noise", (b, n, 64), seed=52)
+    losses = {}
+    orig_rl, orig_u = torch.randn_like, torch.Tensor.uniform_
+    try:
+        torch.randn_like = lambda a, **k: noise.clone()
+        torch.Tensor.uniform_ = lambda self, *a, **k: self.copy_(times)
+        for objective in ("v", "eps", "x0"):
+            for min_snr in (True, False):
+                d = ns2.NaturalSpeech2(model=m, codec=None, target_sample_hz=24000, timesteps=10, objective=objective,
+                                       min_snr_loss_weight=min_snr)
+                with torch.no_grad():
+                    losses[f"{objective}/min_snr={min_snr}"] = float(d(audio))
+    finally:
+        torch.randn_like, torch.Tensor.uniform_ = orig_rl, orig_u
+    torch.save(dict(kind="loss", kwargs=kw, shapes=shapes, weight_seed=51, input_seed=52, batch=b, n=n, losses=losses,
+                    torch_version=torch.__version__), os.path.join(OUT, "loss_uncond_d64.pt"))
+    print("loss", losses)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["grads"]:                 # only the gradient fixtures (added in round 4)
+    if sys.argv[1:] == ["grads"]:                 # only the fixtures added in round 4
         ns2 = load_reference()
         for name, spec in GRAD_CASES.items():
             gen_grad_case(ns2, name, spec)
+        gen_loss(ns2)
         sys.exit(0)
     gen_rvq()                     # before the reference stubs shadow torchaudio (transformers probes it)
     ns2 = load_reference()
@@ -220,3 +251,4 @@ if __name__ == "__main__":
     gen_encoders(ns2)
     for name, spec in GRAD_CASES.items():
         gen_grad_case(ns2, name, spec)
+    gen_loss(ns2)

@@ -558,3 +558,22 @@ def test_seanet_resblock_concatenated_weight(monkeypatch):
         both[:, cat["hs"]:cat["hs"] + 48] = x.t()
         got = both @ cat["w"].w.t() + cat["b"]
     assert torch.allclose(got, ref, atol=1e-5), (got - ref).abs().max()
+
+
+def test_training_loss_matches_the_reference_golden():
+    """tests/golden/loss_uncond_d64.pt: `NaturalSpeech2.forward(latents)` of the UNMODIFIED reference (NS2:1503-1684) for the three
+    objectives with and without the min-SNR weight, random times / noise injected (make_golden.py gen_loss).  This package's
+    `NaturalSpeech2.forward` with the same times / noise, the composite forward on CPU."""
+    fix = torch.load(os.path.join(GOLD, "loss_uncond_d64.pt"), weights_only=False)
+    m = Model(**fix["kwargs"])
+    m.load_state_dict(make_weights(fix["shapes"], seed=fix["weight_seed"]))
+    b, n = fix["batch"], fix["n"]
+    audio = make_input("audio", (b, n, 64), seed=fix["input_seed"])
+    times = make_input("times", (b,), seed=fix["input_seed"], uniform=True)
+    noise = make_input("noise", (b, n, 64), seed=fix["input_seed"])
+    assert len(fix["losses"]) == 6
+    for key, ref in fix["losses"].items():
+        objective, ms = key.split("/")
+        d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=10, objective=objective, min_snr_loss_weight=(ms == "min_snr=True"))
+        loss = d(audio, times=times, noise=noise)
+        assert abs(loss.item() - ref) < 2e-5 * max(1.0, abs(ref)), (key, loss.item(), ref)
