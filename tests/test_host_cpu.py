@@ -577,3 +577,46 @@ def test_training_loss_matches_the_reference_golden():
         d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=10, objective=objective, min_snr_loss_weight=(ms == "min_snr=True"))
         loss = d(audio, times=times, noise=noise)
         assert abs(loss.item() - ref) < 2e-5 * max(1.0, abs(ref)), (key, loss.item(), ref)
+
+
+def test_sampler_demotes_to_exact_when_a_fast_mode_leaves_the_half_range():
+    """diffusion.ddim_sample(on_saturation=...): host logic of the range guard's last resort, with the HIP call substituted (the
+    unfused loop: a non-default schedule).  A fast mode whose forward reports clamped activations is repeated ONCE, from the same
+    initial latents, in `exact`, and the model stays there; "raise" keeps the error; any other error is not retried."""
+    import warnings
+    m = Model(dim=64, depth=1, precision="hybrid").eval()
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    calls = []
+
+    def fake_hip(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, out=None, cond_row=None):
+        calls.append(self.precision)
+        if self.precision != "exact" and len(calls) == 2:
+            raise _lib.Ns2Error(fake_hip.message)
+        return O.model_forward(sd, x, times)
+
+    fake_hip.message = "3 conversions left the IEEE-half range (precision hybrid)"
+    d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=3, schedule_kwargs=dict(start=-3.0, end=3.0, tau=1.0))
+    assert not d._fused_ddim_ok()
+    noise = make_input("noise", (2, 12, 64), seed=8)
+    try:
+        type(m)._forward_hip = fake_hip
+        with pytest.warns(UserWarning, match="repeating the sampling run with precision='exact'"):
+            out = d.ddim_sample((2, 12, 64), noise=noise)
+        assert m.precision == "exact" and calls == ["hybrid", "hybrid", "exact", "exact", "exact"]
+        calls.clear()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                                  # already exact: a clean run, no warning
+            again = d.ddim_sample((2, 12, 64), noise=noise)
+        assert torch.equal(out, again) and calls == ["exact"] * 3           # the repeated run started from the SAME latents
+        m.precision = "mixed"
+        calls.clear()
+        with pytest.raises(_lib.Ns2Error):
+            d.ddim_sample((2, 12, 64), noise=noise, on_saturation="raise")
+        assert m.precision == "mixed" and calls == ["mixed", "mixed"]
+        fake_hip.message = "workspace too small"
+        calls.clear()
+        with pytest.raises(_lib.Ns2Error):
+            d.ddim_sample((2, 12, 64), noise=noise)
+        assert m.precision == "mixed" and calls == ["mixed", "mixed"]       # not a range error: no second attempt
+    finally:
+        del type(m)._forward_hip
