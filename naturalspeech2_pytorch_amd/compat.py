@@ -39,9 +39,14 @@ def hip_backed_model_class(reference_model_cls):
             """train_backend="reference" (default): the reference's own forward under torch autograd -- the loss is upstream's bit for
             bit.  "hip": forward AND backward in libns2hip (training.py), through the reference's own parameters; the unmodified
             reference `Trainer` / `NaturalSpeech2.forward` (NS2:1635, 1886) then trains on the HIP kernels."""
-            if self.train_backend == "hip" and x.is_cuda:
-                from .training import model_forward_train
-                return model_forward_train(self, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)
+            if self.train_backend == "hip" and x.is_cuda and prompt_mask is None:
+                # (a prompt_mask goes to the reference's own forward below, which raises on it: model.py _PROMPT_MASK_MSG)
+                from . import training
+                why = training.unsupported_reason(self)
+                if why is None:
+                    return training.model_forward_train(self, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)
+                import warnings
+                warnings.warn(f"HIP training path not usable for this Model ({why}): running the reference's own forward")
             return reference_model_cls.forward(self, x, times, prompt=prompt, prompt_mask=prompt_mask, cond=cond,
                                                cond_drop_prob=cond_drop_prob)
 

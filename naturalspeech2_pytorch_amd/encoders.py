@@ -12,7 +12,7 @@ from torch import nn
 from . import ops
 from ._cache import PackedCache
 from .model import _NoParams, _PRECISIONS
-from .transformer import Transformer
+from .transformer import Transformer, needs_autograd
 
 
 class _ConvStack(PackedCache):
@@ -49,7 +49,7 @@ class SpeechPromptEncoder(nn.Module):
         """Under autograd (the reference trains prompt_enc jointly, NS2:1542-1543) the differentiable composite runs; inference
         runs in the HIP kernels."""
         assert x.shape[-1] == self.dim
-        if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
+        if needs_autograd(self, x):
             from .autograd_path import speech_prompt_encoder_autograd
             return speech_prompt_encoder_autograd(self, x)
         return self._forward_hip(x)
@@ -95,7 +95,7 @@ class PhonemeEncoder(nn.Module):
     def forward(self, x, mask=None):
         if not torch.is_tensor(x):
             raise NotImplementedError("List[str] input needs the tokenizer / espeak front-end (out of scope); pass token ids")
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+        if needs_autograd(self):
             from .autograd_path import phoneme_encoder_autograd
             return phoneme_encoder_autograd(self, x, mask)
         return self._forward_hip(x, mask)

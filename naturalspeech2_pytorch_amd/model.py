@@ -405,7 +405,7 @@ class HipDenoiserMixin:
     @torch.no_grad()
     def _forward_hip(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None, out=None, cond_row=None):
         if prompt_mask is not None:
-            raise NotImplementedError("prompt_mask: no reference caller passes one (NS2:1333, 1410, 1635)")
+            raise NotImplementedError(_PROMPT_MASK_MSG)
         p = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
         conditional = bool(self._hip_cfg["condition_on_prompt"])
         if conditional and p not in (0, 0., 1, 1.):
@@ -483,12 +483,27 @@ class HipDenoiserMixin:
         return out, bufs
 
 
-def _train_forward(m, x, times, prompt, cond, cond_drop_prob):
+# `prompt_mask` is in the reference's signature (NS2:929-937) but upstream cannot run with one: the resampler's attention
+# concatenates its 32 latents in front of the prompt keys (cross_attn_include_queries, NS2:1060-1061) and then applies the
+# [b, n_p] mask to [b, h, 32, 32 + n_p] scores -- a shape error on both of Attend's paths (ATT:92-94, 136-138; verified by
+# execution, tests/test_compat_reference.py).  No upstream caller passes it (NS2:1333, 1410, 1635).  Every path of this package
+# rejects it the same way instead of guessing a semantics the reference never had.
+_PROMPT_MASK_MSG = ("prompt_mask: the reference itself raises on it (the PerceiverResampler applies the [b, n_p] mask to scores over "
+                    "32 + n_p keys, NS2:962-968 / 1060-1061 / ATT:92-94) and no reference caller passes one")
+
+
+def _train_forward(m, x, times, prompt, cond, cond_drop_prob, prompt_mask=None):
     import os
     from . import training
+    if prompt_mask is not None:
+        raise NotImplementedError(_PROMPT_MASK_MSG)
     which = os.environ.get("NS2_TRAIN_BACKEND") or getattr(m, "train_backend", "hip")
     if which == "hip" and training.available(next(m.parameters()).device):
-        return training.model_forward_train(m, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)
+        why = training.unsupported_reason(m)
+        if why is None:
+            return training.model_forward_train(m, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)
+        import warnings
+        warnings.warn(f"HIP training path not usable for this Model ({why}): running the PyTorch composite")
     from .autograd_path import model_forward_autograd
     return model_forward_autograd(m, x, times, prompt=prompt, cond=cond, cond_drop_prob=cond_drop_prob)
 
@@ -597,4 +612,4 @@ class Model(HipDenoiserMixin, nn.Module):
         (training.py: forward and backward kernels of libns2hip behind torch.autograd.Functions).  `train_backend = "composite"`
         (or NS2_TRAIN_BACKEND=composite), and parameters on the CPU (BASELINE config 1 as the reference runs it): the PyTorch
         composite of autograd_path.py."""
-        return _train_forward(self, x, times, prompt, cond, cond_drop_prob)
+        return _train_forward(self, x, times, prompt, cond, cond_drop_prob, prompt_mask=prompt_mask)

@@ -114,6 +114,11 @@ class HipBackend:
         x = x if x.is_contiguous() else x.contiguous()
         return ops.split(x, precision=3)
 
+    @staticmethod
+    def _rows(t, d):
+        """[M, d] fp32 with row stride exactly d (kernels that take no stride for this operand)"""
+        return t if (t.stride(1) == 1 and t.stride(0) == d) else t.contiguous()
+
     def rmsnorm(self, x, seq_len, gamma=None, cond=None):
         return ops.rmsnorm(x, seq_len=seq_len, gamma=gamma, cond=cond, precision=3)
 
@@ -172,6 +177,8 @@ class HipBackend:
     def grad_prep(self, x, C, want_row=False, want_t=False, want_colsum=False, seq_len=0, per_batch=False, t_rows=None):
         """x fp32 [M, >= C] -> (row planes [M, round_up(C, 32)], transposed planes, column sums [C])"""
         M, dev = x.shape[0], x.device
+        if not (want_row or want_t or want_colsum):
+            return None, None, None
         row = ops.empty_planes(M, round_up(C, 32), dev) if want_row else None
         tp, ld_t = None, 0
         if want_t:
@@ -246,6 +253,8 @@ class HipBackend:
         dx = torch.empty(B * seq_len, d, dtype=torch.float32, device=dev)
         cpart = torch.empty(B * S, 2 * d, dtype=torch.float32, device=dev) if cond is not None else None
         gpart = torch.empty(B * S, d, dtype=torch.float32, device=dev) if gamma is not None else None
+        if dx_add is not None:
+            dx_add = self._rows(dx_add[:, :d], d)          # the kernel reads dx_add with dx's row stride (= d)
         check(self.lib.ns2_rmsnorm_bwd(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), _p(gamma), _p(cond),
                                        cond.stride(0) if cond is not None else 0, B, seq_len, d, _p(dx_add), dx.data_ptr(), d, _p(cpart),
                                        _p(gpart), _s()), "ns2_rmsnorm_bwd")
@@ -350,9 +359,13 @@ class GemmFn(torch.autograd.Function):
         taps, dil, seq_len, cin, has_resid = ctx.cfg
         cout = w.shape[0]
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
-        dy_row, dy_t, db = bk.grad_prep(dy, cout, want_row=ctx.needs_input_grad[0], want_t=True, want_colsum=b is not None)
-        xt = bk.transpose(ctx.xp, 0, cin, seq_len if taps else 0, _shifts(taps, dil))
-        dw = _dw(bk.wgrad(dy_t, xt, cout, max(taps, 1), cin), w)
+        # (frozen weights / a gradient wanted for the input only -- guidance: no wgrad GEMM, no transposes, no workspace: ADVICE r4)
+        need_w, need_b = ctx.needs_input_grad[1], b is not None and ctx.needs_input_grad[2]
+        dy_row, dy_t, db = bk.grad_prep(dy, cout, want_row=ctx.needs_input_grad[0], want_t=need_w, want_colsum=need_b)
+        dw = None
+        if need_w:
+            xt = bk.transpose(ctx.xp, 0, cin, seq_len if taps else 0, _shifts(taps, dil))
+            dw = _dw(bk.wgrad(dy_t, xt, cout, max(taps, 1), cin), w)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = bk.gemm_f32(_bwd_pack(bk, w), dy_row, taps=taps, dil=dil, seq_len=seq_len if taps else 0, pad_left=0 if taps else -1)[:, :cin]
@@ -381,12 +394,17 @@ class WavenetBlockFn(torch.autograd.Function):
         seq_len, dil, d = ctx.cfg
         B = dout.shape[0] // seq_len
         dout = dout if dout.stride(1) == 1 else dout.contiguous()
-        dout_row, dout_t, dbr = bk.grad_prep(dout, d, want_row=True, want_t=True, want_colsum=True)
+        ng = ctx.needs_input_grad                                           # (u, film, wc, bc, wr, br, -, -)
+        dout_row, dout_t, dbr = bk.grad_prep(dout, d, want_row=True, want_t=ng[4], want_colsum=ng[5])
         dhc, dfilm = bk.film_gate_bwd(dout, hc, film, B, seq_len, d)
-        dhc_row, dhc_t, dbc = bk.grad_prep(dhc, d, want_row=True, want_t=True, want_colsum=True)
-        xt = bk.transpose(ctx.up, 0, d, seq_len, _shifts(3, dil))           # taps 0, 1, 2: shifts 2 dil, dil, 0
-        dwc = bk.wgrad(dhc_t, xt, d, 3, d)
-        dwr = bk.wgrad(dout_t, xt, d, 1, d, row_off=2 * round_up(d, 32))    # res_conv reads the unshifted block (tap 2)
+        dhc_row, dhc_t, dbc = bk.grad_prep(dhc, d, want_row=True, want_t=ng[2], want_colsum=ng[3])
+        dwc = dwr = None
+        if ng[2] or ng[4]:
+            xt = bk.transpose(ctx.up, 0, d, seq_len, _shifts(3, dil))       # taps 0, 1, 2: shifts 2 dil, dil, 0
+            if ng[2]:
+                dwc = bk.wgrad(dhc_t, xt, d, 3, d)
+            if ng[4]:
+                dwr = bk.wgrad(dout_t, xt, d, 1, d, row_off=2 * round_up(d, 32))    # res_conv reads the unshifted block (tap 2)
         du = bk.gemm_f32(_bwd_pack(bk, wc), dhc_row, taps=3, dil=dil, seq_len=seq_len, pad_left=0)
         du = bk.gemm_f32(_bwd_pack(bk, wr), dout_row, resid=du, taps=1, dil=1, seq_len=seq_len, pad_left=0)
         return du[:, :d], dfilm, dwc, dbc, dwr, dbr, None, None
@@ -427,8 +445,9 @@ class AttnFn(torch.autograd.Function):
         M, d = h.shape
         B, a = M // seq_len, heads * 64
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
-        dy_row, dy_t, _ = bk.grad_prep(dy, d, want_row=True, want_t=True)
-        dwout = bk.wgrad(dy_t, bk.transpose(o, 0, a, 0), d, 1, a)[:, :, 0]
+        ng = ctx.needs_input_grad                                           # (h, film, ctxt, wq, wkv, wout, ...)
+        dy_row, dy_t, _ = bk.grad_prep(dy, d, want_row=True, want_t=ng[5])
+        dwout = bk.wgrad(dy_t, bk.transpose(o, 0, a, 0), d, 1, a)[:, :, 0] if ng[5] else None
         do = bk.gemm_f32(_bwd_pack(bk, wout), dy_row)                       # [M, a]
         delta = bk.attention_delta(do, o, B, heads, seq_len)
         do_row, do_tb, _ = bk.grad_prep(do, a, want_row=True, want_t=True, seq_len=seq_len, per_batch=True)
@@ -437,9 +456,12 @@ class AttnFn(torch.autograd.Function):
         if not cross:
             dqkv = torch.empty(M, 3 * a, dtype=torch.float32, device=h.device)
             bk.attention_bwd(q, qc, k, kc, v, vc, do_row, kt, qt, do_tb, lse, delta, B, heads, seq_len, Nk, dq=(dqkv, 0), dkv=(dqkv, a, 2 * a))
-            g_row, g_t, _ = bk.grad_prep(dqkv, 3 * a, want_row=True, want_t=True)
-            dwqkv = bk.wgrad(g_t, bk.transpose(xn, 0, d, 0), 3 * a, 1, d)[:, :, 0]
-            dwq, dwkv = dwqkv[:a], dwqkv[a:]
+            need_w = ng[3] or ng[4]
+            g_row, g_t, _ = bk.grad_prep(dqkv, 3 * a, want_row=True, want_t=need_w)
+            dwq = dwkv = None
+            if need_w:
+                dwqkv = bk.wgrad(g_t, bk.transpose(xn, 0, d, 0), 3 * a, 1, d)[:, :, 0]
+                dwq, dwkv = dwqkv[:a], dwqkv[a:]
             wqkv = bk.pack(("qkv_b", id(wq), id(wkv)), (wq, wkv), lambda: torch.cat((wq.detach(), wkv.detach()), 0).t())
             dxn = bk.gemm_f32(wqkv, g_row)
             dctx = None
@@ -447,12 +469,12 @@ class AttnFn(torch.autograd.Function):
             dq = torch.empty(M, a, dtype=torch.float32, device=h.device)
             dkv = torch.empty(B * Nk, 2 * a, dtype=torch.float32, device=h.device)
             bk.attention_bwd(q, qc, k, kc, v, vc, do_row, kt, qt, do_tb, lse, delta, B, heads, seq_len, Nk, dq=(dq, 0), dkv=(dkv, 0, a))
-            q_row, q_t, _ = bk.grad_prep(dq, a, want_row=True, want_t=True)
-            dwq = bk.wgrad(q_t, bk.transpose(xn, 0, d, 0), a, 1, d)[:, :, 0]
+            q_row, q_t, _ = bk.grad_prep(dq, a, want_row=True, want_t=ng[3])
+            dwq = bk.wgrad(q_t, bk.transpose(xn, 0, d, 0), a, 1, d)[:, :, 0] if ng[3] else None
             dxn = bk.gemm_f32(_bwd_pack(bk, wq), q_row)
-            kv_row, kv_t, _ = bk.grad_prep(dkv, 2 * a, want_row=True, want_t=True)
-            dwkv = bk.wgrad(kv_t, bk.transpose(cp, 0, d, 0), 2 * a, 1, d)[:, :, 0]
-            dctx = bk.gemm_f32(_bwd_pack(bk, wkv), kv_row)[:, :d] if ctx.needs_input_grad[2] else None
+            kv_row, kv_t, _ = bk.grad_prep(dkv, 2 * a, want_row=ng[2], want_t=ng[4])
+            dwkv = bk.wgrad(kv_t, bk.transpose(cp, 0, d, 0), 2 * a, 1, d)[:, :, 0] if ng[4] else None
+            dctx = bk.gemm_f32(_bwd_pack(bk, wkv), kv_row)[:, :d] if ng[2] else None
         dh, dfilm, _ = bk.rmsnorm_bwd(h, dxn, B, seq_len, d, cond=film, dx_add=dy)
         return dh, dfilm, dctx, dwq, dwkv, dwout, None, None, None
 
@@ -483,15 +505,16 @@ class FeedForwardFn(torch.autograd.Function):
         M, d = h.shape
         B = M // seq_len
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
-        dy_row, dy_t, db2 = bk.grad_prep(dy, d, want_row=True, want_t=True, want_colsum=True)
-        dw2 = bk.wgrad(dy_t, bk.transpose(cp, 0, round_up(f, 32), 0), d, 1, f)[:, :, 0]
+        ng = ctx.needs_input_grad                                           # (h, film, w1, b1, wc, bc, w2, b2, -)
+        dy_row, dy_t, db2 = bk.grad_prep(dy, d, want_row=True, want_t=ng[6], want_colsum=ng[7])
+        dw2 = bk.wgrad(dy_t, bk.transpose(cp, 0, round_up(f, 32), 0), d, 1, f)[:, :, 0] if ng[6] else None
         dc = bk.gemm_f32(_bwd_pack(bk, w2), dy_row)                         # [M, f]
-        dc_row, dc_t, dbc = bk.grad_prep(dc, f, want_row=True, want_t=True, want_colsum=True)
-        dwc = bk.wgrad(dc_t, bk.transpose(hp, 0, round_up(f, 32), seq_len, _shifts(3, 1)), f, 3, f)
+        dc_row, dc_t, dbc = bk.grad_prep(dc, f, want_row=True, want_t=ng[4], want_colsum=ng[5])
+        dwc = bk.wgrad(dc_t, bk.transpose(hp, 0, round_up(f, 32), seq_len, _shifts(3, 1)), f, 3, f) if ng[4] else None
         dhh = bk.gemm_f32(_bwd_pack(bk, wc), dc_row, taps=3, dil=1, seq_len=seq_len, pad_left=0)
         dpre = bk.geglu_bwd(dhh, pre, f)                                    # [M, 2 f]
-        p_row, p_t, db1 = bk.grad_prep(dpre, 2 * f, want_row=True, want_t=True, want_colsum=True)
-        dw1 = bk.wgrad(p_t, bk.transpose(xn, 0, d, 0), 2 * f, 1, d)[:, :, 0]
+        p_row, p_t, db1 = bk.grad_prep(dpre, 2 * f, want_row=True, want_t=ng[2], want_colsum=ng[3])
+        dw1 = bk.wgrad(p_t, bk.transpose(xn, 0, d, 0), 2 * f, 1, d)[:, :, 0] if ng[2] else None
         dxn = bk.gemm_f32(_bwd_pack(bk, w1), p_row)
         dh, dfilm, _ = bk.rmsnorm_bwd(h, dxn, B, seq_len, d, cond=film, dx_add=dy)
         return dh, dfilm, dw1, db1, dwc, dbc, dw2, db2, None
@@ -515,8 +538,8 @@ class NormLinearFn(torch.autograd.Function):
         h, gamma, w = ctx.saved_tensors
         M, d = h.shape
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
-        dy_row, dy_t, _ = bk.grad_prep(dy, w.shape[0], want_row=True, want_t=True)
-        dw = bk.wgrad(dy_t, bk.transpose(ctx.xn, 0, d, 0), w.shape[0], 1, d)[:, :, 0]
+        dy_row, dy_t, _ = bk.grad_prep(dy, w.shape[0], want_row=True, want_t=ctx.needs_input_grad[2])
+        dw = bk.wgrad(dy_t, bk.transpose(ctx.xn, 0, d, 0), w.shape[0], 1, d)[:, :, 0] if ctx.needs_input_grad[2] else None
         dxn = bk.gemm_f32(_bwd_pack(bk, w), dy_row)
         dh, _, dgamma = bk.rmsnorm_bwd(h, dxn, M // ctx.seq_len, ctx.seq_len, d, gamma=gamma)
         return dh, dgamma, dw, None
@@ -685,3 +708,19 @@ def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None
 def available(device):
     """the HIP training path needs the library and parameters on an MI355X"""
     return device.type == "cuda" and torch.cuda.is_available()
+
+
+def unsupported_reason(m):
+    """None when `model_forward_train` can run `m`, else why not.  The Functions above are written for what the inference executor
+    accepts (ns2_model_create): heads of 64 (q / k / v column offsets, the attention kernels' head dim, scale 1/8), dim a multiple
+    of 32 (whole 32-column lines per operand row), fp32 parameters (the packs and the returned gradients are fp32).  Anything else
+    must not reach the kernels (a `dim_head=32` model would read past its packed qkv planes)."""
+    cfg = m._hip_cfg
+    if cfg["dim_head"] != 64:
+        return f"dim_head={cfg['dim_head']} (the HIP attention kernels have a head dim of 64)"
+    if cfg["dim"] % 32:
+        return f"dim={cfg['dim']} is not a multiple of 32"
+    for name, p in m.named_parameters():
+        if p.dtype != torch.float32:
+            return f"parameter {name} is {p.dtype} (fp32 master weights are required)"
+    return None

@@ -11,6 +11,34 @@ from ._cache import PackedCache
 from .model import _Attention, _RMSNorm, _feedforward, _PRECISIONS
 
 
+_warned_eval_no_graph = False
+
+
+def needs_autograd(module, x=None):
+    """Which path a per-utterance module (plain `Transformer`, `SpeechPromptEncoder`, `PhonemeEncoder`) takes: the differentiable
+    PyTorch composite when a gradient can be wanted -- grad mode on AND (the input carries one, or the module is in training mode
+    with trainable parameters) -- else the forward-only HIP kernels.  An `eval()` module called without `torch.no_grad()` keeps
+    the HIP kernels and its `precision` (a freshly built module has requires_grad parameters: ADVICE r3) -- but PyTorch's `eval()`
+    does not switch autograd off, so that call records NO graph where the reference would: it warns once, and
+    `module.force_autograd = True` (or `.train()`, or an input that requires grad) selects the composite."""
+    if not torch.is_grad_enabled():
+        return False
+    if (x is not None and torch.is_tensor(x) and x.requires_grad) or getattr(module, "force_autograd", False):
+        return True
+    trainable = any(p.requires_grad for p in module.parameters())
+    if module.training and trainable:
+        return True
+    if trainable:
+        global _warned_eval_no_graph
+        if not _warned_eval_no_graph:
+            _warned_eval_no_graph = True
+            import warnings
+            warnings.warn(f"{type(module).__name__} is in eval() mode with grad enabled and trainable parameters: running the forward-only "
+                          f"HIP kernels, no autograd graph is recorded.  For gradients call .train(), set .force_autograd = True, or "
+                          f"pass an input that requires grad; for inference wrap the call in torch.no_grad().")
+    return False
+
+
 class Transformer(nn.Module):
     def __init__(self, dim, *, depth, causal=False, dim_head=64, heads=8, use_flash=False, dropout=0., ff_mult=4,
                  final_norm=False, precision="exact"):
@@ -49,10 +77,7 @@ class Transformer(nn.Module):
         return packed
 
     def _needs_autograd(self, x):
-        """the differentiable composite only when a gradient can be wanted: grad mode on AND (the input carries one, or the module
-        is in training mode with trainable parameters).  An `eval()` module called without `torch.no_grad()` keeps the HIP
-        kernels and its `precision` (a freshly built module has requires_grad parameters)."""
-        return torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters())))
+        return needs_autograd(self, x)
 
     def forward(self, x, mask=None):
         """x [b, n, dim]; mask: optional bool [b, n] key-padding mask (True = attend).  Under autograd (training: the reference

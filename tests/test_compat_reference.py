@@ -95,3 +95,28 @@ def test_our_loss_equals_the_reference_loss_bit_for_bit():
         torch.manual_seed(5)
         lo = do(audio)
         assert abs(lr.item() - lo.item()) < 2e-6 * max(1., abs(lr.item())), (objective, lr.item(), lo.item())
+
+
+@pytest.mark.parametrize("use_flash_attn", [True, False])
+def test_upstream_cannot_run_with_a_prompt_mask(use_flash_attn):
+    """`Model.forward(prompt_mask=)` (NS2:929-937) is unrunnable upstream: the resampler's attention puts its 32 latents in front of
+    the prompt keys (cross_attn_include_queries, NS2:1060-1061) and then applies the [b, n_p] mask to scores over 32 + n_p keys
+    (ATT:92-94 on the SDPA path, ATT:136-138 on the einsum path).  That is why every path of this package rejects the argument
+    (model.py `_PROMPT_MASK_MSG`; tests/test_host_cpu.py) -- like `ddpm_sample`, a reference defect that is kept, not papered over."""
+    ns2 = load_reference()
+    m = ns2.Model(dim=64, depth=1, dim_prompt=64, condition_on_prompt=True, use_flash_attn=use_flash_attn)
+    x, t = torch.randn(2, 16, 64), torch.rand(2)
+    prompt, cond = torch.randn(2, 10, 64), torch.randn(2, 64, 16)
+    mask = torch.ones(2, 10, dtype=torch.bool)
+    with torch.no_grad():
+        m(x, t, prompt=prompt, cond=cond)                                     # runs without the mask
+        with pytest.raises(RuntimeError, match="must match the size"):
+            m(x, t, prompt=prompt, prompt_mask=mask, cond=cond)
+    # the subclass at the reference's own boundary: the mask reaches the reference's forward (and its error) on the autograd path,
+    # and is rejected with the reason on the HIP path
+    H = hip_backed_model_class(ns2.Model)
+    h = H(dim=64, depth=1, dim_prompt=64, condition_on_prompt=True, use_flash_attn=use_flash_attn, train_backend="hip")
+    with pytest.raises(RuntimeError, match="must match the size"):
+        h(x, t, prompt=prompt, prompt_mask=mask, cond=cond)
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="reference itself raises"):
+        h(x, t, prompt=prompt, prompt_mask=mask, cond=cond)

@@ -620,3 +620,41 @@ def test_sampler_demotes_to_exact_when_a_fast_mode_leaves_the_half_range():
         assert m.precision == "mixed" and calls == ["mixed", "mixed"]       # not a range error: no second attempt
     finally:
         del type(m)._forward_hip
+
+
+def test_prompt_mask_is_rejected_on_every_path_like_upstream():
+    """`prompt_mask` is in the reference's signature but the reference raises on it (shape error in the resampler's attention:
+    test_compat_reference.py runs that); every path of this package rejects it with the reason instead of guessing a semantics"""
+    import pytest
+    import torch
+    from naturalspeech2_pytorch_amd import Model
+    m = Model(dim=64, depth=1, dim_prompt=64, condition_on_prompt=True)
+    x, t = torch.randn(2, 16, 64), torch.rand(2)
+    prompt, cond = torch.randn(2, 10, 64), torch.randn(2, 64, 16)
+    mask = torch.ones(2, 10, dtype=torch.bool)
+    with pytest.raises(NotImplementedError, match="reference itself raises"):
+        m(x, t, prompt=prompt, prompt_mask=mask, cond=cond)                     # autograd path (parameters require grad)
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="reference itself raises"):
+        m(x, t, prompt=prompt, prompt_mask=mask, cond=cond)                     # inference path: rejected before any device work
+
+
+def test_eval_module_without_no_grad_warns_once_and_force_autograd_selects_the_composite():
+    """eval() does not switch autograd off in PyTorch; a per-utterance module that keeps its HIP kernels there says so"""
+    import warnings
+    import torch
+    from naturalspeech2_pytorch_amd import transformer as T
+    tr = T.Transformer(dim=64, depth=1).eval()
+    x = torch.randn(1, 8, 64)
+    T._warned_eval_no_graph = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert T.needs_autograd(tr, x) is False
+        assert T.needs_autograd(tr, x) is False
+    assert len([i for i in w if "no autograd graph" in str(i.message)]) == 1
+    assert T.needs_autograd(tr, x.clone().requires_grad_(True)) is True
+    tr.force_autograd = True
+    assert T.needs_autograd(tr, x) is True
+    tr.force_autograd = False
+    assert T.needs_autograd(tr.train(), x) is True
+    with torch.no_grad():
+        assert T.needs_autograd(tr, x) is False

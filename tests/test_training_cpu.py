@@ -163,3 +163,64 @@ def test_gradients_match_the_reference_autograd_golden(emu, name):
     w1 = _check_against_golden_grads(fix, m, model_forward_autograd, x, t, extra, 2e-5)
     w2 = _check_against_golden_grads(fix, m, training.model_forward_train, x, t, extra, 2e-4)
     print("worst vs the reference's autograd:", w1, w2)
+
+
+def test_frozen_weights_skip_the_weight_gradients(emu):
+    """with every parameter frozen and only x.requires_grad (guidance, gradient-based analysis) the backward must not run
+    a single wgrad GEMM or operand transpose -- and dL/dx must still be the composite's"""
+    kw = dict(dim=64, depth=1, wavenet_layers=2, wavenet_stacks=2)
+    m = Model(**kw)
+    m.load_state_dict(make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=5))
+    for p in m.parameters():
+        p.requires_grad_(False)
+    x = make_input("x", (2, 40, 64), seed=6)
+    t = make_input("times", (2,), seed=6, uniform=True)
+    bk = training.backend()
+    calls = {"wgrad": 0, "transpose": 0}
+    w0, t0 = bk.wgrad, bk.transpose
+
+    def wgrad(*a, **k):
+        calls["wgrad"] += 1
+        return w0(*a, **k)
+
+    def transpose(p, col0, C, seq_len, shifts=(0,), per_batch=False, **k):
+        calls["transpose"] += 0 if per_batch else 1          # per_batch transposes feed the attention backward, not a wgrad
+        return t0(p, col0, C, seq_len, shifts, per_batch=per_batch, **k)
+
+    bk.wgrad, bk.transpose = wgrad, transpose
+    try:
+        _, dx0, _ = _grads(m, model_forward_autograd, x, t)
+        calls["wgrad"] = calls["transpose"] = 0
+        _, dx1, g1 = _grads(m, training.model_forward_train, x, t)
+    finally:
+        bk.wgrad, bk.transpose = w0, t0
+    assert calls == {"wgrad": 0, "transpose": 0}, calls
+    assert all(g is None for g in g1.values())
+    assert _rel(dx1, dx0) < 1e-4
+
+
+def test_partially_frozen_model_trains_the_rest(emu):
+    """only the Wavenet's res convs and the FF-out weights trainable: their gradients match the composite's, the frozen ones get none"""
+    m = Model(dim=64, depth=1, wavenet_layers=2, wavenet_stacks=2)
+    m.load_state_dict(make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=5))
+    keep = lambda k: "res_conv" in k or k.endswith("5.3.weight")          # noqa: E731
+    for k, p in m.named_parameters():
+        p.requires_grad_(keep(k))
+    x = make_input("x", (2, 40, 64), seed=6)
+    t = make_input("times", (2,), seed=6, uniform=True)
+    _, dx0, g0 = _grads(m, model_forward_autograd, x, t)
+    _, dx1, g1 = _grads(m, training.model_forward_train, x, t)
+    assert _rel(dx1, dx0) < 1e-4
+    for k in g0:
+        if keep(k):
+            assert g1[k] is not None and _rel(g1[k], g0[k]) < 1e-4, k
+        else:
+            assert g1[k] is None, k
+
+
+def test_training_path_refuses_shapes_the_kernels_are_not_written_for():
+    """dim_head != 64 must never reach the HIP training kernels (q / k / v offsets assume heads of 64)"""
+    assert training.unsupported_reason(Model(dim=64, depth=1)) is None
+    why = training.unsupported_reason(Model(dim=64, depth=1, dim_head=32))
+    assert why is not None and "dim_head" in why
+    assert "fp32" in training.unsupported_reason(Model(dim=64, depth=1).half())

@@ -152,6 +152,9 @@ SCHEMES = [
     Scheme("fp16 hi.hi + cross terms fp8 e5m2 (GEMMs), fp16 attention", 2.0, f16_e5m2_cross(), mk(FH, [(0, 0)])),
     per_site("mixed, FF conv fp16 x1", 1.55, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)])),
     per_site("mixed, FF conv + wavenet k3 convs fp16 x1 (= hybrid)", 1.4, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), wavenet3=mk(FH, [(0, 0)])),
+    per_site("hybrid + FF-in fp16 x1 (= hybrid_ffin)", 1.3, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), wavenet3=mk(FH, [(0, 0)]), ffin=mk(FH, [(0, 0)])),
+    per_site("hybrid + FF-out fp16 x1", 1.35, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), wavenet3=mk(FH, [(0, 0)]), ffout=mk(FH, [(0, 0)])),
+    per_site("hybrid + whole FF fp16 x1 (= hybrid_ff)", 1.2, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), wavenet3=mk(FH, [(0, 0)]), ffin=mk(FH, [(0, 0)]), ffout=mk(FH, [(0, 0)])),
     per_site("mixed, FF conv + wavenet 1x1 convs fp16 x1", 1.45, f16_e5m2_cross(), ffconv=mk(FH, [(0, 0)]), wavenet1=mk(FH, [(0, 0)])),
     per_site("mixed, FF-in fp16 x1", 1.9, f16_e5m2_cross(), ffin=mk(FH, [(0, 0)])),
     per_site("mixed, FF-out fp16 x1", 1.95, f16_e5m2_cross(), ffout=mk(FH, [(0, 0)])),
