@@ -42,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PMC_TRAFFIC = "r04_pmc_traffic.json"  # profiles/: committed PMC profile of the dominant kernel (tools/final_profile_r4.sh)
-PARITY_RECORD = "r04_parity.json"    # profiles/: the tracked key-wise parity record (tests/parity_record.py)
+PARITY_RECORD = "r05_parity.json"    # profiles/: the tracked key-wise parity record (tests/parity_record.py)
 PEAK_16BIT_TFLOPS = 2500.0         # dense bf16 / f16 MFMA peak, MI355X_MICROARCH.md (spec; 2495 measured)
 PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (RVQ)
 UTT_GFLOP = {(512, 12, False): 316.37, (512, 12, True): 331.98, (128, 6, False): 26.74}   # per 1024-frame utterance, SURVEY §8d
@@ -103,7 +103,10 @@ def train_step_side(dev):
             for _ in range(k):
                 loss = step()
             torch.cuda.synchronize()
-            res[backend] = ((time.perf_counter() - t0) / k, float(loss.detach()))
+            dt = (time.perf_counter() - t0) / k
+            for _ in range(iters - k):                   # (untimed) so that both backends report the loss of the SAME iteration
+                loss = step()
+            res[backend] = (dt, float(loss.detach()))
             del m, d, opt
             torch.cuda.empty_cache()
         flops = 3.0 * UTT_GFLOP[(kw["dim"], kw["depth"], False)] * 1e9 * b * n / 1024        # forward + dgrad + wgrad
@@ -116,8 +119,9 @@ def train_step_side(dev):
                         pytorch_composite_ms_per_step=round(1e3 * res["composite"][0], 2),
                         speedup_vs_pytorch_composite=round(res["composite"][0] / res["hip"][0], 2),
                         loss_hip=res["hip"][1], loss_composite=res["composite"][1],
+                        loss_iteration=f"both after 2 warm-up + {iters} Adam steps from the same init (bf16 x3 vs fp32 torch ops)",
                         parity="every parameter's .grad vs the reference's own autograd: tests/test_backward_gpu.py, "
-                               "profiles/r04_parity.json keys backward_vs_reference_autograd/*")
+                               "profiles/r05_parity.json keys backward_vs_reference_autograd/*")
     return out
 
 
@@ -305,8 +309,8 @@ def main():
                     step(tab[i - warmup] if use_table else None)
             if world > 1:                                # the sharded sampler's single collective
                 src = audio if dist.get_backend() != "gloo" else audio.cpu()     # gloo (functional test only) gathers on the host
-                bufs = [torch.empty_like(src) for _ in range(world)]
-                dist.all_gather(bufs, src)
+                gathered = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+                dist.all_gather_into_tensor(gathered, src)       # single-buffer form: the collective row measures the wire, not copies
             barrier()
             elapsed = time.perf_counter() - t0
             kern_ms, kern_n = ctypes.c_double(0), ctypes.c_int64(0)

@@ -56,12 +56,16 @@ def sharded_sample(sample_fn: Callable[[torch.Tensor], torch.Tensor], total: int
     per = (total + world - 1) // world
     pad = torch.zeros(per, length, dim, device=local.device, dtype=local.dtype)
     pad[: hi - lo] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)                                   # the only collective of the path
+    # the only collective of the path, in its single-buffer form: every rank's shard lands at its final offset of ONE
+    # [world * per, length, dim] tensor (the list form makes `world` extra device copies of 64 MiB each at dim 512)
+    gathered = torch.empty(world * per, length, dim, device=pad.device, dtype=pad.dtype)
+    dist.all_gather_into_tensor(gathered, pad)
+    if per * world == total:
+        return gathered
     parts = []
-    for r in range(world):
+    for r in range(world):                                       # uneven split: drop the padding rows of the short shards
         rlo, rhi = shard_range(total, r, world)
-        parts.append(bufs[r][: rhi - rlo])
+        parts.append(gathered[r * per: r * per + (rhi - rlo)])
     return torch.cat(parts, dim=0)
 
 

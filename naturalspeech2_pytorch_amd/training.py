@@ -21,8 +21,9 @@ precision the `Model` was built with -- gradients match the reference's fp32 aut
 Rows = batch entries: every conditioning Linear ([B, dim_cond] -> [B, 2 dim] for FiLM / adaptive norms, `to_time_cond.1`,
 `to_prompt_cond.1`: NS2:623, 744, 841, 860) is `SkinnyLinearFn` -- the fp32 weight-streaming kernel of the inference path in all
 three roles (y = x W^T + b, dx = dy W, dW = dy^T x).  What stays in PyTorch ops are pointwise glue on [B, *] rows (sin / cos of the
-time embedding, SiLU, cat, mean-pool, `torch.where` null selects) and the 32-token PerceiverResampler of the conditioned model
-(NS2:532-579: the composite of autograd_path.py).  Autograd chains them with the Functions above.
+time embedding, SiLU, cat, mean-pool, `torch.where` null selects) and `torch.cat` of the
+PerceiverResampler's context (NS2:1060-1061).  Autograd chains them with the Functions above; since round 5 the 32-token resampler
+of the conditioned model (NS2:532-579) runs on the same Functions (`_resampler`), so no contraction of `Model`'s backward is a torch op.
 
 `Backend` is the seam the CPU tests use: `tests/emu_backend.py` restates every backend call with plain torch ops on CPU, so the
 chain rule, tap flips, shifts and layouts of THIS file are checked against torch autograd without a GPU; the kernels behind
@@ -121,6 +122,10 @@ class HipBackend:
 
     def rmsnorm(self, x, seq_len, gamma=None, cond=None):
         return ops.rmsnorm(x, seq_len=seq_len, gamma=gamma, cond=cond, precision=3)
+
+    def rmsnorm_f32(self, x, gamma):
+        """RMSNorm(x) * gamma as fp32 [M, d] (the resampler's final norm, NS2:579: its output is a tensor of the graph, not an operand)"""
+        return ops.rmsnorm(x, seq_len=0, gamma=gamma, want_f32=True, precision=3)[1]
 
     def gemm_f32(self, pw, a, bias=None, resid=None, taps=0, dil=1, seq_len=0, pad_left=-1):
         """-> fp32 [M, ldo] with ldo = round_up(N, 32); columns >= N are NOT written"""
@@ -412,14 +417,16 @@ class WavenetBlockFn(torch.autograd.Function):
 
 class AttnFn(torch.autograd.Function):
     """h + to_out(attention(q, k, v)) with q = to_q(norm(h)), k, v = to_kv(context or norm(h)); norm = RMSNorm with the adaptive
-    (gamma, beta) of `film` (Model, NS2:727-746) -- heads of 64, non-causal, no mask (ATT:77-155)"""
+    (gamma, beta) of `film` (Model, NS2:727-746) -- heads of 64, non-causal, no mask (ATT:77-155).  `film = None`: no norm in front
+    (the PerceiverResampler's attention, NS2:574: its context = cat(latents, prompt) is formed by the caller, so the part of the
+    context gradient that belongs to the latents reaches them through torch's cat)"""
 
     @staticmethod
     def forward(ctx, h, film, ctxt, wq, wkv, wout, seq_len, heads, ctx_len):
         bk = backend()
         M, d = h.shape
         B, a = M // seq_len, heads * 64
-        xn = bk.rmsnorm(h, seq_len, cond=film)
+        xn = bk.rmsnorm(h, seq_len, cond=film) if film is not None else bk.split(h)
         if ctxt is None:                                                    # self attention: one GEMM for q | k | v
             wqkv = bk.pack(("qkv", id(wq), id(wkv)), (wq, wkv), lambda: torch.cat((wq.detach(), wkv.detach()), 0))
             qkv = bk.gemm_split(wqkv, xn)
@@ -475,22 +482,26 @@ class AttnFn(torch.autograd.Function):
             kv_row, kv_t, _ = bk.grad_prep(dkv, 2 * a, want_row=ng[2], want_t=ng[4])
             dwkv = bk.wgrad(kv_t, bk.transpose(cp, 0, d, 0), 2 * a, 1, d)[:, :, 0] if ng[4] else None
             dctx = bk.gemm_f32(_bwd_pack(bk, wkv), kv_row)[:, :d] if ng[2] else None
-        dh, dfilm, _ = bk.rmsnorm_bwd(h, dxn, B, seq_len, d, cond=film, dx_add=dy)
+        if film is None:
+            dh, dfilm = dy[:, :d] + dxn[:, :d], None
+        else:
+            dh, dfilm, _ = bk.rmsnorm_bwd(h, dxn, B, seq_len, d, cond=film, dx_add=dy)
         return dh, dfilm, dctx, dwq, dwkv, dwout, None, None, None
 
 
 class FeedForwardFn(torch.autograd.Function):
-    """h + Linear(CausalConv1d_k3(GEGLU(Linear(norm(h)))))   (NS2:1004-1025 with the adaptive RMSNorm in front, NS2:805-807)"""
+    """h + Linear(CausalConv1d_k3(GEGLU(Linear(norm(h)))))   (NS2:1004-1025 with the adaptive RMSNorm in front, NS2:805-807).
+    `film = None`: no norm; `wc = None`: no conv -- the PerceiverResampler's FeedForward (NS2:564, 575)"""
 
     @staticmethod
     def forward(ctx, h, film, w1, b1, wc, bc, w2, b2, seq_len):
         bk = backend()
         M, d = h.shape
         f = w2.shape[1]
-        xn = bk.rmsnorm(h, seq_len, cond=film)
+        xn = bk.rmsnorm(h, seq_len, cond=film) if film is not None else bk.split(h)
         pre = bk.gemm_f32(_fwd_pack(bk, w1), xn, bias=b1)                   # [M, 2 f]: x | gate
         hp = bk.geglu_fwd(pre, f)
-        cp = bk.gemm_split(_fwd_pack(bk, wc), hp, bias=bc, taps=3, dil=1, seq_len=seq_len)
+        cp = bk.gemm_split(_fwd_pack(bk, wc), hp, bias=bc, taps=3, dil=1, seq_len=seq_len) if wc is not None else hp
         y = bk.gemm_f32(_fwd_pack(bk, w2), cp, bias=b2, resid=h)
         ctx.save_for_backward(h, film, w1, wc, w2, pre)
         ctx.pl, ctx.cfg = (xn, hp, cp), (seq_len, f)
@@ -509,14 +520,21 @@ class FeedForwardFn(torch.autograd.Function):
         dy_row, dy_t, db2 = bk.grad_prep(dy, d, want_row=True, want_t=ng[6], want_colsum=ng[7])
         dw2 = bk.wgrad(dy_t, bk.transpose(cp, 0, round_up(f, 32), 0), d, 1, f)[:, :, 0] if ng[6] else None
         dc = bk.gemm_f32(_bwd_pack(bk, w2), dy_row)                         # [M, f]
-        dc_row, dc_t, dbc = bk.grad_prep(dc, f, want_row=True, want_t=ng[4], want_colsum=ng[5])
-        dwc = bk.wgrad(dc_t, bk.transpose(hp, 0, round_up(f, 32), seq_len, _shifts(3, 1)), f, 3, f) if ng[4] else None
-        dhh = bk.gemm_f32(_bwd_pack(bk, wc), dc_row, taps=3, dil=1, seq_len=seq_len, pad_left=0)
+        dwc = dbc = None
+        if wc is not None:
+            dc_row, dc_t, dbc = bk.grad_prep(dc, f, want_row=True, want_t=ng[4], want_colsum=ng[5])
+            dwc = bk.wgrad(dc_t, bk.transpose(hp, 0, round_up(f, 32), seq_len, _shifts(3, 1)), f, 3, f) if ng[4] else None
+            dhh = bk.gemm_f32(_bwd_pack(bk, wc), dc_row, taps=3, dil=1, seq_len=seq_len, pad_left=0)
+        else:
+            dhh = dc
         dpre = bk.geglu_bwd(dhh, pre, f)                                    # [M, 2 f]
         p_row, p_t, db1 = bk.grad_prep(dpre, 2 * f, want_row=True, want_t=ng[2], want_colsum=ng[3])
         dw1 = bk.wgrad(p_t, bk.transpose(xn, 0, d, 0), 2 * f, 1, d)[:, :, 0] if ng[2] else None
         dxn = bk.gemm_f32(_bwd_pack(bk, w1), p_row)
-        dh, dfilm, _ = bk.rmsnorm_bwd(h, dxn, B, seq_len, d, cond=film, dx_add=dy)
+        if film is None:
+            dh, dfilm = dy[:, :d] + dxn[:, :d], None
+        else:
+            dh, dfilm, _ = bk.rmsnorm_bwd(h, dxn, B, seq_len, d, cond=film, dx_add=dy)
         return dh, dfilm, dw1, db1, dwc, dbc, dw2, db2, None
 
 
@@ -543,6 +561,23 @@ class NormLinearFn(torch.autograd.Function):
         dxn = bk.gemm_f32(_bwd_pack(bk, w), dy_row)
         dh, _, dgamma = bk.rmsnorm_bwd(h, dxn, M // ctx.seq_len, ctx.seq_len, d, gamma=gamma)
         return dh, dgamma, dw, None
+
+
+class RmsNormFn(torch.autograd.Function):
+    """RMSNorm(h) * gamma as a tensor of the graph: the PerceiverResampler's final norm (NS2:579, 727-746 with scale = True)"""
+
+    @staticmethod
+    def forward(ctx, h, gamma):
+        ctx.save_for_backward(h, gamma)
+        return backend().rmsnorm_f32(h, gamma)
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, gamma = ctx.saved_tensors
+        M, d = h.shape
+        dy = dy if dy.stride(1) == 1 else dy.contiguous()
+        dh, _, dgamma = backend().rmsnorm_bwd(h, dy, 1, M, d, gamma=gamma)      # one "utterance" of M rows: the norm is per row
+        return dh, dgamma
 
 
 class SkinnyLinearFn(torch.autograd.Function):
@@ -614,10 +649,29 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _resampler(pr, prompt, heads):
+    """PerceiverResampler (NS2:532-579) on the Functions above: per layer latents += Attention(latents, context = cat(latents,
+    proj(prompt))) and latents += FeedForward(latents) (no norms in front, no conv), then RMSNorm * gamma.  Round 4 ran this part of
+    the conditioned model's graph as the PyTorch composite (0.2 % of the FLOPs, but the one piece of `Model`'s backward on torch ops)."""
+    b, n_p, _ = prompt.shape
+    pc = getattr(pr, "proj_context", None)
+    px = _c(prompt).reshape(b * n_p, -1)
+    if isinstance(pc, torch.nn.Linear):                                      # dim_prompt != dim (NS2:548)
+        px = GemmFn.apply(px, pc.weight, pc.bias, None, 0, 1)
+    Lm, d = pr.latents.shape
+    px = px.reshape(b, n_p, d)
+    lat = pr.latents[None].expand(b, -1, -1).reshape(b * Lm, d)              # (a copy: its gradient sums over the batch into pr.latents)
+    for attn, ff in pr.layers:
+        context = torch.cat((lat.reshape(b, Lm, d), px), dim=1).reshape(b * (Lm + n_p), d)     # cross_attn_include_queries, NS2:1060-1061
+        lat = AttnFn.apply(_c(lat), None, context, attn.to_q.weight, attn.to_kv.weight, attn.to_out.weight, Lm, heads, Lm + n_p)
+        l1, l2 = getattr(ff, "0"), getattr(ff, "2")
+        lat = FeedForwardFn.apply(_c(lat), None, l1.weight, l1.bias, None, None, l2.weight, l2.bias, Lm)
+    return RmsNormFn.apply(_c(lat), pr.norm.gamma).reshape(b, Lm, d)
+
+
 def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None):
     """`Model.forward` (NS2:929-1000) as a differentiable graph whose token-sized arithmetic is HIP (module docstring).
     `m` owns the reference's parameters (this package's `Model` or `compat.HipBackedModel`)."""
-    from . import autograd_path as AP
     b, n, d = x.shape
     M = b * n
     p = m.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
@@ -643,13 +697,7 @@ def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None
         pc = F.silu(_lin(getattr(m.to_prompt_cond, "1"), prompt.float().mean(dim=1)))
         pc = torch.where(dm[:, None], m.null_prompt_cond, pc)
         t = torch.cat((t, pc), dim=-1)
-        pr = m.perceiver_resampler                                          # 32 latents per utterance: the PyTorch composite
-        px = pr.proj_context(prompt) if hasattr(pr, "proj_context") else prompt
-        lat = pr.latents[None].expand(b, -1, -1)
-        for attn, ff in pr.layers:
-            lat = AP._attention(lat, attn, heads, context=px, include_queries=True) + lat
-            lat = AP._feedforward(lat, ff, False) + lat
-        c = torch.where(dm[:, None, None], m.null_prompt_tokens, AP._rmsnorm(lat, pr.norm))       # [b, Lm, d]
+        c = torch.where(dm[:, None, None], m.null_prompt_tokens, _resampler(m.perceiver_resampler, prompt.float(), heads))   # [b, Lm, d]
         # cond_to_model_dim: 1x1 conv over channel-first cond (NS2:978) = a Linear over the frames
         n_c = cond.shape[-1]
         cm = GemmFn.apply(_c(cond.float().transpose(1, 2)).reshape(b * n_c, -1), m.cond_to_model_dim.weight, m.cond_to_model_dim.bias, None,

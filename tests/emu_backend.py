@@ -66,6 +66,9 @@ class EmuBackend:
             y = (y.reshape(b, seq_len, d) * g[:, None] + be[:, None]).reshape(-1, d)
         return self.split(y)
 
+    def rmsnorm_f32(self, x, gamma):
+        return F.normalize(x, dim=-1) * math.sqrt(x.shape[1]) * gamma
+
     def _gemm(self, pw, a, taps, dil, seq_len, pad_left):
         w = pw.w
         M = a.rows

@@ -310,7 +310,7 @@ def test_parity_record_merges_key_by_key(tmp_path, monkeypatch):
     PR.record("a", 10)
     got = json.load(open(scratch))
     assert got["a"] == 10 and got["b"] == {"max": 2} and got["c"] == 3
-    assert got["_meta"]["updated_keys_r04"] == ["a", "c"]
+    assert got["_meta"]["updated_keys_r05"] == ["a", "c"]
 
 
 def test_conditional_training_reaches_the_encoders():

@@ -5,7 +5,7 @@ caller of the HIP model, the non-default schedules / objectives, concurrent mode
 there are two), the sampler over an RCCL process group, RVQ at BASELINE config-4 size with every mismatch adjudicated,
 and the codec boundary class with HF EnCodec's SEANet injected.
 
-Measured numbers are merged key by key into the parity record (tests/parity_record.py -> profiles/r04_parity.json)."""
+Measured numbers are merged key by key into the parity record (tests/parity_record.py -> profiles/r05_parity.json)."""
 import json
 import math
 import os

@@ -34,11 +34,12 @@ def _rel(a, b):
     return ((a - b).norm() / b.norm().clamp(min=1e-30)).item()
 
 
-@pytest.mark.parametrize("cond", [False, True], ids=["uncond", "cond"])
+@pytest.mark.parametrize("cond", [False, True, 96], ids=["uncond", "cond", "cond_proj_context"])
 def test_training_functions_match_autograd_composite(emu, cond):
     kw = dict(dim=64, depth=2, wavenet_layers=3, wavenet_stacks=2)
+    dpr = 64 if cond is True else cond             # dim_prompt != dim: the resampler's proj_context Linear (NS2:548) through GemmFn
     if cond:
-        kw.update(dim_prompt=64, condition_on_prompt=True, num_latents_m=8)
+        kw.update(dim_prompt=dpr, condition_on_prompt=True, num_latents_m=8)
     m = Model(**kw)
     sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=5)
     m.load_state_dict(sd)
@@ -47,7 +48,7 @@ def test_training_functions_match_autograd_composite(emu, cond):
     t = make_input("times", (b,), seed=6, uniform=True)
     extra = {}
     if cond:
-        extra = dict(prompt=make_input("prompt", (b, 11, 64), seed=7), cond=make_input("cond", (b, 64, 33), seed=7), cond_drop_prob=0.)
+        extra = dict(prompt=make_input("prompt", (b, 11, dpr), seed=7), cond=make_input("cond", (b, dpr, 33), seed=7), cond_drop_prob=0.)
     y0, dx0, g0 = _grads(m, model_forward_autograd, x, t, **extra)
     y1, dx1, g1 = _grads(m, training.model_forward_train, x, t, **extra)
     assert _rel(y1, y0) < 1e-5
