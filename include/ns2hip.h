@@ -21,7 +21,7 @@
  *     (ns2_*_workspace_bytes), constants live in per-device __device__ storage, so one host thread per device (or one
  *     process per device) may drive several devices concurrently, also under stream capture.  What it does keep, all of it
  *     write-once or atomic: per-device "attribute raised" / occupancy answers, the environment switches NS2_GEMM,
- *     NS2_WAVENET_DENSE, NS2_LSTM_PERSISTENT and NS2_LSTM_FUSED (read once per process), and the test hooks ns2_debug_*.  One thread-local
+ *     NS2_LSTM_PERSISTENT and NS2_LSTM_FUSED (read once per process), and the test hooks ns2_debug_*.  One thread-local
  *     pointer exists for the duration of a ns2_model_forward* / ns2_model_prepare_cond call: the split-K region of the
  *     workspace that call was given (set on entry, restored on return).
  *   - layout of a split-plane matrix (x_hi, x_lo, ld): `ld` is the LOGICAL column count, a multiple of 32.
@@ -53,11 +53,6 @@ int ns2_version(void);
 /* test hook: force the GEMM kernel variant (0 = dispatch by shape, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA,
  * 3 = dispatch by shape but never split K) */
 int ns2_debug_force_gemm(int kernel);
-/* test / A-B hook for models FINALIZED afterwards: the hybrid plan's Wavenet (model precision 5 / 6, dim > 128) keeps dense
- * IEEE-half copies of its column buffers and conv-tap weights for the half product of the dilated convs (1) or gathers the half
- * parts out of the FMT_H8 lines as rounds 2-4 did (0); -1 = what the environment says (NS2_WAVENET_DENSE, default 1).  Both give
- * the same bits (tests/test_round5_gpu.py). */
-int ns2_debug_wavenet_dense(int mode);
 /* Split-K of small products.  ns2_model_forward* lend a region of their workspace to every GEMM of the pass: a product with too
  * few output tiles to fill the chip runs as K slices into fixed slots plus a second launch that adds the slots in order and
  * applies the epilogue (deterministic).  The stand-alone GEMM entry points below have no workspace argument and never split --

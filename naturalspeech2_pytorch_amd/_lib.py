@@ -48,7 +48,6 @@ SIGNATURES = {
     "ns2_last_error": (c_char_p, []),
     "ns2_version": (I, []),
     "ns2_debug_force_gemm": (I, [I]),
-    "ns2_debug_wavenet_dense": (I, [I]),
     "ns2_splitk_scratch_bytes": (L, []),
     "ns2_debug_splitk_plan": (I, [I, I, I, I, I, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "ns2_debug_lend_splitk_scratch": (I, [P, L]),

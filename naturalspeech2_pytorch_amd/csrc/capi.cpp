@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 111; }   // 111: ns2_debug_wavenet_dense (dense half operands of the hybrid plan's Wavenet); 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 110; }   // 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 3, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel, 3 = auto without split-K");
   force_gemm_kernel(kernel);

@@ -43,25 +43,17 @@ NS2_DEVINL uint4 zero16() { return make_uint4(0u, 0u, 0u, 0u); }
 // private LDS region of WBUF bytes.  Returns false when the tile, the alignment or the format asks for the generic path.
 // HALF / BF: which plane formats this caller can be asked for (a kernel on IEEE-half operands writes F16 / H8, one on bf16 operands
 // bf16 planes; the split-K finishing kernel serves both).
-// DENSE2: the caller may be asked for GemmArgs::out2 next to FMT_H8 lines (mixed-mode kernels; others leave it to the generic path).
-template <int EPI, int WBUF, bool HALF, bool BF, bool BF_DENSE, bool DENSE2 = false>
+template <int EPI, int WBUF, bool HALF, bool BF, bool BF_DENSE>
 NS2_DEVINL bool small_tile_fast_epilogue(f32x16 (&acc)[2][2], const GemmArgs& g, int z, int row_base, int col_base, int ocol_base, int lane,
                                          unsigned char* wbuf) {
   if constexpr (EPI == EPI_F32) return false;
   if (row_base + 64 > g.M) return false;
-  const bool al = (reinterpret_cast<uintptr_t>(g.out_hi) & 15) == 0 && (g.ldo_s & 31) == 0 && out2_fast_ok(g);
+  const bool al = (reinterpret_cast<uintptr_t>(g.out_hi) & 15) == 0 && (g.ldo_s & 31) == 0;
   auto planes = [&](auto&& fn) __attribute__((always_inline)) {
     if (!al) return false;
     if constexpr (HALF) {
       if (g.out_fmt == FMT_F16 && !g.out_lo) { fn(std::integral_constant<int, PF_F16>{}); return true; }
-      if (g.out_fmt == FMT_H8) {
-        if (g.out2) {
-          if constexpr ((EPI == EPI_SPLIT || EPI == EPI_WAVENET) && DENSE2) { fn(std::integral_constant<int, PF_H8D>{}); return true; }
-          return false;
-        }
-        fn(std::integral_constant<int, PF_H8>{});
-        return true;
-      }
+      if (g.out_fmt == FMT_H8) { fn(std::integral_constant<int, PF_H8>{}); return true; }
     }
     if constexpr (BF) {
       if (g.out_fmt == FMT_BF16 && g.out_lo) { fn(std::integral_constant<int, PF_BF16IL>{}); return true; }
@@ -350,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
   // store per value -- cost more than their 16 K tiles; small batches put QKV / GEGLU here as well)
   if constexpr (EPI != EPI_F32) {
     constexpr int WBUF = STAGE_BYTES / 2;
-    if (small_tile_fast_epilogue<EPI, WBUF, F16, !F16, (!F16 && NSPLIT == 1), NSPLIT == 2>(acc, g, z, row_base, col_base, tn * 64 + wn * 32, lane, smem + wave * WBUF))
+    if (small_tile_fast_epilogue<EPI, WBUF, F16, !F16, (!F16 && NSPLIT == 1)>(acc, g, z, row_base, col_base, tn * 64 + wn * 32, lane, smem + wave * WBUF))
       return;
   }
   gemm_epilogue<EPI, 2, 2>(acc, g, z, row_base, col_base, tn * 64 + wn * 32, lane);

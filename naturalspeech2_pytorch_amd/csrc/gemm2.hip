@@ -111,9 +111,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
 
   // operand layouts (ns2_common.h): exact mode requires interleaved operands (checked by launch_gemm); the fast kernel
   // reads the hi plane of either layout
-  // (mutable only for the dense first K phase of the hybrid Wavenet block, see `operands` below)
-  bool ail = g.a_lo != nullptr, wil = g.w_lo != nullptr;
-  long a_rs = pld(g.lda, ail), w_rs = pld(g.ldw, wil);           // physical row strides
+  const bool ail = g.a_lo != nullptr, wil = g.w_lo != nullptr;
+  const long a_rs = pld(g.lda, ail), w_rs = pld(g.ldw, wil);     // physical row strides
 
   // ---- DMA roles: instruction j = (wave&3)*8 + i of the operand; waves 0-3 stream A, waves 4-7 stream W
   const bool a_wave = wave < 4;
@@ -124,29 +123,21 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   // logical 16-B chunk this lane fetches: pchunk ^ swizzle(row); row = 8 rg + lrow and rg = 8 (wave & 3) + i, so the
   // swizzle (row >> 1) & 7 = 4 (i & 1) + (lrow >> 1) takes two values per lane, for even and odd i
   const int lchunk_par[2] = {pchunk ^ (lrow >> 1), pchunk ^ (4 + (lrow >> 1))};
-  bool opil = a_wave ? ail : wil;
-  // row pointers of the one-barrier K loop (run_k) for operands A = a_base [M, .] / W = w_base [rows_p, .] in the layouts (ail, wil)
-  auto operands = [&](const bf16_t* a_base, bool a_il, long a_stride, const bf16_t* w_base, bool w_il, long w_stride) __attribute__((always_inline)) {
-    ail = a_il; wil = w_il; a_rs = a_stride; w_rs = w_stride;
-    opil = a_wave ? ail : wil;
+  const bool opil = a_wave ? ail : wil;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rg = (wave & 3) * 8 + i;               // row group inside the operand: [0, IPO)
-      const int row = rg * RPI + lrow;                 // tile row
-      ldst[i] = (a_wave ? 0 : REGION) + rg * 1024;
-      if (a_wave) {
-        const long m = (long)tm * G2_BM + row;
-        src[i] = a_base + m * a_rs;
-        nseq[i] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -0x40000000;
-      } else {
-        src[i] = w_base + ((long)tn * G2_BN + row) * w_rs;
-        nseq[i] = 0;
-      }
+  for (int i = 0; i < 8; ++i) {
+    const int rg = (wave & 3) * 8 + i;               // row group inside the operand: [0, IPO)
+    const int row = rg * RPI + lrow;                 // tile row
+    ldst[i] = (a_wave ? 0 : REGION) + rg * 1024;
+    if (a_wave) {
+      const long m = (long)tm * G2_BM + row;
+      src[i] = g.a_hi + pcol((int)(z * g.a_zs), ail) + m * a_rs;
+      nseq[i] = (m < g.M) ? ((g.seq_len > 0) ? (int)(m % g.seq_len) : 0x3fffffff) : -0x40000000;
+    } else {
+      src[i] = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0)) + ((long)tn * G2_BN + row) * w_rs;
+      nseq[i] = 0;
     }
-  };
-  const bf16_t* const a_main = g.a_hi + pcol((int)(z * g.a_zs), ail);
-  const bf16_t* const w_main = g.w_hi + (((long)z * g.w_zs) << (wil ? 1 : 0));
-  operands(a_main, ail, a_rs, w_main, wil, w_rs);
+  }
 
   // K tiling in BK units: every tap spans tpt tiles; with BK = 64 an odd 32-multiple tap ends in a half tile whose
   // upper 32 columns are zero-filled (A and W lanes of those chunks read the zero page)
@@ -211,11 +202,6 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   // nothing to compute or store for this wave (it still streams its share of the operands and joins the barriers)
   const int ncols_needed = (EPI == EPI_GEGLU || EPI == EPI_F32 || EPI == EPI_QKV) ? g.N : max(g.N, g.out_ncols);
   const bool wave_active = col_base < ncols_needed;
-  // Last column tile at most half valid (the FF conv: N = 1365 = 5 tiles + 85 columns): W rows 128 ... 255 of the tile feed only
-  // the column quarters 2 and 3, i.e. waves 4-7, which have nothing to compute -- and in the phased loops exactly those waves
-  // request those rows.  They skip the requests (11 % of the FF conv's operand line requests were for columns nobody stores) and
-  // count their outstanding A pieces only.  LDS rows that are never written are never read: results are unchanged.
-  const bool w_skip = wave >= 4 && tn * G2_BN + G2_BN / 2 >= ncols_needed;
 
   // fragment read addressing: row = wave base + 32*i + l31 ; physical chunk = (4*plane + 2*kc + hi) ^ swz(row); the swizzle
   // depends on l31 only, and a 16-lane ds_read_b128 group covers 16 distinct (row&1, (row>>1)&7) pairs = all 64 banks
@@ -434,7 +420,6 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
         glds16(ok ? (psrc[H][e] + off + coff[e]) : zero_page, sbase + pldst[H][e]);
       }
     } else {
-      if (w_skip) return;                                 // W rows nobody reads (see w_skip)
       const long off = pcol(c.tap * tap_k + c.it * BK, wil);
 #pragma unroll
       for (int e = 0; e < 2; ++e)
@@ -500,9 +485,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     }
     __builtin_amdgcn_s_setprio(0);
   };
-  // everything older than the last four half-tile requests has landed: 8 pieces, or 4 for a wave that skips its W pieces (any four
-  // consecutive requests of the cycle B1, A1, A0, B0 are two A and two B halves)
-#define G2_VMWAIT(fill) do { if (!(fill)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else if (w_skip) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
+#define G2_VMWAIT(fill) do { if (fill) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
 
   auto run_k8 = [&](auto mode, const int kt0, const int kt1) __attribute__((always_inline)) {
     const int T = kt1 - kt0;
@@ -516,11 +499,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     if (T > 1) {
       c1 = tile_coord(mode, kt0 + 1);
       issue_half(mode, c1, (kt0 + 1) & 1, HA0{}); issue_half(mode, c1, (kt0 + 1) & 1, HB0{});
-      if (w_skip) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // issued A0(0), A1(0), A0(1): A0(0) has landed
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
-      if (w_skip) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
 #ifdef G2_BLKTRACE
@@ -578,7 +559,14 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   // A wave issues 2 pieces per W request and 1 or 2 per A' part (33 = 3 x 11 row groups over 8 waves), so the counted waits
   // differ per wave and tap: before phase 0 of step s + 1 and before phase 1 of step s the wave allows exactly the requests
   // younger than the half tile it is about to read: 4 (two W halves) + its A' pieces of the previous step.
-  auto run_k8_conv3 = [&](auto mode) __attribute__((always_inline)) {
+  // `helper` = this wave is one of waves 4-7 of a column tile that is at most half valid (the last tile of the FF conv, N = 1365 =
+  // 5 tiles + 85 columns).  W rows 128 ... 255 feed only the column quarters 2 and 3 = those waves, which have nothing to compute --
+  // and exactly those waves request those rows.  So they take a loop of their own: their share of the A' pieces, the counted waits
+  // for them and every barrier of the schedule below, but no W request (11 % of the FF conv's operand line requests were for
+  // columns nobody stores), no fragment read, no MFMA.  LDS rows that are never written are never read: results are unchanged.
+  // A separate loop because the same test as a run-time flag inside the common loop split its phases into more basic blocks and cost
+  // every other GEMM 2 %, and a second instantiation of the whole loop spilled (profiles/r05_wavenet_dense_and_wskip_ab.txt).
+  auto run_k8_conv3 = [&](auto mode, const bool helper) __attribute__((always_inline)) {
     using M = decltype(mode);
     constexpr int BK = M::bk;
     constexpr int A_BUF = 264 * RB, W_BUF = REGION;
@@ -598,7 +586,6 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     const int nA = wave < 3 ? 2 : 1;                          // A' pieces of this wave per 11-piece part
 
     auto issue_wh = [&](int st, int b) __attribute__((always_inline)) {        // this wave's 2 pieces of half tile B<b> of W(step st)
-      if (w_skip) return;                                                       // W rows 128 ... 255: nobody reads them (see w_skip)
       const int it = st / 3, tap = st - 3 * it;
       const bool half = half_tail && (it == tpt - 1);
       const long off = pcol(tap * tap_k + it * BK, wil);
@@ -623,7 +610,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
         glds16(ok ? (a_base + (long)row * a_rs + off + (par ? cofA1 : cofA0)) : zero_page, sA + (it & 1) * A_BUF + j * 1024);
       }
     };
-    auto vmwait = [&](int n) __attribute__((always_inline)) {                   // wave-uniform n in {0, 4, 5, 6, 8}; {0, 1, 2} for a w_skip wave
+    auto vmwait = [&](int n) __attribute__((always_inline)) {                   // wave-uniform n in {0, 4, 5, 6, 8}; {0, 1, 2} in the helper loop
       if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -633,12 +620,38 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
+    if (helper) {
+      // ---- the helper loop (see above): the same requests of A' pieces in the same phases, the same barriers, nothing else
+      issue_ap(0, 0); issue_ap(0, 1); issue_ap(0, 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();                             // waves 4-7 run half a phase behind
+      for (int it = 0; it < tpt; ++it) {
+        const bool next_it = it + 1 < tpt;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+          const int st = 3 * it + tap;
+          const bool more1 = st + 1 < nst, more2 = st + 2 < nst;
+          const int a_prev = (tap == 0) ? 0 : (next_it ? (tap == 1 ? 2 * nA : nA) : 0);
+          const int a_this = next_it ? (tap == 0 ? 2 * nA : (tap == 1 ? nA : 0)) : 0;
+          vmwait(more1 ? a_prev : 0);                            // phase 0
+          __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();
+          if (next_it && tap == 0) issue_ap(it + 1, 0);           // phase 1
+          if (next_it && tap == 1) issue_ap(it + 1, 2);
+          __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();
+          if (next_it && tap == 0) issue_ap(it + 1, 1);           // phase 2
+          __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();
+          vmwait(more2 ? a_this : 0);                            // phase 3
+          __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();
+        }
+      }
+      return;
+    }
     // ---- prologue: A'(0), W(0), B0 of W(1)
     issue_ap(0, 0); issue_ap(0, 1); issue_ap(0, 2);
     issue_wh(0, 0); issue_wh(0, 1);
-    if (nst > 1 && !w_skip) { issue_wh(1, 0); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    if (nst > 1) { issue_wh(1, 0); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int nW = w_skip ? 0 : 4;                              // pieces of two W half tiles in flight
     __builtin_amdgcn_s_barrier();
 #ifdef G2_BLKTRACE
     if (bts[1] == 0) BSTAMP(1);
@@ -663,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
         // ---- phase 0: quadrant (0, 0); request B1 of W(step + 1); B1 of this step must have landed for phase 1
         if (wave_active) { load_a(mode, sa, a_off, fz_a, 0, A); load_w(mode, sw, w_off, fswz, 0, W0); }
         if (more1) issue_wh(st + 1, 1);
-        vmwait(more1 ? nW + a_prev : 0);
+        vmwait(more1 ? 4 + a_prev : 0);
         __builtin_amdgcn_s_barrier();
         if (wave_active) mma_quadrant(mode, 0, 0, A, W0);
         __builtin_amdgcn_s_barrier();
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
         __builtin_amdgcn_s_barrier();
         // ---- phase 3: quadrant (1, 0); request B0 of W(step + 2); B0 of step + 1 (and, before tap 0, A'(it + 1)) must have landed
         if (more2) issue_wh(st + 2, 0);
-        vmwait(more2 ? nW + a_this : 0);
+        vmwait(more2 ? 4 + a_this : 0);
         __builtin_amdgcn_s_barrier();
         if (wave_active) mma_quadrant(mode, 1, 0, A, W0);
         __builtin_amdgcn_s_barrier();
@@ -697,26 +710,17 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     const bool mid_uni = g.seq_len > 0 && (g.seq_len & 127) == 0;      // row_base % 128 == 0: the wave tile lies inside one utterance
     // the one-barrier-per-tile loop: the phased schedule measured 9 % SLOWER on this kernel (two short K phases = two pipeline
     // ramps per block, and the K loops of this kernel family are bound by LDS-DMA throughput, not by its latency: DESIGN.md)
-    if constexpr (P1 != 0) {
-      // hybrid plan: the half product of the dilated conv reads DENSE IEEE-half copies of its operands when the caller has them
-      // (GemmArgs::a1_hi / w1_hi: one line request per row and 64-deep tile instead of two half lines gathered out of the FMT_H8
-      // lines); the same values in the same order, so the result does not depend on which layout was read
-      const bool dense1 = g.a1_hi != nullptr;
-      const bool ail0 = ail, wil0 = wil;
-      const long a_rs0 = a_rs, w_rs0 = w_rs;
-      if (dense1) operands(g.a1_hi + z * g.a1_zs, false, g.lda1, g.w1_hi + z * g.w1_zs, false, g.ldw1);
-      run_k(ModeP1{}, 0, mid_tap * tiles_per_tap(ModeP1{}));
-      if (dense1) operands(a_main, ail0, a_rs0, w_main, wil0, w_rs0);
-    } else {
-      run_k(ModeP1{}, 0, mid_tap * tiles_per_tap(ModeP1{}));
-    }
+    run_k(ModeP1{}, 0, mid_tap * tiles_per_tap(ModeP1{}));
     wavenet_midgate<4, 2>(acc, g, z, row_base, col_base, l31, hi, mid_uni);
     run_k(ModeMain{}, mid_tap * tiles_per_tap(ModeMain{}), ntaps * tiles_per_tap(ModeMain{}));
   } else if constexpr (EPI == EPI_SPLIT) {
     const bool conv3 = g.conv_taps == 3 && ntaps == 3 && !g.dil_z && g.dil == 1 && g.pad_left < 0 && g.seq_len > 0 &&
                        (g.seq_len % G2_BM) == 0;
-    if (conv3) run_k8_conv3(ModeMain{});
-    else run_k8(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
+    if (conv3) {
+      run_k8_conv3(ModeMain{}, /*helper=*/wave >= 4 && tn * G2_BN + G2_BN / 2 >= ncols_needed);
+    } else {
+      run_k8(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
+    }
   } else {
     run_k8(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
   }
@@ -732,18 +736,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     if (row_base + 128 <= g.M) {
       // plane format of the output: kernels on IEEE-half operands write F16 / H8, kernels on bf16 operands bf16 planes
       auto planes = [&](auto&& fn) __attribute__((always_inline)) {
-        const bool al = ((reinterpret_cast<uintptr_t>(g.out_hi) & 15) == 0) && (g.ldo_s & 31) == 0 && out2_fast_ok(g);
+        const bool al = ((reinterpret_cast<uintptr_t>(g.out_hi) & 15) == 0) && (g.ldo_s & 31) == 0;
         if (!al) return false;
         if constexpr (F16) {
           if (g.out_fmt == FMT_F16 && !g.out_lo) { fn(std::integral_constant<int, PF_F16>{}); return true; }
-          if (g.out_fmt == FMT_H8) {
-            if (g.out2) {                                 // + the dense half copy: the mixed-mode producers of Wavenet column buffers
-              if constexpr ((EPI == EPI_SPLIT || EPI == EPI_WAVENET) && NSPLIT == 2) { fn(std::integral_constant<int, PF_H8D>{}); return true; }
-              return false;
-            }
-            fn(std::integral_constant<int, PF_H8>{});
-            return true;
-          }
+          if (g.out_fmt == FMT_H8) { fn(std::integral_constant<int, PF_H8>{}); return true; }
         } else {
           if (g.out_fmt == FMT_BF16 && g.out_lo) { fn(std::integral_constant<int, PF_BF16IL>{}); return true; }
           if constexpr (NSPLIT == 1) { if (g.out_fmt == FMT_BF16 && !g.out_lo) { fn(std::integral_constant<int, PF_BF16>{}); return true; } }
@@ -889,12 +886,6 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
   if ((precision == 3 || precision == 4) && (!g.a_lo || !g.w_lo)) return hipErrorInvalidValue;
   if (g.out_hi && ((g.out_fmt == FMT_F16 && g.out_lo) || (g.out_fmt == FMT_H8 && !g.out_lo))) return hipErrorInvalidValue;
   if (g.vt_hi && g.vt_fmt == FMT_F16 && g.vt_lo) return hipErrorInvalidValue;
-  // the dense half copies (GemmArgs::a1_hi / w1_hi / out2) belong to the hybrid plan's Wavenet: FMT_H8 lines next to dense IEEE half
-  if (g.out2 && !(g.out_fmt == FMT_H8 && (g.epi == EPI_SPLIT || g.epi == EPI_WAVENET) && g.ldo2 >= g.out_ncols)) return hipErrorInvalidValue;
-  if ((g.a1_hi != nullptr) != (g.w1_hi != nullptr)) return hipErrorInvalidValue;
-  if (g.a1_hi && !(g.epi == EPI_WAVENET && precision == 4 && g.p1_half && (g.lda1 & 7) == 0 && (g.ldw1 & 7) == 0 && (g.a1_zs & 7) == 0 &&
-                   (g.w1_zs & 7) == 0 && ((reinterpret_cast<uintptr_t>(g.a1_hi) | reinterpret_cast<uintptr_t>(g.w1_hi)) & 15) == 0))
-    return hipErrorInvalidValue;
   if (g.M <= 0 || g.N <= 0 || g.nkt <= 0 || g.kt_per_tap <= 0 || (g.nkt % g.kt_per_tap)) return hipErrorInvalidValue;
   // a lo plane means the interleaved layout: lo = hi + 32 (ns2_common.h)
   if (!planes_ok(g.a_hi, g.a_lo) || !planes_ok(g.w_hi, g.w_lo) || !planes_ok(g.out_hi, g.out_lo) ||

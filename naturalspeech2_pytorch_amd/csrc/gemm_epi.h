@@ -135,9 +135,6 @@ NS2_DEVINL void gemm_epilogue(f32x16 (&acc)[MI][NI], const GemmArgs& g, int z, i
               if (c0 >= g.N) c_lo = 0.f;             // zero the K-padding columns of the next GEMM's operand
               if (c0 + 1 >= g.N) c_hi = 0.f;
               store_cols2(out_hi + (long)row * pld(g.ldo_s, il), c0, c_lo, c_hi, g.out_fmt, il);
-              if constexpr (EPI != EPI_QKV) {          // optional dense IEEE-half copy of an FMT_H8 output: the half parts of the line, bit for bit
-                if (g.out2) *reinterpret_cast<uint32_t*>(g.out2 + z * g.out2_zs + (long)row * g.ldo2 + c0) = cvt2h_of_h8(c_lo, c_hi);
-              }
             }
           }
         } else {

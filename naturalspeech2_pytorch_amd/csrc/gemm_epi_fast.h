@@ -21,15 +21,12 @@
 
 namespace ns2 {
 
-// PF_H8D = FMT_H8 lines plus the dense IEEE-half copy GemmArgs::out2 (a format of its own so that the epilogue body has no
-// run-time branch: with one, the compiler duplicated the unrolled body and spilled the 128 accumulators at the merge)
-enum FastPlaneFmt : int { PF_F16 = 0, PF_BF16IL = 1, PF_H8 = 2, PF_BF16 = 3, PF_H8D = 4 };
+enum FastPlaneFmt : int { PF_F16 = 0, PF_BF16IL = 1, PF_H8 = 2, PF_BF16 = 3 };
 template <int PF> struct PlaneGeom {
-  static constexpr bool h8 = (PF == PF_H8 || PF == PF_H8D);
-  static constexpr bool il = (PF == PF_BF16IL || h8);              // interleaved 128-B lines of 32 logical columns
+  static constexpr bool il = (PF == PF_BF16IL || PF == PF_H8);     // interleaved 128-B lines of 32 logical columns
   static constexpr int bytes_per_col32 = il ? 128 : 64;            // global bytes of 32 logical columns of one row
-  static constexpr float limit = h8 ? H8_MAX : 65504.f;
-  static constexpr bool guarded = (PF == PF_F16 || h8);            // formats with the IEEE-half range
+  static constexpr float limit = (PF == PF_H8) ? H8_MAX : 65504.f;
+  static constexpr bool guarded = (PF == PF_F16 || PF == PF_H8);   // formats with the IEEE-half range
 };
 
 // value of lane ^ 1 (DPP quad_perm [1,0,3,2]): one VALU move, no LDS crossbar
@@ -104,27 +101,6 @@ NS2_DEVINL void lds_flush_rows(const unsigned char* wbuf, unsigned char* gbase, 
   }
 }
 
-// GemmArgs::out2 absent, or laid out for lds_flush_half_parts (16-byte row segments); otherwise the generic epilogue writes it
-NS2_DEVINL bool out2_fast_ok(const GemmArgs& g) {
-  return !g.out2 || ((reinterpret_cast<uintptr_t>(g.out2) & 15) == 0 && (g.ldo2 & 7) == 0 && (g.out2_zs & 7) == 0);
-}
-
-// the IEEE-half parts of ROWS staged rows of two FMT_H8 lines each (64 logical columns: LDS row = [half32|h8|l8][half32|h8|l8], stride
-// 272) -> a dense half plane: 128 contiguous bytes per row, 8 rows per wave-instruction (GemmArgs::out2)
-template <int ROWS>
-NS2_DEVINL void lds_flush_half_parts(const unsigned char* wbuf, unsigned char* gbase, long row_stride_bytes, int lane) {
-  constexpr int RS = 256 + 16;
-  static_assert(ROWS % 8 == 0, "8 rows per store instruction");
-  const int lr0 = lane >> 3, ch = lane & 7;
-  const int src = (ch >> 2) * 128 + (ch & 3) * 16;       // 16-byte chunk ch of the dense row inside the two staged lines
-#pragma unroll
-  for (int it = 0; it < ROWS / 8; ++it) {
-    const int lr = it * 8 + lr0;
-    const uint4 v = *reinterpret_cast<const uint4*>(wbuf + lr * RS + src);
-    *reinterpret_cast<uint4*>(gbase + (long)lr * row_stride_bytes + ch * 16) = v;
-  }
-}
-
 // ---- split planes: EPI_SPLIT (bias; calls with an activation keep the generic path), EPI_WAVENET (biases were applied mid-loop), the q / k part of EPI_QKV
 // MI = 32-row accumulator tiles of the wave (4: gemm2.hip's 128 x 64 wave tile, 2: gemm.hip's 64 x 64), WBUF = bytes of the wave's
 // private LDS region: the tile leaves in passes of the most rows (a power of two, at least 32) that fit it.
@@ -148,9 +124,6 @@ NS2_DEVINL void epi_planes_fast(f32x16 (&acc)[MI][2], const GemmArgs& g, int z, 
   const long rsb = pld(g.ldo_s, G::il) * 2;
   unsigned char* gbase = reinterpret_cast<unsigned char*>(g.out_hi + pcol((int)(z * g.out_zs), G::il)) + (long)row_base * rsb +
                          (long)(col_base >> 5) * G::bytes_per_col32;
-  // PF_H8D: the dense IEEE-half copy of the output (the caller checked pointer and alignment)
-  unsigned char* g2base = nullptr;
-  if constexpr (PF == PF_H8D) g2base = reinterpret_cast<unsigned char*>(g.out2 + z * g.out2_zs + (long)row_base * g.ldo2 + col_base);
   RangeTrack rt;
 #pragma unroll
   for (int pass = 0; pass < 32 * MI / RPP; ++pass) {
@@ -173,7 +146,6 @@ NS2_DEVINL void epi_planes_fast(f32x16 (&acc)[MI][2], const GemmArgs& g, int z, 
     }
     __builtin_amdgcn_wave_barrier();
     lds_flush_rows<ROWB, RPP>(wbuf, gbase + (long)pass * RPP * rsb, rsb, lane);
-    if constexpr (PF == PF_H8D) lds_flush_half_parts<RPP>(wbuf, g2base + (long)pass * RPP * g.ldo2 * 2, (long)g.ldo2 * 2, lane);
     __builtin_amdgcn_wave_barrier();
   }
   if constexpr (G::guarded) rt.flush(G::limit);

@@ -65,8 +65,6 @@ struct ns2_model {
   float* wt_cond; float* b_cond;
   PackedW w_init; const float* b_init;
   std::vector<PackedW> w_wn;           // per stack, batched over z
-  std::vector<PackedW> w_wn_half;      // hybrid plan: the dilated-conv taps once more as dense IEEE-half rows (first K phase of the block kernel)
-  bool wn_dense = false;               // ... and dense half copies of the Wavenet column buffers next to their FMT_H8 lines (GemmArgs::a1_hi)
   std::vector<float*> b_wn_conv, b_wn_res;
   PackedW w_skip; float* b_skip;
   PackedW w_final; const float* b_final;
@@ -252,25 +250,6 @@ static void set_conv(GemmArgs& g, const PackedW& w, int taps, int dil, int seq_l
   g.kt_per_tap = w.kt_per_tap; g.conv_taps = taps; g.dil = dil; g.seq_len = seq_len;
 }
 
-// A/B switch (process-wide like NS2_GEMM; consulted by ns2_model_finalize): NS2_WAVENET_DENSE=0 keeps the hybrid plan's Wavenet on the gathered half parts
-// of its FMT_H8 operands (rounds 2-4).  The two are bit-identical (tests/test_round5_gpu.py); the dense copies cost 0.6 GB of
-// workspace at the headline shape.
-static std::atomic<int> g_wavenet_dense{-1};          // -1: NS2_WAVENET_DENSE (read once), 0 / 1: set by ns2_debug_wavenet_dense
-static bool wavenet_dense_enabled() {
-  int v = g_wavenet_dense.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("NS2_WAVENET_DENSE");
-    v = (e && e[0] == '0') ? 0 : 1;
-    g_wavenet_dense.store(v, std::memory_order_relaxed);
-  }
-  return v != 0;
-}
-extern "C" int ns2_debug_wavenet_dense(int mode) {
-  if (mode < -1 || mode > 1) { set_error("ns2_debug_wavenet_dense: -1 environment, 0 off, 1 on"); return NS2_ERR_ARG; }
-  g_wavenet_dense.store(mode, std::memory_order_relaxed);
-  return NS2_OK;
-}
-
 int gemm_f32(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
              const float* bias, const float* resid, int ldr, float* out, int ldo, int prec, hipStream_t s, int pad_left, int act) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
@@ -281,13 +260,11 @@ int gemm_f32(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, 
   return NS2_OK;
 }
 int gemm_split(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
-               const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left, int act, int out_fmt,
-               bf16_t* out2) {
+               const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left, int act, int out_fmt) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
   if (conv_taps) set_conv(g, w, conv_taps, dil, seq_len);
   g.pad_left = pad_left; g.act = act; g.out_fmt = out_fmt;
   g.epi = EPI_SPLIT; g.bias = bias; g.out_hi = o_hi; g.out_lo = o_lo; g.ldo_s = ldo; g.out_ncols = ldo;
-  g.out2 = out2; g.ldo2 = ldo;
   HIPCHK(launch_gemm(g, prec, s));
   return NS2_OK;
 }
@@ -312,18 +289,10 @@ int gemm_qkv(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, 
 }
 int gemm_wavenet(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, long a_zs, int M, int seq_len, int dil,
                  int dil_z, int nz, const float* b_conv, const float* b_res, long bias_zs, const float* film, int film_ld,
-                 long film_zs, bf16_t* o_hi, bf16_t* o_lo, int ldo, long out_zs, int out_ncols, int prec, hipStream_t s, int p1_half,
-                 const WavenetDense* dense) {
+                 long film_zs, bf16_t* o_hi, bf16_t* o_lo, int ldo, long out_zs, int out_ncols, int prec, hipStream_t s, int p1_half) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
   set_conv(g, w, 3, dil, seq_len);
   g.p1_half = (prec == 4) ? p1_half : 0;
-  if (dense && g.p1_half) {
-    if (dense->a1) {
-      g.a1_hi = dense->a1; g.lda1 = lda; g.a1_zs = a_zs;                  // same logical geometry as the FMT_H8 buffer it mirrors
-      g.w1_hi = dense->w1->hi; g.ldw1 = dense->w1->ldk; g.w1_zs = (long)dense->w1->rows_p * dense->w1->ldk;
-    }
-    g.out2 = dense->out2; g.ldo2 = ldo; g.out2_zs = out_zs;
-  }
   g.dil_z = dil_z; g.nz = nz; g.a_zs = a_zs; g.w_zs = (long)w.rows_p * w.ldk; g.bias_zs = bias_zs; g.film_zs = film_zs;
   g.out_zs = out_zs;
   g.mid_kt = 3 * w.kt_per_tap;
@@ -451,27 +420,6 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
       NSCHK(pack_into(&view, rw->p, dim, 1, m->dp, identity_map(dim, W.rows_p), 0, 3 * m->dp, s));
       HIPCHK(hipMemcpyAsync(m->b_wn_conv[st] + (size_t)i * dim, cb->p, dim * sizeof(float), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(m->b_wn_res[st] + (size_t)i * dim, rb->p, dim * sizeof(float), hipMemcpyDeviceToDevice, s));
-    }
-  }
-  // hybrid plan on the 256 x 256 kernel (dim > 128): the block kernel's first K phase reads dense IEEE-half operands (GemmArgs::a1_hi)
-  m->wn_dense = hybrid_plan(m->cfg.precision) && dim > 128 && wavenet_dense_enabled();
-  if (m->wn_dense) {
-    const PackCtx pch = pack_ctx_for(&m->owned, 2);
-    m->w_wn_half.resize(S);
-    for (int st = 0; st < S; ++st) {
-      PackedW& W = m->w_wn_half[st];
-      W.N = dim; W.rows_p = rup(dim, 256); W.ldk = 3 * m->dp; W.nkt = W.ldk / 32; W.kt_per_tap = m->dp / 32;
-      const size_t per = (size_t)W.rows_p * W.ldk;
-      NSCHK(dev_alloc(&m->owned, (void**)&W.hi, per * L * sizeof(bf16_t)));
-      W.lo = nullptr;
-      W.fmt = pch.fmt;
-      HIPCHK(hipMemset(W.hi, 0, per * L * sizeof(bf16_t)));
-      for (int i = 0; i < L; ++i) {
-        snprintf(key, sizeof key, "wavenet.stacks.%d.blocks.%d.conv.weight", st, i);
-        GETP(cw, key);
-        PackedW view = W; view.hi = W.hi + per * i;
-        NSCHK(pack_into(&view, cw->p, dim, 3, m->dp, identity_map(dim, W.rows_p), 0, 0, s));
-      }
     }
   }
   { // skip convs of the last stack, concatenated along K; summed bias (NS2:639-640, 685-686, 725)
@@ -626,7 +574,6 @@ struct Work {
   float* skinny_ws; size_t skinny_ws_bytes;     // split-K partial sums of the conditioning projections (caller-owned)
   float* sk_ws;                                 // split-K slots of the small-batch GEMMs (SPLITK_SCRATCH_FLOATS, ns2_kernels.h)
   Planes xs, h0, wA, wB, ssum, xn, qk, vt, o, ffh, ffc;
-  bf16_t *h0d, *wAd, *wBd; // hybrid plan: dense IEEE-half copies of h0 / wA / wB (null when the model does not use them)
   Planes xq;               // cross-attention queries [M, a] in the cross-attention operand format: a view of qk's memory
   Planes ffh_conv;         // the FF conv's input: ffh itself, or (precision 5) a dense IEEE-half view of the same memory
   int Nkp;
@@ -660,12 +607,6 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
   w->h0 = take_planes(c, M * dp, il, f16);
   w->wA = take_planes(c, M * L * dp, il, f16);
   w->wB = take_planes(c, M * L * dp, il, f16);
-  w->h0d = w->wAd = w->wBd = nullptr;
-  if (m->wn_dense) {
-    w->h0d = c.take<bf16_t>(M * dp);
-    w->wAd = c.take<bf16_t>(M * L * dp);
-    w->wBd = c.take<bf16_t>(M * L * dp);
-  }
   w->ssum = take_planes(c, M * dp, il, f16);
   w->xn = take_planes(c, M * dp, il, f16);
   w->qk = take_planes(c, Mq * 2 * a, ail, afmt);
@@ -955,26 +896,20 @@ static int forward_impl(ns2_model* m, const float* x, const float* times, const 
   HIPCHK(launch_split(x, dim, cond ? cs.condadd : nullptr, dim, n_cond, cond ? cs.n_cond_valid : 0, w.xs.hi, w.xs.lo, dp, M, dim, N, s, w.xs.fmt));
 
   // ---- wavenet (NS2:718-725)
-  PROF(PC_GEMM_SPLIT, gemm_split(m->w_init, w.xs.hi, w.xs.lo, dp, M, 3, 1, N, m->b_init, w.h0.hi, w.h0.lo, dp, prec, s, -1, 0, -1, w.h0d));
+  PROF(PC_GEMM_SPLIT, gemm_split(m->w_init, w.xs.hi, w.xs.lo, dp, M, 3, 1, N, m->b_init, w.h0.hi, w.h0.lo, dp, prec, s));
   NSCHK(tap_planes(m, "wavenet.init", w.h0, dp, M, dim, s));
   Planes cur = w.wA, prev = w.wB;
-  bf16_t *curd = w.wAd, *prevd = w.wBd;               // dense half copies of cur / prev (hybrid plan, wn_dense)
   for (int st = 0; st < S; ++st) {
     const bf16_t* a_hi = (st == 0) ? w.h0.hi : prev.hi;
     const bf16_t* a_lo = (st == 0) ? w.h0.lo : prev.lo;
     const int lda = (st == 0) ? dp : L * dp;
     const long a_zs = (st == 0) ? 0 : dp;
-    WavenetDense dense{nullptr, nullptr, nullptr};
-    if (m->wn_dense) {                                 // the last stack feeds only the (mixed) skip GEMM: no dense copy of its output
-      dense.a1 = (st == 0) ? w.h0d : prevd; dense.w1 = &m->w_wn_half[st]; dense.out2 = (st + 1 < S) ? curd : nullptr;
-    }
     PROF(PC_GEMM_WAVENET, gemm_wavenet(m->w_wn[st], a_hi, a_lo, lda, a_zs, M, N, /*dil=*/1, /*dil_z=*/1, /*nz=*/L, m->b_wn_conv[st], m->b_wn_res[st],
                        dim, call + (size_t)st * L * 2 * dim, cld, 2 * dim, cur.hi, cur.lo, L * dp, dp, dp, prec, s,
-                       /*p1_half=*/hybrid_plan(m->cfg.precision) ? 1 : 0, m->wn_dense ? &dense : nullptr));
+                       /*p1_half=*/hybrid_plan(m->cfg.precision) ? 1 : 0));
     snprintf(name, sizeof name, "wavenet.stack%d", st);
     NSCHK(tap_planes(m, name, cur, L * dp, M, L * dp, s));
     Planes tmp = prev; prev = cur; cur = tmp;
-    bf16_t* tmpd = prevd; prevd = curd; curd = tmpd;
   }
   // sum of the 8 skip convs == one GEMM over the concatenated columns (NS2:639-640, 685-686, 725), then final_conv
   PROF(PC_GEMM_SPLIT, gemm_split(m->w_skip, prev.hi, prev.lo, L * dp, M, 0, 1, 0, m->b_skip, w.ssum.hi, w.ssum.lo, dp, prec, s));

@@ -132,11 +132,6 @@ NS2_DEVINL void cvt2_h8(float a, float b, uint32_t& h16, uint32_t& h8, uint32_t&
   h8 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xffffu;
   l8 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(fminf(fmaxf(r.x, -H8_MAX), H8_MAX), fminf(fmaxf(r.y, -H8_MAX), H8_MAX), 0, false) & 0xffffu;
 }
-// the half pair cvt2_h8 stores (same clamp), without the byte parts and without the range note (cvt2_h8 of the same values made it)
-NS2_DEVINL uint32_t cvt2h_of_h8(float a, float b) {
-  f32x2_t v = {fminf(fmaxf(a, -H8_MAX), H8_MAX), fminf(fmaxf(b, -H8_MAX), H8_MAX)};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
-}
 NS2_DEVINL float bf8_to_f(uint32_t byte) {        // e5m2 -> fp32 (e5m2 is the top byte of an IEEE half)
   return (float)__builtin_bit_cast(_Float16, (uint16_t)(byte << 8));
 }

@@ -22,18 +22,14 @@ int gemm_f32(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, 
              int act = 0);
 int gemm_split(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
                const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left = -1, int act = 0,
-               int out_fmt = -1, bf16_t* out2 = nullptr);      // out2: dense IEEE-half copy of an FMT_H8 output [M, ldo] (GemmArgs::out2)
+               int out_fmt = -1);
 int gemm_geglu(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, const float* pbias, bf16_t* o_hi,
                bf16_t* o_lo, int ldo, int prec, hipStream_t s, int out_fmt = -1);
 int gemm_qkv(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int seq_len, int split_col,
              bf16_t* o_hi, bf16_t* o_lo, int ldo, bf16_t* vt_hi, bf16_t* vt_lo, int vt_ld, int prec, hipStream_t s, int att_fmt = -1);
-// dense IEEE-half companions of a hybrid-plan Wavenet launch (GemmArgs::a1_hi / w1_hi / out2): a1 mirrors the A operand (same lda,
-// same column offset per slice), w1 holds the conv taps, out2 mirrors the output; a1 or out2 may be null
-struct WavenetDense { const bf16_t* a1; const PackedW* w1; bf16_t* out2; };
 int gemm_wavenet(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, long a_zs, int M, int seq_len, int dil,
                  int dil_z, int nz, const float* b_conv, const float* b_res, long bias_zs, const float* film, int film_ld,
-                 long film_zs, bf16_t* o_hi, bf16_t* o_lo, int ldo, long out_zs, int out_ncols, int prec, hipStream_t s, int p1_half = 0,
-                 const WavenetDense* dense = nullptr);
+                 long film_zs, bf16_t* o_hi, bf16_t* o_lo, int ldo, long out_zs, int out_ncols, int prec, hipStream_t s, int p1_half = 0);
 
 int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, int precision, PackedW* out,
                        std::vector<void*>* owned, hipStream_t s);

@@ -80,14 +80,6 @@ struct GemmArgs {
   // one slice covers (slice z: input columns [z * ksplit * 32, ...) of each tap); 0 = the plain launch.
   float* sk_ws; long sk_ws_floats;
   int ksplit;
-  // The hybrid plan's Wavenet (EPI_WAVENET with p1_half) on DENSE half operands.  The first K phase multiplies only the IEEE-half
-  // parts of its operands; gathered out of FMT_H8 lines they cost two 64-byte line requests per row and 64-deep tile where a dense
-  // plane costs one, and the K loops are bound by line requests.  So the producer of a Wavenet column buffer also
-  // writes `out2`, a dense IEEE-half copy of its output (bit for bit the half parts of the lines it writes), and the consumer's
-  // first K phase reads `a1` / `w1` (dense planes of the same values) instead of gathering.  All optional: null = gather.
-  const bf16_t* a1_hi; int lda1; long a1_zs;     // [M, lda1] dense IEEE half, slice z at column offset z * a1_zs
-  const bf16_t* w1_hi; int ldw1; long w1_zs;     // [rows_p, ldw1] dense IEEE half: the conv taps only (K = conv_taps * kt_per_tap * 32); slice z at element offset z * w1_zs
-  bf16_t* out2; int ldo2; long out2_zs;          // EPI_SPLIT / EPI_WAVENET writing FMT_H8: columns [0, out_ncols) once more as dense IEEE half; slice z at column offset z * out2_zs
 };
 
 // precision: 3 = bf16 x3 ("exact"), 1 = bf16 ("fast"), 2 = one IEEE-half product ("half"), 4 = half product + both

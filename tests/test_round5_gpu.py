@@ -1,12 +1,10 @@
 """Round-5 GPU tests.
 
-  * The hybrid plan's Wavenet on DENSE half operands (gemm2.hip `operands`, GemmArgs::a1_hi / w1_hi / out2; gemm_epi_fast.h PF_H8D):
-    the block kernel's first K phase reads dense IEEE-half copies written by the producing epilogues instead of gathering the half
-    parts out of the FMT_H8 lines.  Same values, same order: the model output must be BIT-identical with the copies on and off, on
-    both GEMM kernels, at shapes that take the staged fast epilogue and at ragged ones that take the generic one.
   * every gradient of the CONDITIONED model at the headline architecture (d512 / L12, 2 x 512 frames) against the
     reference's own autograd -- with the PerceiverResampler's backward now on the HIP Functions (training._resampler).
   * a frozen model with only x.requires_grad runs no weight-gradient GEMM and still returns the reference's dL/dx.
+  (The helper loop of the tap-shared conv for half-empty column tiles -- gemm2.hip `helper` -- is covered by the shapes of
+  tests/test_kernels_gpu.py::test_causal_conv whose last column tile has at most 128 valid columns: Cout = 300, 100, 341.)
 """
 import pytest
 import torch
@@ -15,8 +13,7 @@ pytestmark = pytest.mark.gpu
 if not torch.cuda.is_available():
     pytest.skip("needs an MI355X", allow_module_level=True)
 
-from naturalspeech2_pytorch_amd import Model, _lib  # noqa: E402
-from oracle import ns2_oracle as O  # noqa: E402
+from naturalspeech2_pytorch_amd import Model  # noqa: E402
 from oracle.ref_stub import load_reference, reference_available  # noqa: E402
 from tests.golden.gen import make_input, make_weights  # noqa: E402
 from tests.parity_record import record  # noqa: E402
@@ -35,42 +32,6 @@ def _model(kw, seed, precision):
     sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=seed)
     m.load_state_dict(sd)
     return m.to(DEV).eval(), sd
-
-
-@pytest.fixture()
-def hooks():
-    lib = _lib.load()
-    yield lib
-    torch.cuda.synchronize()
-    lib.ns2_debug_wavenet_dense(-1)
-    lib.ns2_debug_force_gemm(0)
-
-
-@pytest.mark.parametrize("kernel", [0, 2, 1], ids=["auto", "gemm256", "gemm128"])
-@pytest.mark.parametrize("kw,b,n", [(dict(dim=512, depth=1), 4, 512),                                   # interior tiles: the staged epilogues ("auto" = 256 x 256 kernel)
-                                    (dict(dim=192, depth=1, wavenet_layers=3, wavenet_stacks=3), 3, 200),   # ragged rows and columns: generic epilogue
-                                    (dict(dim=256, depth=1, wavenet_layers=8, wavenet_stacks=2), 1, 1024)])  # dilations up to 128 across tiles
-def test_wavenet_on_dense_half_operands_is_bit_identical(hooks, kw, b, n, kernel):
-    x = make_input("x", (b, n, kw["dim"]), seed=12).to(DEV)
-    t = make_input("times", (b,), seed=12, uniform=True).to(DEV)
-    outs = {}
-    for dense in (0, 1):
-        _lib.check(hooks.ns2_debug_wavenet_dense(dense))
-        _lib.check(hooks.ns2_debug_force_gemm(kernel))
-        m, sd = _model(kw, 11, "hybrid")                         # finalized under the switch
-        S = kw.get("wavenet_stacks", 4)
-        taps = {f"wavenet.stack{S - 1}": b * n * kw.get("wavenet_layers", 8) * kw["dim"], "wavenet.out": b * n * kw["dim"]}
-        with torch.no_grad():
-            y, bufs = m.debug_forward(x, t, taps)
-        outs[dense] = (y.clone(), {k: v.clone() for k, v in bufs.items()})
-        del m
-    for k in outs[0][1]:
-        assert torch.equal(outs[0][1][k], outs[1][1][k]), (k, rel(outs[1][1][k], outs[0][1][k]))
-    assert torch.equal(outs[0][0], outs[1][0])
-    ref = O.model_forward(sd, x.cpu(), t.cpu())
-    e = rel(outs[1][0], ref)
-    record(f"wavenet_dense_operands/d{kw['dim']}_b{b}_n{n}/kernel{kernel}/hybrid_vs_oracle", e)
-    assert e < 2.5e-4, e
 
 
 def _grads(m, fwd, x, t, seed=11, **kw):
