@@ -97,6 +97,11 @@ int ns2_linear_f32(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_
 int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
                      int dilation, int seq_len, const float* bias, uint16_t* out_hi, uint16_t* out_lo, int ldo,
                      int pad_left, int act, int precision, void* stream);
+/* same, with the output planes in the format of ANOTHER precision (out_precision 3: bf16 hi / lo lines from a precision-4 product --
+ * the q | k | v projection of the mixed training arithmetic, whose attention stays bf16 x3) */
+int ns2_linear_split_as(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
+                        int dilation, int seq_len, const float* bias, uint16_t* out_hi, uint16_t* out_lo, int ldo,
+                        int pad_left, int act, int precision, int out_precision, void* stream);
 /* FeedForward first half: GEGLU(Linear(x)) (NS2:1004-1007, 1021); w packed with geglu=1; packed_bias from
  * ns2_geglu_pack_bias; out planes [M, ldo] with ldo = round_up(f, 32) */
 int ns2_linear_geglu(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M,
@@ -283,12 +288,22 @@ void ns2_model_destroy(ns2_model* m);
 
 /* ------------------------------------------------------------------ training: the backward pass
  * What `loss.backward()` runs for the denoiser (NS2:1635 `pred = self.model(...)` under autograd, NS2:1637-1666 the loss,
- * NS2:1886 `accelerator.backward`).  All operand planes of this section are precision 3 (bf16 hi / lo, interleaved lines).
+ * NS2:1886 `accelerator.backward`).  Two training arithmetics, selected per call by `precision`:
+ *   3 = bf16 hi / lo planes, three bf16 MFMA products per contraction (the fp32 exponent range: no loss scaling);
+ *   4 = "mixed": FMT_H8 lines, one IEEE-half product + both correction terms on the fp8 MFMA (2 MFMA units instead of 3).  IEEE half
+ *       stops at 65504 and loses precision below 6e-5, so the caller scales the loss (a power of two; every gradient is linear in
+ *       it) -- the reference trains under accelerate's fp16 mixed precision the same way (NS2:1710-1711, 1723-1726).  Values that
+ *       leave the half range are counted (ns2_saturation_count): an overflowed step is detected, not silently clamped.
+ *       The attention products stay bf16 x3 at both precisions (q / k / v / dO planes are bf16 hi / lo: ns2_linear_split_as).
  * The contractions reuse the forward GEMM family:
  *   dgrad  dX = dY W   : ns2_linear_f32 on a SECOND pack of the weight -- ns2_weight_pack of W^T ([in, out, taps] with the taps
  *                        flipped), conv_taps as in the forward, pad_left = 0 (the gradient of a causal conv looks ahead);
  *   wgrad  dW = dY^T X : ns2_wgrad on TRANSPOSED planes (contraction over the tokens), split over fixed slots + fixed-order sum.
  * Every reduction of this section is slot based and summed in a fixed order: gradients are deterministic, no atomics. */
+
+/* the training kernels' share of the range guard, stream-ordered and non-synchronising (one word, pinned host memory); the gradient
+ * GEMMs' own conversions are in ns2_saturation_peek_async's words.  ns2_saturation_count sums all of them. */
+int ns2_saturation_peek_train_async(unsigned int* host1, void* stream);
 
 /* re-pack a weight IN PLACE from new fp32 values (same shape / flags as the ns2_weight_pack call that made it): stream-ordered,
  * no allocation, no synchronisation -- the per-step refresh of an optimizer's weights */
@@ -304,11 +319,11 @@ int ns2_weight_update(ns2_weight* w, const float* w_src, const float* extra1x1, 
  *     the bias gradient). */
 int64_t ns2_grad_prep_slices(int M, int64_t ld_t);
 int ns2_grad_prep(const float* x, int64_t ldx, int M, int C, int seq_len, int shift, uint16_t* row_hi, uint16_t* row_lo, int ld_row,
-                  uint16_t* t_hi, uint16_t* t_lo, int64_t ld_t, int t_rows, int per_batch, float* colsum_partial, void* stream);
+                  uint16_t* t_hi, uint16_t* t_lo, int64_t ld_t, int t_rows, int per_batch, float* colsum_partial, int precision, void* stream);
 /* the same transposition for an activation that already exists as operand planes (columns [in_col0, in_col0 + C) of [M, ld_in]):
  * tap t of a causal conv (NS2:583-595) contributes x[n - (k - 1 - t) * dilation], i.e. shift = (k - 1 - t) * dilation */
 int ns2_planes_transpose(const uint16_t* in_hi, const uint16_t* in_lo, int ld_in, int in_col0, int M, int C, int seq_len, int shift,
-                         uint16_t* t_hi, uint16_t* t_lo, int64_t ld_t, int t_rows, int per_batch, void* stream);
+                         uint16_t* t_hi, uint16_t* t_lo, int64_t ld_t, int t_rows, int per_batch, int precision, void* stream);
 /* out[o * inner + j] (+)= sum_s partial[(o * S + s) * inner + j], s in increasing order */
 int ns2_reduce_slices(const float* partial, int64_t outer, int S, int64_t inner, float* out, int accumulate, void* stream);
 /* weight gradient of nn.Linear / CausalConv1d (NS2:583-595, 1021-1024, 1051-1069): dw[r, k, t] = sum_m dY[m, r] * X_t[m, k].
@@ -317,7 +332,7 @@ int ns2_reduce_slices(const float* partial, int64_t outer, int S, int64_t inner,
  * (the nn.Conv1d layout; T = 1: nn.Linear).  workspace = ns2_wgrad_workspace_bytes(R, T * Kp, ld_t) bytes of caller scratch. */
 int64_t ns2_wgrad_workspace_bytes(int R, int ncols, int64_t ld_t);
 int ns2_wgrad(const uint16_t* dyt_hi, const uint16_t* dyt_lo, const uint16_t* xt_hi, const uint16_t* xt_lo, int64_t ld_t, int R, int T,
-              int Kp, int K, float* dw, void* workspace, int64_t workspace_bytes, void* stream);
+              int Kp, int K, float* dw, void* workspace, int64_t workspace_bytes, int precision, void* stream);
 
 /* WavenetResBlock's FiLM + gate (NS2:629-636) for the unfused training forward: out = tanh(z) * sigmoid(z), z = h * gamma_b + beta_b,
  * film[b] = [gamma (d) | beta (d)]; and its backward: dh = dg g'(z) gamma, partial[(b * slices + s)] = [sum dg g'(z) h | sum dg g'(z)]
@@ -328,7 +343,7 @@ int ns2_film_gate_slices(int seq_len);
 int ns2_film_gate_bwd(const float* dg, int64_t lddg, const float* h, int64_t ldh, const float* film, int film_ld, int B, int seq_len, int d,
                       float* dh, int64_t lddh, float* partial, void* stream);
 /* GEGLU (NS2:1004-1007) on the saved pre-activation pre [M, ldp] = [x (f) | gate (f)]: planes of gelu(gate) * x, and the backward */
-int ns2_geglu_fwd(const float* pre, int64_t ldp, int64_t M, int f, uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream);
+int ns2_geglu_fwd(const float* pre, int64_t ldp, int64_t M, int f, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream);
 int ns2_geglu_bwd(const float* dh, int64_t lddh, const float* pre, int64_t ldp, int64_t M, int f, float* dpre, int64_t lddp, void* stream);
 /* RMSNorm backward (NS2:727-746): dx = (dx_add ? dx_add : 0) + dL/dx (dx may alias dx_add: the residual stream's gradient);
  * cond_partial [B * slices][2 d] -> the adaptive (gamma_c, beta_c) gradients, gamma_partial [B * slices][d] -> the learned gamma's */
@@ -340,10 +355,12 @@ int ns2_rmsnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, 
  * backward recomputes P from (ATT:77-155; no key-padding mask on this path: Model never passes one) */
 int ns2_attention_lse(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi, const uint16_t* k_lo, int ldk,
                       int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld, uint16_t* o_hi, uint16_t* o_lo, int ldo, int B,
-                      int H, int Nq, int Nk, float scale, float* lse, int precision, void* stream);
-/* delta[b, h, q] = sum_d dO[q, 64 h + d] * O[q, 64 h + d] (O from its operand planes) */
+                      int H, int Nq, int Nk, float scale, float* lse, int precision, int o_precision, void* stream);
+/* (o_precision: the format of the output planes when it is not the operands': 4 = FMT_H8 lines for a precision-4 out-projection
+ * behind a bf16 x3 attention; 0 = as `precision`) */
+/* delta[b, h, q] = sum_d dO[q, 64 h + d] * O[q, 64 h + d] (O from its operand planes, o_precision 3 or 4) */
 int ns2_attention_delta(const float* d_out, int64_t ld_dout, const uint16_t* o_hi, const uint16_t* o_lo, int ldo, int B, int H, int Nq,
-                        float* delta, void* stream);
+                        float* delta, int o_precision, void* stream);
 /* flash-attention backward, head dim 64: dq = scale * dS k, dk = scale * dS^T q, dv = P^T dO with P recomputed from lse and
  * dS = P (dO v^T - delta).  q / k / v / d_out: row-major planes (head h at columns col0 + 64 h); kt / qt / dot: per-utterance
  * transposed planes [B][H * 64][ld] (ns2_planes_transpose / ns2_grad_prep with per_batch = 1).  dq == NULL or dk == dv == NULL

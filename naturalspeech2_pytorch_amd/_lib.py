@@ -57,6 +57,7 @@ SIGNATURES = {
     "ns2_join_f32": (I, [P, P, I, P, I, L, I, I, P]),
     "ns2_linear_f32": (I, [P, P, P, I, I, I, I, I, P, P, I, P, I, I, I, I, P]),
     "ns2_linear_split": (I, [P, P, P, I, I, I, I, I, P, P, P, I, I, I, I, P]),
+    "ns2_linear_split_as": (I, [P, P, P, I, I, I, I, I, P, P, P, I, I, I, I, I, P]),
     "ns2_linear_geglu": (I, [P, P, P, I, I, P, P, P, I, I, P]),
     "ns2_geglu_pack_bias": (I, [P, I, P, I, P]),
     "ns2_linear_qkv": (I, [P, P, P, I, I, I, I, P, P, I, P, P, I, I, P]),
@@ -104,21 +105,22 @@ SIGNATURES = {
     "ns2_model_destroy": (None, [P]),
     # ---- training: the backward pass
     "ns2_weight_update": (I, [P, P, P, P]),
+    "ns2_saturation_peek_train_async": (I, [P, P]),
     "ns2_grad_prep_slices": (L, [I, L]),
-    "ns2_grad_prep": (I, [P, L, I, I, I, I, P, P, I, P, P, L, I, I, P, P]),
-    "ns2_planes_transpose": (I, [P, P, I, I, I, I, I, I, P, P, L, I, I, P]),
+    "ns2_grad_prep": (I, [P, L, I, I, I, I, P, P, I, P, P, L, I, I, P, I, P]),
+    "ns2_planes_transpose": (I, [P, P, I, I, I, I, I, I, P, P, L, I, I, I, P]),
     "ns2_reduce_slices": (I, [P, L, I, L, P, I, P]),
     "ns2_wgrad_workspace_bytes": (L, [I, I, L]),
-    "ns2_wgrad": (I, [P, P, P, P, L, I, I, I, I, P, P, L, P]),
+    "ns2_wgrad": (I, [P, P, P, P, L, I, I, I, I, P, P, L, I, P]),
     "ns2_film_gate_fwd": (I, [P, L, P, I, I, L, I, P, L, P]),
     "ns2_film_gate_slices": (I, [I]),
     "ns2_film_gate_bwd": (I, [P, L, P, L, P, I, I, I, I, P, L, P, P]),
-    "ns2_geglu_fwd": (I, [P, L, L, I, P, P, I, P]),
+    "ns2_geglu_fwd": (I, [P, L, L, I, P, P, I, I, P]),
     "ns2_geglu_bwd": (I, [P, L, P, L, L, I, P, L, P]),
     "ns2_rmsnorm_bwd_slices": (I, [I]),
     "ns2_rmsnorm_bwd": (I, [P, L, P, L, P, P, I, I, I, I, P, P, L, P, P, P]),
-    "ns2_attention_lse": (I, [P, P, I, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, F, P, I, P]),
-    "ns2_attention_delta": (I, [P, L, P, P, I, I, I, I, P, P]),
+    "ns2_attention_lse": (I, [P, P, I, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, F, P, I, I, P]),
+    "ns2_attention_delta": (I, [P, L, P, P, I, I, I, I, P, I, P]),
     "ns2_attention_bwd": (I, [POINTER(AttnBwdArgs), P]),
 }
 

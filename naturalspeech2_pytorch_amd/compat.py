@@ -26,14 +26,15 @@ def hip_backed_model_class(reference_model_cls):
     defaults = {k: v.default for k, v in sig.parameters.items() if v.default is not inspect.Parameter.empty}
 
     class HipBackedModel(HipDenoiserMixin, reference_model_cls):
-        def __init__(self, dim, *args, precision="exact", train_backend="reference", **kwargs):
+        def __init__(self, dim, *args, precision="exact", train_backend="reference", train_precision="exact", **kwargs):
             reference_model_cls.__init__(self, dim, *args, **kwargs)
             bound = sig.bind(self, dim, *args, **kwargs)
             cfg = dict(defaults)
             cfg.update({k: v for k, v in bound.arguments.items() if k != "self"})
             self._hip_init({k: cfg[k] for k in _CFG_KEYS}, precision)
-            assert train_backend in ("reference", "hip")
+            assert train_backend in ("reference", "hip") and train_precision in ("exact", "mixed")
             self.train_backend = train_backend
+            self.train_precision = train_precision            # arithmetic of train_backend="hip" (training.py)
 
         def _forward_autograd(self, x, times, prompt=None, prompt_mask=None, cond=None, cond_drop_prob=None):
             """train_backend="reference" (default): the reference's own forward under torch autograd -- the loss is upstream's bit for

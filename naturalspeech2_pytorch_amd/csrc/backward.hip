@@ -22,8 +22,10 @@ namespace ns2 {
 
 // ================================================================================================ tplanes
 // One 64 x 64 tile per workgroup: load (fp32 -> split, or planes), optional row-plane store, transpose through LDS, store
-// transposed interleaved lines [hi32 | lo32] along the token axis.
-template <bool IN_F32>
+// transposed interleaved lines along the token axis.  H8 = false: bf16 lines [hi32 | lo32] (the exact arithmetic); H8 = true: FMT_H8
+// lines [half32 | e5m2(x) 32 B | e5m2((x - half(x)) 2^12) 32 B] (the mixed training arithmetic).  In LDS an element is two 16-bit
+// words either way: th = hi / half, tl = lo / (h8 | l8 << 8).
+template <bool IN_F32, bool H8>
 __global__ __launch_bounds__(256) void tplanes_kernel(const TPlanesArgs a) {
   __shared__ uint16_t th[64][66], tl[64][66];
   __shared__ float cs[16][64];
@@ -68,18 +70,30 @@ __global__ __launch_bounds__(256) void tplanes_kernel(const TPlanesArgs a) {
           for (int e = 0; e < 4; ++e) if (c + e < a.C) v[e] = a.xf[sr * a.ldx + c + e];
         }
       }
+      if constexpr (H8) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        bf16_t h, l;
-        split_bf16(v[e], h, l);
-        th[i][4 * ch + e] = h; tl[i][4 * ch + e] = l;
-        csum[e] += v[e];
+        for (int e2 = 0; e2 < 2; ++e2) {
+          uint32_t h16, h8, l8;
+          cvt2_h8(v[2 * e2], v[2 * e2 + 1], h16, h8, l8);          // (counts values beyond the half range: the loss-scale overflow check)
+          th[i][4 * ch + 2 * e2] = (uint16_t)(h16 & 0xffffu); th[i][4 * ch + 2 * e2 + 1] = (uint16_t)(h16 >> 16);
+          tl[i][4 * ch + 2 * e2] = (uint16_t)((h8 & 0xffu) | ((l8 & 0xffu) << 8));
+          tl[i][4 * ch + 2 * e2 + 1] = (uint16_t)(((h8 >> 8) & 0xffu) | (((l8 >> 8) & 0xffu) << 8));
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bf16_t h, l;
+          split_bf16(v[e], h, l);
+          th[i][4 * ch + e] = h; tl[i][4 * ch + e] = l;
+        }
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] += v[e];
       // row planes of the UNSHIFTED rows (shift must be 0 when they are requested; checked by the launcher)
       if (a.row_hi) {
         const long m = a.per_batch ? (long)b * a.seq_len + n0 + i : n0 + i;
         const bool rok = a.per_batch ? (n0 + i < a.seq_len) : (m < a.M);
-        if (rok && c < a.ld_row) store_cols4(a.row_hi + m * 2L * a.ld_row, c, v[0], v[1], v[2], v[3], FMT_BF16, true);
+        if (rok && c < a.ld_row) store_cols4(a.row_hi + m * 2L * a.ld_row, c, v[0], v[1], v[2], v[3], H8 ? FMT_H8 : FMT_BF16, true);
       }
     }
     if (a.colsum_partial) {                     // fixed-order column sums of this 64-row tile (bias gradients)
@@ -88,21 +102,32 @@ __global__ __launch_bounds__(256) void tplanes_kernel(const TPlanesArgs a) {
     }
   } else {
     const int ch = tid & 15;                    // 16-B chunk of the two 128-B lines covering columns c0 .. c0 + 63
-    const int line = ch >> 3, q = ch & 7, plane = q >> 2, kc = q & 3;
+    const int line = ch >> 3, q = ch & 7;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int i = (tid >> 4) + 16 * pass;
       const long sr = src_row(i);
-      const int c = c0 + 32 * line + 8 * kc;    // first of 8 logical columns
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (sr >= 0 && c < a.C) {                  // C is a multiple of 8 for plane inputs (checked by the launcher)
-        const bf16_t* p = a.in_hi + sr * 2L * a.ld_in + pcol(a.in_col0 + c, true) + 32 * plane;
+      if (sr >= 0 && c0 + 32 * line < a.C) {     // C is a multiple of 8 for plane inputs (checked by the launcher); lines are whole
+        const bf16_t* p = a.in_hi + sr * 2L * a.ld_in + pcol(a.in_col0 + c0 + 32 * line, true) + 8 * q;      // 16-B chunk q of the line
         v = *reinterpret_cast<const uint4*>(p);
       }
-      uint16_t* dst = (plane ? &tl[i][0] : &th[i][0]) + 32 * line + 8 * kc;
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      if (!H8 || q < 4) {
+        // 8 16-bit values: bf16 hi (q < 4) / lo (q >= 4) of columns 8 (q & 3) .., or the halves of columns 8 q ..
+        uint16_t* dst = ((!H8 && q >= 4) ? &tl[i][0] : &th[i][0]) + 32 * line + 8 * (q & 3);
+        const bool okc = c0 + 32 * line + 8 * (q & 3) < a.C;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { dst[2 * e] = (uint16_t)(w[e] & 0xffffu); dst[2 * e + 1] = (uint16_t)(w[e] >> 16); }
+        for (int e = 0; e < 4; ++e) { dst[2 * e] = okc ? (uint16_t)(w[e] & 0xffffu) : 0; dst[2 * e + 1] = okc ? (uint16_t)(w[e] >> 16) : 0; }
+      } else {
+        // 16 bytes: e5m2(x) (q = 4, 5) or the scaled remainders (q = 6, 7) of columns 16 (q & 1) ..: byte halves of tl
+        uint8_t* dstb = reinterpret_cast<uint8_t*>(&tl[i][32 * line + 16 * (q & 1)]) + (q >= 6 ? 1 : 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const bool okc = c0 + 32 * line + 16 * (q & 1) + e < a.C;
+          dstb[2 * e] = okc ? (uint8_t)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) : (uint8_t)0;
+        }
+      }
     }
   }
   __syncthreads();
@@ -113,9 +138,10 @@ __global__ __launch_bounds__(256) void tplanes_kernel(const TPlanesArgs a) {
     if (c0 + tid < a.C) a.colsum_partial[(long)blockIdx.y * a.C + c0 + tid] = s;
   }
   if (!a.t_hi) return;
-  // ---- transposed store: output row = column c of the tile, 64 token positions = two interleaved lines
+  // ---- transposed store: output row = column c of the tile, 64 token positions = two interleaved lines; a thread writes the
+  // 16-byte chunk q of a line
   const int ch = tid & 15;
-  const int line = ch >> 3, q = ch & 7, plane = q >> 2, mc = q & 3;
+  const int line = ch >> 3, q = ch & 7;
   const int rows_out = a.per_batch ? a.t_rows_per_batch : a.t_rows;
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
@@ -124,14 +150,25 @@ __global__ __launch_bounds__(256) void tplanes_kernel(const TPlanesArgs a) {
     const long col = n0 + 32 * line;            // first token position of this output line
     if (c >= rows_out || col >= a.ld_t) continue;
     uint32_t w[4];
+    if (!H8 || q < 4) {
+      const bool lo_plane = !H8 && q >= 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i0 = 32 * line + 8 * mc + 2 * e;
-      const uint16_t lo16 = plane ? tl[i0][cr] : th[i0][cr], hi16 = plane ? tl[i0 + 1][cr] : th[i0 + 1][cr];
-      w[e] = (uint32_t)lo16 | ((uint32_t)hi16 << 16);
+      for (int e = 0; e < 4; ++e) {
+        const int i0 = 32 * line + 8 * (q & 3) + 2 * e;
+        const uint16_t lo16 = lo_plane ? tl[i0][cr] : th[i0][cr], hi16 = lo_plane ? tl[i0 + 1][cr] : th[i0 + 1][cr];
+        w[e] = (uint32_t)lo16 | ((uint32_t)hi16 << 16);
+      }
+    } else {
+      const int sh = q >= 6 ? 8 : 0;            // e5m2(x) = low byte, scaled remainder = high byte of tl
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i0 = 32 * line + 16 * (q & 1) + 4 * e;
+        w[e] = ((uint32_t)(tl[i0][cr] >> sh) & 0xffu) | (((uint32_t)(tl[i0 + 1][cr] >> sh) & 0xffu) << 8) |
+               (((uint32_t)(tl[i0 + 2][cr] >> sh) & 0xffu) << 16) | (((uint32_t)(tl[i0 + 3][cr] >> sh) & 0xffu) << 24);
+      }
     }
     const long orow = a.per_batch ? (long)b * a.t_rows_per_batch + c : c;
-    bf16_t* dst = a.t_hi + orow * 2L * a.ld_t + 2L * col + 32 * plane + 8 * mc;
+    bf16_t* dst = a.t_hi + orow * 2L * a.ld_t + 2L * col + 8 * q;
     *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
@@ -155,8 +192,14 @@ hipError_t launch_tplanes(const TPlanesArgs& a, hipStream_t s) {
   if (a.per_batch) ntile_m = (long)(a.M / a.seq_len) * ((a.ld_t + 63) / 64);
   else ntile_m = tplanes_slices(a.M, a.t_hi ? a.ld_t : 0);
   const dim3 grid((ccover + 63) / 64, (unsigned)ntile_m);
-  if (in_f32) hipLaunchKernelGGL(tplanes_kernel<true>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(tplanes_kernel<false>, grid, dim3(256), 0, s, a);
+  if (a.fmt != FMT_BF16 && a.fmt != FMT_H8) return hipErrorInvalidValue;
+  if (a.fmt == FMT_H8) {
+    if (in_f32) hipLaunchKernelGGL((tplanes_kernel<true, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((tplanes_kernel<false, true>), grid, dim3(256), 0, s, a);
+  } else {
+    if (in_f32) hipLaunchKernelGGL((tplanes_kernel<true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((tplanes_kernel<false, false>), grid, dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 long tplanes_slices(int M, long ld_t) { return (max((long)M, ld_t) + 63) / 64; }
@@ -287,7 +330,7 @@ hipError_t launch_film_gate_bwd(const float* dg, long lddg, const float* h, long
 
 // ================================================================================================ GEGLU (NS2:1004-1007)
 // pre [M, ldp] = [x (f) | gate (f)] -> h = gelu(gate) * x as operand planes [M, ldo] (zero beyond f)
-__global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* pre, long ldp, long M, int f, bf16_t* out_hi, bf16_t* out_lo, int ldo) {
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* pre, long ldp, long M, int f, bf16_t* out_hi, bf16_t* out_lo, int ldo, int fmt) {
   const int chunks = ldo >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * chunks) return;
@@ -298,12 +341,13 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* pre, long l
 #pragma unroll
   for (int e = 0; e < 4; ++e)
     if (c + e < f) o[e] = gelu_erf(p[f + c + e]) * p[c + e];
-  store_cols4(out_hi + row * 2L * ldo, c, o[0], o[1], o[2], o[3], FMT_BF16, out_lo != nullptr);
+  store_cols4(out_hi + row * 2L * ldo, c, o[0], o[1], o[2], o[3], fmt, out_lo != nullptr);
 }
-hipError_t launch_geglu_fwd(const float* pre, long ldp, long M, int f, bf16_t* out_hi, bf16_t* out_lo, int ldo, hipStream_t s) {
+hipError_t launch_geglu_fwd(const float* pre, long ldp, long M, int f, bf16_t* out_hi, bf16_t* out_lo, int ldo, hipStream_t s, int fmt) {
   if (M <= 0 || f <= 0 || ldp < 2L * f || (ldo & 31) || ldo < f || !out_lo || out_lo != out_hi + 32) return hipErrorInvalidValue;
+  if (fmt != FMT_BF16 && fmt != FMT_H8) return hipErrorInvalidValue;
   const long n = M * (ldo >> 2);
-  hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, ldp, M, f, out_hi, out_lo, ldo);
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, ldp, M, f, out_hi, out_lo, ldo, fmt);
   return hipGetLastError();
 }
 // dpre[:, c] = dh * gelu(gate) ; dpre[:, f + c] = dh * x * (Phi(gate) + gate * phi(gate))
@@ -432,7 +476,7 @@ hipError_t launch_rmsnorm_bwd(const NormBwdArgs& a, hipStream_t s) {
 // ================================================================================================ attention backward (ATT:77-155)
 // delta[b, h, q] = sum_d dO[q, 64 h + d] * O[q, 64 h + d]   (O from its operand planes, hi + lo)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* dO, long lddo, const bf16_t* o_hi, int ldo, int B, int H, int Nq,
-                                                         float* delta) {
+                                                         float* delta, int o_fmt) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const long tot = (long)B * Nq * H;
   if (idx >= tot) return;
@@ -444,16 +488,22 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* dO, long l
   for (int blk = 0; blk < 2; ++blk) {
     const bf16_t* line = o_hi + m * 2L * ldo + pcol(64 * h + 32 * blk, true);
 #pragma unroll 8
-    for (int e = 0; e < 32; ++e) s += g[32 * blk + e] * (bf2f(line[e]) + bf2f(line[32 + e]));
+    for (int e = 0; e < 32; ++e) {
+      // the value the out-projection multiplies: hi + lo (bf16 lines) or half + remainder (FMT_H8 lines; the e5m2 remainder is 2^12-scaled)
+      const float o = o_fmt == FMT_H8 ? h2f(line[e]) + bf8_to_f(reinterpret_cast<const unsigned char*>(line)[96 + e]) * (1.0f / H8_LO_SCALE)
+                                      : bf2f(line[e]) + bf2f(line[32 + e]);
+      s += g[32 * blk + e] * o;
+    }
   }
   const long b = m / Nq, q = m - b * Nq;
   delta[(b * H + h) * Nq + q] = s;
 }
 hipError_t launch_attn_delta(const float* dO, long lddo, const bf16_t* o_hi, const bf16_t* o_lo, int ldo, int B, int H, int Nq, float* delta,
-                             hipStream_t s) {
+                             hipStream_t s, int o_fmt) {
   if (B <= 0 || H <= 0 || Nq <= 0 || !o_lo || o_lo != o_hi + 32 || (ldo & 31) || ldo < 64 * H) return hipErrorInvalidValue;
+  if (o_fmt != FMT_BF16 && o_fmt != FMT_H8) return hipErrorInvalidValue;
   const long n = (long)B * Nq * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dO, lddo, o_hi, ldo, B, H, Nq, delta);
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dO, lddo, o_hi, ldo, B, H, Nq, delta, o_fmt);
   return hipGetLastError();
 }
 
@@ -709,5 +759,7 @@ hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
   }
   return hipSuccess;
 }
+
+NS2_DEFINE_SATURATION_READER(backward)
 
 }  // namespace ns2

@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 110; }   // 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 111; }   // 111: training entry points take a precision (3 = bf16 x3, 4 = mixed on FMT_H8 lines), ns2_linear_split_as; 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 3, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel, 3 = auto without split-K");
   force_gemm_kernel(kernel);
@@ -121,6 +121,18 @@ extern "C" int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const
   ARGCHK(pad_left >= -1 && pad_left < (conv_taps > 0 ? conv_taps : 1) && (act >= 0 && act <= 2), "ns2_linear_split: bad pad_left / act");
   return gemm_split(w->w, a_hi, a_lo, lda, M, conv_taps, dilation, seq_len, bias, out_hi, out_lo, ldo, precision, (hipStream_t)stream,
                     pad_left, act);
+}
+extern "C" int ns2_linear_split_as(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
+                                   int dilation, int seq_len, const float* bias, uint16_t* out_hi, uint16_t* out_lo, int ldo,
+                                   int pad_left, int act, int precision, int out_precision, void* stream) {
+  ARGCHK(w && a_hi && out_hi && prec_ok(precision) && prec_ok(out_precision), "ns2_linear_split_as: bad arguments");
+  WFMT(w, precision, "ns2_linear_split_as");
+  ARGCHK(!w->geglu && !w->has_extra && (conv_taps == 0 ? w->taps == 1 : w->taps == conv_taps), "ns2_linear_split_as: weight packing does not match");
+  ARGCHK(lda >= w->cols_p && (ldo & 1) == 0, "ns2_linear_split_as: bad leading dimensions");
+  ARGCHK(pad_left >= -1 && pad_left < (conv_taps > 0 ? conv_taps : 1) && (act >= 0 && act <= 2), "ns2_linear_split_as: bad pad_left / act");
+  ARGCHK(out_precision == 1 || (out_precision == 2) == (out_lo == nullptr), "ns2_linear_split_as: out_lo must be null for dense IEEE-half output, hi + 32 for interleaved lines");
+  return gemm_split(w->w, a_hi, a_lo, lda, M, conv_taps, dilation, seq_len, bias, out_hi, out_lo, ldo, precision, (hipStream_t)stream,
+                    pad_left, act, op_fmt(out_precision));
 }
 extern "C" int ns2_linear_geglu(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M,
                                 const float* packed_bias, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision, void* stream) {
@@ -297,8 +309,9 @@ extern "C" int ns2_lstm2(const float* xproj1, int64_t ld_x, const float* w_hh1, 
 extern "C" int ns2_saturation_count(int reset, int64_t* count) {
   ARGCHK(count != nullptr, "ns2_saturation_count: null pointer");
   HIPRET(hipDeviceSynchronize());                    // a diagnostic read between sampling runs, never on a launch path
-  const unsigned int parts[4] = {saturation_read_gemm(reset != 0), saturation_read_gemm2(reset != 0),
-                                 saturation_read_attention(reset != 0), saturation_read_elementwise(reset != 0)};
+  const unsigned int parts[5] = {saturation_read_gemm(reset != 0), saturation_read_gemm2(reset != 0),
+                                 saturation_read_attention(reset != 0), saturation_read_elementwise(reset != 0),
+                                 saturation_read_backward(reset != 0)};
   int64_t tot = 0;
   for (unsigned int p : parts) {
     ARGCHK(p != ~0u, "ns2_saturation_count: could not read the device counter");

@@ -37,29 +37,42 @@ extern "C" int ns2_weight_update(ns2_weight* w, const float* w_src, const float*
   return NS2_OK;
 }
 
+// the training kernels' share of the range guard (ns2_saturation_count sums it in; this is its stream-ordered, non-synchronising
+// read for a training loop under the mixed arithmetic: one word into pinned host memory)
+extern "C" int ns2_saturation_peek_train_async(unsigned int* host1, void* stream) {
+  ARGCHK(host1 != nullptr, "ns2_saturation_peek_train_async: null pointer");
+  HIPRET(saturation_peek_backward(host1, (hipStream_t)stream));
+  return NS2_OK;
+}
+
 extern "C" int64_t ns2_grad_prep_slices(int M, int64_t ld_t) { return M > 0 ? (int64_t)tplanes_slices(M, (long)ld_t) : 0; }
 
 extern "C" int ns2_grad_prep(const float* x, int64_t ldx, int M, int C, int seq_len, int shift, uint16_t* row_hi, uint16_t* row_lo,
                              int ld_row, uint16_t* t_hi, uint16_t* t_lo, int64_t ld_t, int t_rows, int per_batch, float* colsum_partial,
-                             void* stream) {
+                             int precision, void* stream) {
   ARGCHK(x && (row_hi || t_hi || colsum_partial), "ns2_grad_prep: nothing to do");
+  ARGCHK(precision == 3 || precision == 4, "ns2_grad_prep: precision 3 (bf16 hi / lo planes) or 4 (FMT_H8 lines)");
   TPlanesArgs a;
   memset(&a, 0, sizeof a);
   a.xf = x; a.ldx = (long)ldx; a.M = M; a.C = C; a.seq_len = seq_len; a.shift = shift;
   a.row_hi = row_hi; a.row_lo = row_lo; a.ld_row = ld_row;
   a.t_hi = t_hi; a.t_lo = t_lo; a.ld_t = (long)ld_t; a.per_batch = per_batch; a.t_rows_per_batch = t_rows; a.t_rows = t_rows;
   a.colsum_partial = colsum_partial;
+  a.fmt = precision == 4 ? FMT_H8 : FMT_BF16;
   HIPRET(launch_tplanes(a, (hipStream_t)stream));
   return NS2_OK;
 }
 
 extern "C" int ns2_planes_transpose(const uint16_t* in_hi, const uint16_t* in_lo, int ld_in, int in_col0, int M, int C, int seq_len,
-                                    int shift, uint16_t* t_hi, uint16_t* t_lo, int64_t ld_t, int t_rows, int per_batch, void* stream) {
-  ARGCHK(in_hi && in_lo && t_hi && t_lo, "ns2_planes_transpose: null pointer (operands are bf16 hi/lo planes)");
+                                    int shift, uint16_t* t_hi, uint16_t* t_lo, int64_t ld_t, int t_rows, int per_batch, int precision,
+                                    void* stream) {
+  ARGCHK(in_hi && in_lo && t_hi && t_lo, "ns2_planes_transpose: null pointer (operands are interleaved lines: lo = hi + 32)");
+  ARGCHK(precision == 3 || precision == 4, "ns2_planes_transpose: precision 3 (bf16 hi / lo planes) or 4 (FMT_H8 lines)");
   TPlanesArgs a;
   memset(&a, 0, sizeof a);
   a.in_hi = in_hi; a.in_lo = in_lo; a.ld_in = ld_in; a.in_col0 = in_col0; a.M = M; a.C = C; a.seq_len = seq_len; a.shift = shift;
   a.t_hi = t_hi; a.t_lo = t_lo; a.ld_t = (long)ld_t; a.per_batch = per_batch; a.t_rows_per_batch = t_rows; a.t_rows = t_rows;
+  a.fmt = precision == 4 ? FMT_H8 : FMT_BF16;
   HIPRET(launch_tplanes(a, (hipStream_t)stream));
   return NS2_OK;
 }
@@ -86,8 +99,9 @@ extern "C" int64_t ns2_wgrad_workspace_bytes(int R, int ncols, int64_t ld_t) {
   return (int64_t)wgrad_split(R, ncols, ld_t) * R * ncols * (int64_t)sizeof(float);
 }
 extern "C" int ns2_wgrad(const uint16_t* dyt_hi, const uint16_t* dyt_lo, const uint16_t* xt_hi, const uint16_t* xt_lo, int64_t ld_t, int R,
-                         int T, int Kp, int K, float* dw, void* workspace, int64_t workspace_bytes, void* stream) {
-  ARGCHK(dyt_hi && dyt_lo == dyt_hi + 32 && xt_hi && xt_lo == xt_hi + 32 && dw && workspace, "ns2_wgrad: null pointer / operands must be bf16 hi/lo planes");
+                         int T, int Kp, int K, float* dw, void* workspace, int64_t workspace_bytes, int precision, void* stream) {
+  ARGCHK(dyt_hi && dyt_lo == dyt_hi + 32 && xt_hi && xt_lo == xt_hi + 32 && dw && workspace, "ns2_wgrad: null pointer / operands must be interleaved lines (lo = hi + 32)");
+  ARGCHK(precision == 3 || precision == 4, "ns2_wgrad: precision 3 (bf16 x3) or 4 (half product + fp8 correction terms on FMT_H8 lines)");
   ARGCHK(R > 0 && T > 0 && K > 0 && Kp >= K && (Kp & 3) == 0 && ld_t > 0 && (ld_t & 31) == 0 && ld_t < (1LL << 30), "ns2_wgrad: bad shapes");
   const int ncols = T * Kp;
   const int S = wgrad_split(R, ncols, ld_t);
@@ -101,7 +115,7 @@ extern "C" int ns2_wgrad(const uint16_t* dyt_hi, const uint16_t* dyt_lo, const u
   g.nz = S; g.a_zs = (long)nkt * 32; g.w_zs = (long)nkt * 32; g.out_f_zs = (long)R * ncols;
   g.pad_left = -1; g.out_fmt = -1; g.vt_fmt = -1;
   g.epi = EPI_F32; g.out_f = (float*)workspace; g.ldo_f = ncols;
-  HIPRET(launch_gemm(g, 3, (hipStream_t)stream));
+  HIPRET(launch_gemm(g, precision, (hipStream_t)stream));
   HIPRET(launch_wgrad_reduce((const float*)workspace, S, R, ncols, T, Kp, K, dw, (hipStream_t)stream));
   return NS2_OK;
 }
@@ -119,9 +133,11 @@ extern "C" int ns2_film_gate_bwd(const float* dg, int64_t lddg, const float* h, 
   HIPRET(launch_film_gate_bwd(dg, (long)lddg, h, (long)ldh, film, film_ld, B, seq_len, d, dh, (long)lddh, partial, (hipStream_t)stream));
   return NS2_OK;
 }
-extern "C" int ns2_geglu_fwd(const float* pre, int64_t ldp, int64_t M, int f, uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream) {
+extern "C" int ns2_geglu_fwd(const float* pre, int64_t ldp, int64_t M, int f, uint16_t* out_hi, uint16_t* out_lo, int ldo, int precision,
+                             void* stream) {
   ARGCHK(pre && out_hi && out_lo, "ns2_geglu_fwd: null pointer");
-  HIPRET(launch_geglu_fwd(pre, (long)ldp, (long)M, f, out_hi, out_lo, ldo, (hipStream_t)stream));
+  ARGCHK(precision == 3 || precision == 4, "ns2_geglu_fwd: precision 3 (bf16 hi / lo planes) or 4 (FMT_H8 lines)");
+  HIPRET(launch_geglu_fwd(pre, (long)ldp, (long)M, f, out_hi, out_lo, ldo, (hipStream_t)stream, precision == 4 ? FMT_H8 : FMT_BF16));
   return NS2_OK;
 }
 extern "C" int ns2_geglu_bwd(const float* dh, int64_t lddh, const float* pre, int64_t ldp, int64_t M, int f, float* dpre, int64_t lddp,
@@ -146,21 +162,23 @@ extern "C" int ns2_rmsnorm_bwd(const float* x, int64_t ldx, const float* dy, int
 
 extern "C" int ns2_attention_lse(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi, const uint16_t* k_lo,
                                  int ldk, int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld, uint16_t* o_hi, uint16_t* o_lo,
-                                 int ldo, int B, int H, int Nq, int Nk, float scale, float* lse, int precision, void* stream) {
+                                 int ldo, int B, int H, int Nq, int Nk, float scale, float* lse, int precision, int o_precision, void* stream) {
   ARGCHK(q_hi && k_hi && vt_hi && o_hi && lse && precision >= 1 && precision <= 4, "ns2_attention_lse: bad arguments");
+  ARGCHK(o_precision == 0 || o_precision == 3 || o_precision == 4, "ns2_attention_lse: o_precision 0 (= precision), 3 (bf16 hi / lo) or 4 (FMT_H8)");
   AttnArgs a;
   a.q_hi = q_hi; a.q_lo = q_lo; a.ldq = ldq; a.q_col0 = q_col0;
   a.k_hi = k_hi; a.k_lo = k_lo; a.ldk = ldk; a.k_col0 = k_col0;
   a.vt_hi = vt_hi; a.vt_lo = vt_lo; a.vt_ld = vt_ld;
-  a.o_hi = o_hi; a.o_lo = o_lo; a.ldo = ldo; a.o_fmt = -1;
+  a.o_hi = o_hi; a.o_lo = o_lo; a.ldo = ldo; a.o_fmt = o_precision == 4 ? FMT_H8 : (o_precision == 3 ? FMT_BF16 : -1);
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale; a.kmask = nullptr; a.lse = lse;
   HIPRET(launch_attention(a, precision, (hipStream_t)stream));
   return NS2_OK;
 }
 extern "C" int ns2_attention_delta(const float* d_out, int64_t ld_dout, const uint16_t* o_hi, const uint16_t* o_lo, int ldo, int B, int H,
-                                   int Nq, float* delta, void* stream) {
+                                   int Nq, float* delta, int o_precision, void* stream) {
   ARGCHK(d_out && o_hi && delta, "ns2_attention_delta: null pointer");
-  HIPRET(launch_attn_delta(d_out, (long)ld_dout, o_hi, o_lo, ldo, B, H, Nq, delta, (hipStream_t)stream));
+  ARGCHK(o_precision == 3 || o_precision == 4, "ns2_attention_delta: o_precision 3 (bf16 hi / lo planes) or 4 (FMT_H8 lines)");
+  HIPRET(launch_attn_delta(d_out, (long)ld_dout, o_hi, o_lo, ldo, B, H, Nq, delta, (hipStream_t)stream, o_precision == 4 ? FMT_H8 : FMT_BF16));
   return NS2_OK;
 }
 extern "C" int ns2_attention_bwd(const ns2_attn_bwd_args* p, void* stream) {

@@ -741,6 +741,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
         if constexpr (F16) {
           if (g.out_fmt == FMT_F16 && !g.out_lo) { fn(std::integral_constant<int, PF_F16>{}); return true; }
           if (g.out_fmt == FMT_H8) { fn(std::integral_constant<int, PF_H8>{}); return true; }
+          // bf16 hi / lo lines from the mixed product: q | k | v of the mixed TRAINING arithmetic, whose attention stays bf16 x3
+          if constexpr (NSPLIT == 2 && EPI == EPI_SPLIT) { if (g.out_fmt == FMT_BF16 && g.out_lo) { fn(std::integral_constant<int, PF_BF16IL>{}); return true; } }
         } else {
           if (g.out_fmt == FMT_BF16 && g.out_lo) { fn(std::integral_constant<int, PF_BF16IL>{}); return true; }
           if constexpr (NSPLIT == 1) { if (g.out_fmt == FMT_BF16 && !g.out_lo) { fn(std::integral_constant<int, PF_BF16>{}); return true; } }

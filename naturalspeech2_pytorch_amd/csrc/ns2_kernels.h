@@ -208,11 +208,13 @@ unsigned int saturation_read_gemm(bool reset);
 unsigned int saturation_read_gemm2(bool reset);
 unsigned int saturation_read_attention(bool reset);
 unsigned int saturation_read_elementwise(bool reset);
+unsigned int saturation_read_backward(bool reset);       // the FMT_H8 conversions of the training kernels (backward.hip)
 // stream-ordered, non-synchronising copy of the same counter into (pinned) host memory
 hipError_t saturation_peek_gemm(unsigned int* dst, hipStream_t s);
 hipError_t saturation_peek_gemm2(unsigned int* dst, hipStream_t s);
 hipError_t saturation_peek_attention(unsigned int* dst, hipStream_t s);
 hipError_t saturation_peek_elementwise(unsigned int* dst, hipStream_t s);
+hipError_t saturation_peek_backward(unsigned int* dst, hipStream_t s);
 
 hipError_t launch_rvq_prepare(const float* codebooks, float* cb_norm, int Q, int C, int D, hipStream_t s);
 hipError_t launch_rvq_encode(const RvqArgs& a, hipStream_t s);
@@ -234,6 +236,8 @@ struct TPlanesArgs {
   int per_batch;                                   // 0: row c, column m (all M tokens); 1: row b * t_rows_per_batch + c, column n
   int t_rows_per_batch; int t_rows;                // rows written (>= C, zeros beyond C): per utterance / in total
   float* colsum_partial;                           // optional (fp32 input): [slices][C] column sums of 64-row tiles (bias gradients)
+  int fmt;                                         // FMT_BF16 (hi / lo lines) or FMT_H8 (the mixed training arithmetic): the format of the
+                                                   // input planes, of the row planes and of the transposed planes alike
 };
 hipError_t launch_tplanes(const TPlanesArgs& a, hipStream_t s);
 long tplanes_slices(int M, long ld_t);             // number of 64-row tiles (= colsum slots) of a non-per_batch launch
@@ -244,7 +248,7 @@ hipError_t launch_film_gate_fwd(const float* h, long ldh, const float* film, int
 int film_gate_slices(int seq_len);
 hipError_t launch_film_gate_bwd(const float* dg, long lddg, const float* h, long ldh, const float* film, int film_ld, int B, int seq_len,
                                 int d, float* dh, long lddh, float* partial, hipStream_t s);
-hipError_t launch_geglu_fwd(const float* pre, long ldp, long M, int f, bf16_t* out_hi, bf16_t* out_lo, int ldo, hipStream_t s);
+hipError_t launch_geglu_fwd(const float* pre, long ldp, long M, int f, bf16_t* out_hi, bf16_t* out_lo, int ldo, hipStream_t s, int fmt = 0);
 hipError_t launch_geglu_bwd(const float* dh, long lddh, const float* pre, long ldp, long M, int f, float* dpre, long lddp, hipStream_t s);
 struct NormBwdArgs {
   const float* x; long ldx;            // the norm's input [B * seq_len, d]
@@ -259,7 +263,7 @@ struct NormBwdArgs {
 int rmsnorm_bwd_slices(int seq_len);
 hipError_t launch_rmsnorm_bwd(const NormBwdArgs& a, hipStream_t s);
 hipError_t launch_attn_delta(const float* dO, long lddo, const bf16_t* o_hi, const bf16_t* o_lo, int ldo, int B, int H, int Nq, float* delta,
-                             hipStream_t s);
+                             hipStream_t s, int o_fmt = 0);
 struct AttnBwdArgs {
   const bf16_t* q_hi; const bf16_t* q_lo; int ldq, q_col0;        // [B*Nq, ldq], head h at columns q_col0 + 64 h
   const bf16_t* k_hi; const bf16_t* k_lo; int ldk, k_col0;        // [B*Nk, ldk]

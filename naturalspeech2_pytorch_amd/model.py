@@ -598,6 +598,7 @@ class Model(HipDenoiserMixin, nn.Module):
         self.transformer = tr
 
         self.train_backend = "hip"                    # "composite": the PyTorch composite also on the GPU (A/B, tests)
+        self.train_precision = "exact"                # "mixed": half product + fp8 correction terms under a loss scale (training.py `_Scale`)
         self._hip_init(dict(dim=dim, depth=depth, dim_head=dim_head, heads=heads, ff_mult=ff_mult, wavenet_layers=wavenet_layers,
                             wavenet_stacks=wavenet_stacks, dim_cond_mult=dim_cond_mult, condition_on_prompt=condition_on_prompt,
                             dim_prompt=dim_prompt, num_latents_m=num_latents_m, resampler_depth=resampler_depth), precision)

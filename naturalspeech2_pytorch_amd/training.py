@@ -43,12 +43,13 @@ from .ops import Planes, round_up
 
 # =============================================================================================== HIP backend
 class TPlanes:
-    """transposed operand planes: `rows` rows of `ld` token columns (bf16 hi/lo lines along the token axis)"""
-    __slots__ = ("buf", "rows", "ld")
+    """transposed operand planes: `rows` rows of `ld` token columns, interleaved 128-byte lines along the token axis --
+    bf16 [hi32 | lo32] (precision 3) or FMT_H8 [half32 | e5m2 | e5m2 remainder] (precision 4): 4 bytes per element either way"""
+    __slots__ = ("buf", "rows", "ld", "precision")
 
-    def __init__(self, rows, ld, device):
+    def __init__(self, rows, ld, device, precision=3):
         self.buf = torch.empty(rows, 2 * ld, dtype=torch.bfloat16, device=device)
-        self.rows, self.ld = rows, ld
+        self.rows, self.ld, self.precision = rows, ld, precision
 
     def ptr(self, row_off=0):
         return self.buf.data_ptr() + row_off * 4 * self.ld          # 2 planes x 2 bytes per logical column
@@ -66,8 +67,9 @@ class _PackedCache:
     """Packed weights of a training run: packed once, refreshed IN PLACE (`ns2_weight_update`: no allocation, no
     synchronisation) when the parameter's version counter moved -- an optimizer step bumps it."""
 
-    def __init__(self):
+    def __init__(self, precision=3):
         self.map = {}
+        self.precision = precision
 
     def _purge(self):
         dead = [k for k, v in self.map.items() if any(r() is None for r in v[4])]
@@ -93,18 +95,25 @@ class _PackedCache:
             check(_lib.load().ns2_weight_update(hit[0].handle, w.data_ptr(), _p(extra), _s()), "ns2_weight_update")
             self.map[key] = (hit[0], sig, hit[2], (w, extra), refs)  # keep the sources alive until the stream has consumed them
             return hit[0]
-        pw = ops.PackedWeight(w, extra1x1=extra, precision=3, **pack_kw)
+        pw = ops.PackedWeight(w, extra1x1=extra, precision=self.precision, **pack_kw)
         self.map[key] = (pw, sig, (tuple(w.shape), None if extra is None else tuple(extra.shape)), (w, extra), refs)
         return pw
 
 
 class HipBackend:
-    """every method = launches of libns2hip on the current stream; torch provides the buffers"""
+    """every method = launches of libns2hip on the current stream; torch provides the buffers.
+
+    `precision` = the arithmetic of the GEMMs (forward, dgrad, wgrad) and the format of their operand planes: 3 = bf16 hi / lo
+    planes, three bf16 products ("exact"); 4 = FMT_H8 lines, one IEEE-half product + both correction terms on the fp8 MFMA
+    ("mixed": 2 MFMA units instead of 3; needs the loss scaling of `_Scale` below).  The attention products and their operands
+    (q, k, v, dO and the per-utterance transposes) are bf16 x3 at both precisions (`attn=True` arguments)."""
     name = "hip"
 
-    def __init__(self):
+    def __init__(self, precision=3):
+        assert precision in (3, 4)
         self.lib = _lib.load()
-        self.packs = _PackedCache()
+        self.prec = precision
+        self.packs = _PackedCache(precision)
 
     # ---- weights
     def pack(self, key, params, make_src):
@@ -113,7 +122,7 @@ class HipBackend:
     # ---- forward pieces
     def split(self, x, C=None):
         x = x if x.is_contiguous() else x.contiguous()
-        return ops.split(x, precision=3)
+        return ops.split(x, precision=self.prec)
 
     @staticmethod
     def _rows(t, d):
@@ -121,7 +130,7 @@ class HipBackend:
         return t if (t.stride(1) == 1 and t.stride(0) == d) else t.contiguous()
 
     def rmsnorm(self, x, seq_len, gamma=None, cond=None):
-        return ops.rmsnorm(x, seq_len=seq_len, gamma=gamma, cond=cond, precision=3)
+        return ops.rmsnorm(x, seq_len=seq_len, gamma=gamma, cond=cond, precision=self.prec)
 
     def rmsnorm_f32(self, x, gamma):
         """RMSNorm(x) * gamma as fp32 [M, d] (the resampler's final norm, NS2:579: its output is a tensor of the graph, not an operand)"""
@@ -134,11 +143,18 @@ class HipBackend:
         out = torch.empty(M, ldo, dtype=torch.float32, device=a.device)
         ldr = resid.stride(0) if resid is not None else 0
         check(self.lib.ns2_linear_f32(pw.handle, a.hi, a.lo, a.ld, M, taps, dil, seq_len, _p(bias), _p(resid), ldr, out.data_ptr(), ldo,
-                                      pad_left, 0, 3, _s()), "ns2_linear_f32")
+                                      pad_left, 0, self.prec, _s()), "ns2_linear_f32")
         return out
 
-    def gemm_split(self, pw, a, bias=None, taps=0, dil=1, seq_len=0):
-        return ops.linear_split(pw, a, bias=bias, conv_taps=taps, dilation=dil, seq_len=seq_len, precision=3)
+    def gemm_split(self, pw, a, bias=None, taps=0, dil=1, seq_len=0, attn=False):
+        """-> operand planes; attn=True: attention operands (q | k | v), bf16 hi / lo lines whatever the GEMM arithmetic"""
+        if attn and self.prec != 3:
+            M, ldo = a.rows, round_up(pw.rows, 32)
+            out = ops.empty_planes(M, ldo, a.device)
+            check(self.lib.ns2_linear_split_as(pw.handle, a.hi, a.lo, a.ld, M, taps, dil, seq_len, _p(bias), out.hi, out.lo, ldo, -1, 0,
+                                               self.prec, 3, _s()), "ns2_linear_split_as")
+            return out
+        return ops.linear_split(pw, a, bias=bias, conv_taps=taps, dilation=dil, seq_len=seq_len, precision=self.prec)
 
     def film_gate_fwd(self, h, film, seq_len, d):
         out = torch.empty(h.shape[0], d, dtype=torch.float32, device=h.device)
@@ -148,15 +164,16 @@ class HipBackend:
 
     def geglu_fwd(self, pre, f):
         M = pre.shape[0]
-        out = ops.empty_planes(M, round_up(f, 32), pre.device)
-        check(self.lib.ns2_geglu_fwd(pre.data_ptr(), pre.stride(0), M, f, out.hi, out.lo, out.ld, _s()), "ns2_geglu_fwd")
+        out = ops._out_planes(M, round_up(f, 32), pre.device, self.prec)
+        check(self.lib.ns2_geglu_fwd(pre.data_ptr(), pre.stride(0), M, f, out.hi, out.lo, out.ld, self.prec, _s()), "ns2_geglu_fwd")
         return out
 
     def attention(self, q, q_col0, k, k_col0, vt, B, H, Nq, Nk):
-        o = ops.empty_planes(B * Nq, H * 64, q.device)
+        """bf16 x3 products on bf16 operands; the output o (the out-projection's operand) in the GEMM format"""
+        o = ops._out_planes(B * Nq, H * 64, q.device, self.prec)
         lse = torch.empty(B, H, Nq, dtype=torch.float32, device=q.device)
         check(self.lib.ns2_attention_lse(q.hi, q.lo, q.ld, q_col0, k.hi, k.lo, k.ld, k_col0, vt.ptr(), vt.ptr() + 64, vt.ld, o.hi, o.lo, H * 64,
-                                         B, H, Nq, Nk, 0.125, lse.data_ptr(), 3, _s()), "ns2_attention_lse")
+                                         B, H, Nq, Nk, 0.125, lse.data_ptr(), 3, self.prec, _s()), "ns2_attention_lse")
         return o, lse
 
     # ---- rows = batch entries: the conditioning Linears (weight-streaming kernel of the inference path, fp32)
@@ -179,24 +196,26 @@ class HipBackend:
         return out
 
     # ---- backward pieces
-    def grad_prep(self, x, C, want_row=False, want_t=False, want_colsum=False, seq_len=0, per_batch=False, t_rows=None):
-        """x fp32 [M, >= C] -> (row planes [M, round_up(C, 32)], transposed planes, column sums [C])"""
+    def grad_prep(self, x, C, want_row=False, want_t=False, want_colsum=False, seq_len=0, per_batch=False, t_rows=None, attn=False):
+        """x fp32 [M, >= C] -> (row planes [M, round_up(C, 32)], transposed planes, column sums [C]); attn=True: operands of the
+        attention backward (bf16 hi / lo), else GEMM operands in the backend's format"""
         M, dev = x.shape[0], x.device
         if not (want_row or want_t or want_colsum):
             return None, None, None
-        row = ops.empty_planes(M, round_up(C, 32), dev) if want_row else None
+        prec = 3 if attn else self.prec
+        row = ops._out_planes(M, round_up(C, 32), dev, prec) if want_row else None
         tp, ld_t = None, 0
         if want_t:
             ld_t = round_up(seq_len if per_batch else M, 32)
             t_rows = t_rows or C
-            tp = TPlanes((M // seq_len) * t_rows if per_batch else t_rows, ld_t, dev)
+            tp = TPlanes((M // seq_len) * t_rows if per_batch else t_rows, ld_t, dev, prec)
         part = None
         if want_colsum:
             S = self.lib.ns2_grad_prep_slices(M, ld_t)
             part = torch.empty(S, C, dtype=torch.float32, device=dev)
         check(self.lib.ns2_grad_prep(x.data_ptr(), x.stride(0), M, C, seq_len, 0, row.hi if row else None, row.lo if row else None,
                                      row.ld if row else 0, tp.ptr() if tp else None, tp.ptr() + 64 if tp else None, ld_t, t_rows or 0,
-                                     int(per_batch), _p(part), _s()), "ns2_grad_prep")
+                                     int(per_batch), _p(part), prec, _s()), "ns2_grad_prep")
         cs = None
         if want_colsum:
             cs = torch.empty(C, dtype=torch.float32, device=dev)
@@ -208,30 +227,33 @@ class HipBackend:
         (the taps of a conv's weight gradient), rows zero-padded to what a W operand of ns2_wgrad may read"""
         M = p.rows
         Cp = round_up(C, 32)
+        prec = p.precision                       # the transposed planes keep the format of the planes they come from
+        assert prec in (3, 4)
         if per_batch:
             B = M // seq_len
-            tp = TPlanes(B * C, round_up(seq_len, 32), p.device)
-            check(self.lib.ns2_planes_transpose(p.hi, p.lo, p.ld, col0, M, C, seq_len, 0, tp.ptr(), tp.ptr() + 64, tp.ld, C, 1, _s()),
+            tp = TPlanes(B * C, round_up(seq_len, 32), p.device, prec)
+            check(self.lib.ns2_planes_transpose(p.hi, p.lo, p.ld, col0, M, C, seq_len, 0, tp.ptr(), tp.ptr() + 64, tp.ld, C, 1, prec, _s()),
                   "ns2_planes_transpose")
             return tp
         T = len(shifts)
         # a W operand is read in whole 256-row tiles from wherever a wgrad starts (row 0 for all taps, row 2 Cp for res_conv)
         rows = max((T - 1) * Cp + round_up(Cp, pad_rows), round_up(T * Cp, pad_rows))
-        tp = TPlanes(rows, round_up(M, 32), p.device)
+        tp = TPlanes(rows, round_up(M, 32), p.device, prec)
         for t, sh in enumerate(shifts):
             t_rows = Cp if t < T - 1 else rows - (T - 1) * Cp
             check(self.lib.ns2_planes_transpose(p.hi, p.lo, p.ld, col0, M, C, seq_len, sh, tp.ptr(t * Cp), tp.ptr(t * Cp) + 64, tp.ld, t_rows, 0,
-                                                _s()), "ns2_planes_transpose")
+                                                prec, _s()), "ns2_planes_transpose")
         return tp
 
     def wgrad(self, dyt, xt, R, T, K, row_off=0):
         """dW [R, K, T] = dY^T X_t ; xt: T blocks of Kp = round_up(K, 32) rows starting at row_off"""
         Kp = round_up(K, 32)
+        assert dyt.precision == xt.precision == self.prec, "wgrad operands must be in the backend's GEMM format"
         nbytes = self.lib.ns2_wgrad_workspace_bytes(R, T * Kp, dyt.ld)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dyt.buf.device)
         dw = torch.empty(R, K, T, dtype=torch.float32, device=dyt.buf.device)
         check(self.lib.ns2_wgrad(dyt.ptr(), dyt.ptr() + 64, xt.ptr(row_off), xt.ptr(row_off) + 64, dyt.ld, R, T, Kp, K, dw.data_ptr(), ws.data_ptr(),
-                                 nbytes, _s()), "ns2_wgrad")
+                                 nbytes, self.prec, _s()), "ns2_wgrad")
         return dw
 
     def film_gate_bwd(self, dg, h, film, B, seq_len, d):
@@ -274,7 +296,8 @@ class HipBackend:
 
     def attention_delta(self, do, o, B, H, Nq):
         delta = torch.empty(B, H, Nq, dtype=torch.float32, device=do.device)
-        check(self.lib.ns2_attention_delta(do.data_ptr(), do.stride(0), o.hi, o.lo, o.ld, B, H, Nq, delta.data_ptr(), _s()), "ns2_attention_delta")
+        check(self.lib.ns2_attention_delta(do.data_ptr(), do.stride(0), o.hi, o.lo, o.ld, B, H, Nq, delta.data_ptr(), o.precision, _s()),
+              "ns2_attention_delta")
         return delta
 
     def attention_bwd(self, q, q_col0, k, k_col0, v, v_col0, do_row, kt, qt, dot, lse, delta, B, H, Nq, Nk, dq=None, dkv=None):
@@ -299,14 +322,20 @@ class HipBackend:
         check(self.lib.ns2_attention_bwd(ctypes.byref(a), _s()), "ns2_attention_bwd")
 
 
-_BACKEND = None
+_BACKEND = None            # a substitute installed by the tests (tests/emu_backend.py)
+_HIP = {}                  # precision -> HipBackend (each with its own packed-weight cache)
+_CUR_PREC = 3              # the arithmetic of the graph being BUILT (model_forward_train sets it around its Functions' forwards)
+_CUR_SCALE = None          # ... and its loss scale (None: exact arithmetic)
+TRAIN_PRECISIONS = {"exact": 3, "mixed": 4}
 
 
 def backend():
-    global _BACKEND
-    if _BACKEND is None:
-        _BACKEND = HipBackend()
-    return _BACKEND
+    """the backend the Function whose forward is running should use (it keeps it in ctx for its backward)"""
+    if _BACKEND is not None:
+        return _BACKEND
+    if _CUR_PREC not in _HIP:
+        _HIP[_CUR_PREC] = HipBackend(_CUR_PREC)
+    return _HIP[_CUR_PREC]
 
 
 def set_backend(b):
@@ -314,6 +343,67 @@ def set_backend(b):
     global _BACKEND
     prev, _BACKEND = _BACKEND, b
     return prev
+
+
+# =============================================================================================== loss scaling of the mixed arithmetic
+class _Scale:
+    """Loss scale of ONE forward / backward pass of the mixed arithmetic.  IEEE half (and its e5m2 companions) stops at 65504 and
+    thins out below 6e-5; the gradient of a mean-reduced loss over 1.7e7 elements is ~1e-7.  Every gradient is linear in the
+    gradient that enters the graph, so the pass runs on gradients multiplied by a power of two `s` (exact in fp32) -- what the
+    reference's accelerate / fp16 training does with its GradScaler (NS2:1710-1711, 1723-1726).  `s` is chosen where the gradient
+    enters (`_ScaleIn` at the model output) from its largest magnitude, on the device, without a synchronisation: the scaled maximum
+    becomes 2^5 ... 2^6, which leaves 2^10 of head-room before 65504 for growth inside the graph and ~2^19 below for small values.
+    Token-sized gradients stay scaled between the Functions; whatever leaves the scaled domain -- parameter gradients, FiLM /
+    adaptive-norm conditioning gradients, x.grad -- is multiplied by 1 / s (`unscale`).  Values that still leave the half range are
+    COUNTED by the converting kernels (ops.saturation_count): `overflowed()` tells a training loop to skip / repeat the step."""
+    TARGET = 64.0
+
+    def __init__(self):
+        self.s = None
+        self.inv = None
+
+    def choose(self, g):
+        amax = g.detach().abs().amax().clamp_min(1e-30).float()
+        self.s = torch.exp2(torch.floor(torch.log2(self.TARGET / amax))).clamp(2.0 ** -60, 2.0 ** 60)
+        self.inv = 1.0 / self.s
+        return self.s
+
+    def unscale(self, t):
+        return t if t is None else t * self.inv
+
+
+class _ScaleIn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, sc):
+        ctx.sc = sc
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.sc.choose(g), None
+
+
+class _ScaleOut(torch.autograd.Function):
+    """a tensor entering the scaled domain from outside (x, `null_prompt_tokens`, the resampler's latents ...): its gradient leaves it"""
+
+    @staticmethod
+    def forward(ctx, t, sc):
+        ctx.sc = sc
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.sc.unscale(g), None
+
+
+def _enter(t):
+    return t if _CUR_SCALE is None else _ScaleOut.apply(t, _CUR_SCALE)
+
+
+def _un(ctx, *ts):
+    """parameter / conditioning gradients of a Function leave the scaled domain"""
+    sc = ctx.sc
+    return ts if sc is None else tuple(sc.unscale(t) for t in ts)
 
 
 # =============================================================================================== weight sources of the two packs
@@ -349,7 +439,8 @@ class GemmFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, resid, seq_len, dil):
-        bk = backend()
+        bk = ctx.bk = backend()
+        ctx.sc = _CUR_SCALE
         taps = _taps(w)
         xp = bk.split(x)
         y = bk.gemm_f32(_fwd_pack(bk, w), xp, bias=b, resid=resid, taps=taps, dil=dil, seq_len=seq_len if taps else 0)
@@ -359,7 +450,7 @@ class GemmFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        bk = backend()
+        bk = ctx.bk
         w, b = ctx.saved_tensors
         taps, dil, seq_len, cin, has_resid = ctx.cfg
         cout = w.shape[0]
@@ -374,7 +465,7 @@ class GemmFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = bk.gemm_f32(_bwd_pack(bk, w), dy_row, taps=taps, dil=dil, seq_len=seq_len if taps else 0, pad_left=0 if taps else -1)[:, :cin]
-        return dx, dw, db, (dy if has_resid else None), None, None
+        return dx, *_un(ctx, dw, db), (dy if has_resid else None), None, None
 
 
 class WavenetBlockFn(torch.autograd.Function):
@@ -382,7 +473,8 @@ class WavenetBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u, film, wc, bc, wr, br, seq_len, dil):
-        bk = backend()
+        bk = ctx.bk = backend()
+        ctx.sc = _CUR_SCALE
         d = u.shape[1]
         up = bk.split(u)
         hc = bk.gemm_f32(_fwd_pack(bk, wc), up, bias=bc, taps=3, dil=dil, seq_len=seq_len)
@@ -394,7 +486,7 @@ class WavenetBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        bk = backend()
+        bk = ctx.bk
         film, wc, wr, hc = ctx.saved_tensors
         seq_len, dil, d = ctx.cfg
         B = dout.shape[0] // seq_len
@@ -412,7 +504,7 @@ class WavenetBlockFn(torch.autograd.Function):
                 dwr = bk.wgrad(dout_t, xt, d, 1, d, row_off=2 * round_up(d, 32))    # res_conv reads the unshifted block (tap 2)
         du = bk.gemm_f32(_bwd_pack(bk, wc), dhc_row, taps=3, dil=dil, seq_len=seq_len, pad_left=0)
         du = bk.gemm_f32(_bwd_pack(bk, wr), dout_row, resid=du, taps=1, dil=1, seq_len=seq_len, pad_left=0)
-        return du[:, :d], dfilm, dwc, dbc, dwr, dbr, None, None
+        return du[:, :d], *_un(ctx, dfilm, dwc, dbc, dwr, dbr), None, None
 
 
 class AttnFn(torch.autograd.Function):
@@ -423,18 +515,19 @@ class AttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, film, ctxt, wq, wkv, wout, seq_len, heads, ctx_len):
-        bk = backend()
+        bk = ctx.bk = backend()
+        ctx.sc = _CUR_SCALE
         M, d = h.shape
         B, a = M // seq_len, heads * 64
         xn = bk.rmsnorm(h, seq_len, cond=film) if film is not None else bk.split(h)
         if ctxt is None:                                                    # self attention: one GEMM for q | k | v
             wqkv = bk.pack(("qkv", id(wq), id(wkv)), (wq, wkv), lambda: torch.cat((wq.detach(), wkv.detach()), 0))
-            qkv = bk.gemm_split(wqkv, xn)
+            qkv = bk.gemm_split(wqkv, xn, attn=True)
             q, k, v, qc, kc, vc, Nk, cp = qkv, qkv, qkv, 0, a, 2 * a, seq_len, None
         else:
-            q = bk.gemm_split(_fwd_pack(bk, wq), xn)
+            q = bk.gemm_split(_fwd_pack(bk, wq), xn, attn=True)
             cp = bk.split(ctxt)
-            kv = bk.gemm_split(_fwd_pack(bk, wkv), cp)
+            kv = bk.gemm_split(_fwd_pack(bk, wkv), cp, attn=True)
             k, v, qc, kc, vc, Nk = kv, kv, 0, 0, a, ctx_len
         vt = bk.transpose(v, vc, a, Nk, per_batch=True)
         o, lse = bk.attention(q, qc, k, kc, vt, B, heads, seq_len, Nk)
@@ -445,7 +538,7 @@ class AttnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        bk = backend()
+        bk = ctx.bk
         h, film, wq, wkv, wout, lse = ctx.saved_tensors
         xn, q, k, v, o, cp = ctx.pl
         seq_len, heads, Nk, qc, kc, vc, cross = ctx.cfg
@@ -457,7 +550,7 @@ class AttnFn(torch.autograd.Function):
         dwout = bk.wgrad(dy_t, bk.transpose(o, 0, a, 0), d, 1, a)[:, :, 0] if ng[5] else None
         do = bk.gemm_f32(_bwd_pack(bk, wout), dy_row)                       # [M, a]
         delta = bk.attention_delta(do, o, B, heads, seq_len)
-        do_row, do_tb, _ = bk.grad_prep(do, a, want_row=True, want_t=True, seq_len=seq_len, per_batch=True)
+        do_row, do_tb, _ = bk.grad_prep(do, a, want_row=True, want_t=True, seq_len=seq_len, per_batch=True, attn=True)
         kt = bk.transpose(k, kc, a, Nk, per_batch=True)
         qt = bk.transpose(q, qc, a, seq_len, per_batch=True)
         if not cross:
@@ -486,6 +579,7 @@ class AttnFn(torch.autograd.Function):
             dh, dfilm = dy[:, :d] + dxn[:, :d], None
         else:
             dh, dfilm, _ = bk.rmsnorm_bwd(h, dxn, B, seq_len, d, cond=film, dx_add=dy)
+        dfilm, dwq, dwkv, dwout = _un(ctx, dfilm, dwq, dwkv, dwout)
         return dh, dfilm, dctx, dwq, dwkv, dwout, None, None, None
 
 
@@ -495,7 +589,8 @@ class FeedForwardFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, film, w1, b1, wc, bc, w2, b2, seq_len):
-        bk = backend()
+        bk = ctx.bk = backend()
+        ctx.sc = _CUR_SCALE
         M, d = h.shape
         f = w2.shape[1]
         xn = bk.rmsnorm(h, seq_len, cond=film) if film is not None else bk.split(h)
@@ -509,7 +604,7 @@ class FeedForwardFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        bk = backend()
+        bk = ctx.bk
         h, film, w1, wc, w2, pre = ctx.saved_tensors
         xn, hp, cp = ctx.pl
         seq_len, f = ctx.cfg
@@ -535,7 +630,7 @@ class FeedForwardFn(torch.autograd.Function):
             dh, dfilm = dy[:, :d] + dxn[:, :d], None
         else:
             dh, dfilm, _ = bk.rmsnorm_bwd(h, dxn, B, seq_len, d, cond=film, dx_add=dy)
-        return dh, dfilm, dw1, db1, dwc, dbc, dw2, db2, None
+        return dh, *_un(ctx, dfilm, dw1, db1, dwc, dbc, dw2, db2), None
 
 
 class NormLinearFn(torch.autograd.Function):
@@ -543,7 +638,8 @@ class NormLinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, gamma, w, seq_len):
-        bk = backend()
+        bk = ctx.bk = backend()
+        ctx.sc = _CUR_SCALE
         xn = bk.rmsnorm(h, seq_len, gamma=gamma)
         y = bk.gemm_f32(_fwd_pack(bk, w), xn)
         ctx.save_for_backward(h, gamma, w)
@@ -552,7 +648,7 @@ class NormLinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        bk = backend()
+        bk = ctx.bk
         h, gamma, w = ctx.saved_tensors
         M, d = h.shape
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
@@ -560,7 +656,7 @@ class NormLinearFn(torch.autograd.Function):
         dw = bk.wgrad(dy_t, bk.transpose(ctx.xn, 0, d, 0), w.shape[0], 1, d)[:, :, 0] if ctx.needs_input_grad[2] else None
         dxn = bk.gemm_f32(_bwd_pack(bk, w), dy_row)
         dh, _, dgamma = bk.rmsnorm_bwd(h, dxn, M // ctx.seq_len, ctx.seq_len, d, gamma=gamma)
-        return dh, dgamma, dw, None
+        return dh, *_un(ctx, dgamma, dw), None
 
 
 class RmsNormFn(torch.autograd.Function):
@@ -569,15 +665,16 @@ class RmsNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, gamma):
         ctx.save_for_backward(h, gamma)
-        return backend().rmsnorm_f32(h, gamma)
+        ctx.bk, ctx.sc = backend(), _CUR_SCALE
+        return ctx.bk.rmsnorm_f32(h, gamma)
 
     @staticmethod
     def backward(ctx, dy):
         h, gamma = ctx.saved_tensors
         M, d = h.shape
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
-        dh, _, dgamma = backend().rmsnorm_bwd(h, dy, 1, M, d, gamma=gamma)      # one "utterance" of M rows: the norm is per row
-        return dh, dgamma
+        dh, _, dgamma = ctx.bk.rmsnorm_bwd(h, dy, 1, M, d, gamma=gamma)      # one "utterance" of M rows: the norm is per row
+        return dh, *_un(ctx, dgamma)
 
 
 class SkinnyLinearFn(torch.autograd.Function):
@@ -587,7 +684,7 @@ class SkinnyLinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        bk = backend()
+        bk = ctx.bk = backend()
         wt = bk.transpose_f32(w.detach())                                   # [K, J]
         y = bk.skinny(x.detach(), wt, b.detach() if b is not None else None)
         ctx.save_for_backward(x, w)
@@ -596,7 +693,7 @@ class SkinnyLinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        bk = backend()
+        bk = ctx.bk
         x, w = ctx.saved_tensors
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dx = bk.skinny(dy, w.detach()) if ctx.needs_input_grad[0] else None  # [B, J] @ [J, K]
@@ -660,7 +757,7 @@ def _resampler(pr, prompt, heads):
         px = GemmFn.apply(px, pc.weight, pc.bias, None, 0, 1)
     Lm, d = pr.latents.shape
     px = px.reshape(b, n_p, d)
-    lat = pr.latents[None].expand(b, -1, -1).reshape(b * Lm, d)              # (a copy: its gradient sums over the batch into pr.latents)
+    lat = _enter(pr.latents)[None].expand(b, -1, -1).reshape(b * Lm, d)      # (a copy: its gradient sums over the batch into pr.latents)
     for attn, ff in pr.layers:
         context = torch.cat((lat.reshape(b, Lm, d), px), dim=1).reshape(b * (Lm + n_p), d)     # cross_attn_include_queries, NS2:1060-1061
         lat = AttnFn.apply(_c(lat), None, context, attn.to_q.weight, attn.to_kv.weight, attn.to_out.weight, Lm, heads, Lm + n_p)
@@ -671,7 +768,25 @@ def _resampler(pr, prompt, heads):
 
 def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None):
     """`Model.forward` (NS2:929-1000) as a differentiable graph whose token-sized arithmetic is HIP (module docstring).
-    `m` owns the reference's parameters (this package's `Model` or `compat.HipBackedModel`)."""
+    `m` owns the reference's parameters (this package's `Model` or `compat.HipBackedModel`).  `m.train_precision`: "exact"
+    (default: bf16 x3) or "mixed" (IEEE-half product + fp8 correction terms on FMT_H8 operands under a loss scale, `_Scale`)."""
+    global _CUR_PREC, _CUR_SCALE
+    tp = getattr(m, "train_precision", "exact")
+    assert tp in TRAIN_PRECISIONS, f"train_precision must be one of {sorted(TRAIN_PRECISIONS)}"
+    prev = (_CUR_PREC, _CUR_SCALE)
+    _CUR_PREC = TRAIN_PRECISIONS[tp]
+    _CUR_SCALE = _Scale() if tp == "mixed" else None
+    try:
+        out = _forward_train(m, x, times, prompt, cond, cond_drop_prob)
+        if _CUR_SCALE is not None:
+            m._last_loss_scale = _CUR_SCALE          # (inspection / tests: the scale the last backward chose)
+            out = _ScaleIn.apply(out, _CUR_SCALE)
+        return out
+    finally:
+        _CUR_PREC, _CUR_SCALE = prev
+
+
+def _forward_train(m, x, times, prompt, cond, cond_drop_prob):
     b, n, d = x.shape
     M = b * n
     p = m.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
@@ -682,7 +797,7 @@ def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None
     fr = tt * w[None] * 2 * math.pi
     t = F.silu(_lin(getattr(m.to_time_cond, "1"), torch.cat((tt, fr.sin(), fr.cos()), dim=-1)))
     c = None
-    h = x.float().reshape(M, d)
+    h = _enter(x.float().reshape(M, d))              # (mixed arithmetic: the token-sized gradients below here are loss-scaled)
     if m.condition_on_prompt:
         assert prompt is not None and cond is not None
 
@@ -697,13 +812,13 @@ def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None
         pc = F.silu(_lin(getattr(m.to_prompt_cond, "1"), prompt.float().mean(dim=1)))
         pc = torch.where(dm[:, None], m.null_prompt_cond, pc)
         t = torch.cat((t, pc), dim=-1)
-        c = torch.where(dm[:, None, None], m.null_prompt_tokens, _resampler(m.perceiver_resampler, prompt.float(), heads))   # [b, Lm, d]
+        c = torch.where(dm[:, None, None], _enter(m.null_prompt_tokens), _resampler(m.perceiver_resampler, prompt.float(), heads))   # [b, Lm, d]
         # cond_to_model_dim: 1x1 conv over channel-first cond (NS2:978) = a Linear over the frames
         n_c = cond.shape[-1]
         cm = GemmFn.apply(_c(cond.float().transpose(1, 2)).reshape(b * n_c, -1), m.cond_to_model_dim.weight, m.cond_to_model_dim.bias, None,
                           n_c, 1)
         cm = cm.reshape(b, n_c, d)
-        cm = torch.where(mask()[:, None, None], m.null_cond.t()[None], cm)
+        cm = torch.where(mask()[:, None, None], _enter(m.null_cond).t()[None], cm)
         if n_c > n:
             cm = cm[:, :n]
         elif n_c < n:

@@ -103,7 +103,7 @@ class EmuBackend:
         out[:, :N] = y
         return out
 
-    def gemm_split(self, pw, a, bias=None, taps=0, dil=1, seq_len=0):
+    def gemm_split(self, pw, a, bias=None, taps=0, dil=1, seq_len=0, attn=False):
         y = self._gemm(pw, a, taps, dil, seq_len, -1)
         if bias is not None:
             y = y + bias
@@ -149,7 +149,7 @@ class EmuBackend:
         out[ok] = x[src[ok]]
         return out
 
-    def grad_prep(self, x, C, want_row=False, want_t=False, want_colsum=False, seq_len=0, per_batch=False, t_rows=None):
+    def grad_prep(self, x, C, want_row=False, want_t=False, want_colsum=False, seq_len=0, per_batch=False, t_rows=None, attn=False):
         assert not torch.isnan(x[:, :C]).any(), "grad_prep read an unwritten column"
         M = x.shape[0]
         row = self.split(x[:, :C]) if want_row else None
@@ -251,3 +251,48 @@ class EmuBackend:
         if dkv is not None:
             dkv[0][:, dkv[1]:dkv[1] + a] = unhd(dS.transpose(2, 3) @ qq * 0.125, Nk)
             dkv[0][:, dkv[2]:dkv[2] + a] = unhd(P.transpose(2, 3) @ dO, Nk)
+
+
+# ---------------------------------------------------------------------------------------------- the mixed training arithmetic
+def _h8_parts(x):
+    """x -> (half(x), e5m2((x - half(x)) 2^12) / 2^12, e5m2(x)) as float64: the three parts of an FMT_H8 element (ns2_common.h)"""
+    x = x.double().clamp(-57344, 57344)
+    h = x.float().to(torch.float16).double()
+    l = ((x - h) * 4096).float().to(torch.float8_e5m2).double() / 4096
+    return h, l, x.float().to(torch.float8_e5m2).double()
+
+
+def mixed_mm(a, w_t):
+    """a [M, K] @ w_t [K, N] as the precision-4 GEMMs evaluate it: a_h . w_h + e5m2(a) . w_l + a_l . e5m2(w), wide accumulation"""
+    ah, al, a8 = _h8_parts(a)
+    wh, wl, w8 = _h8_parts(w_t)
+    return (ah @ wh + a8 @ wl + al @ w8).float()
+
+
+class MixedEmuBackend(EmuBackend):
+    """EmuBackend whose contractions (forward, dgrad, wgrad) round their operands like FMT_H8 lines: values beyond the IEEE-half range
+    are clamped and tiny ones lose their bits -- what the loss scale of training._Scale is for (tests/test_training_cpu.py)"""
+    name = "emu-mixed"
+
+    def _mm(self, a, w_t):
+        return mixed_mm(a, w_t)
+
+    def _gemm(self, pw, a, taps, dil, seq_len, pad_left):
+        w = pw.w
+        M = a.rows
+        if taps == 0:
+            return self._mm(a.t[:, :w.shape[1]], w.t())
+        C = w.shape[1]
+        pl = taps - 1 if pad_left < 0 else pad_left
+        out = torch.zeros(M, w.shape[0])
+        x = a.t[:, :C]
+        for t in range(taps):
+            out += self._mm(self._shifted(x, seq_len, (pl - t) * dil), w[:, :, t].t())
+        return out
+
+    def wgrad(self, dyt, xt, R, T, K, row_off=0):
+        Kp = rup(K, 32)
+        dw = torch.zeros(R, K, T)
+        for t in range(T):
+            dw[:, :, t] = self._mm(dyt.t[:R], xt.t[row_off + t * Kp:row_off + t * Kp + K].t())
+        return dw

@@ -97,3 +97,139 @@ def test_frozen_model_returns_dx_without_weight_gradients():
     _, dx_frozen, g_frozen = _grads(m, m, x, t)
     assert all(g is None for g in g_frozen.values())
     assert torch.equal(dx_all, dx_frozen)               # the same kernels in the same order produce dL/dx
+
+
+# ------------------------------------------------------------------------------------------------ the mixed training arithmetic
+# (VERDICT r4 missing #2 / item 3c: the reference trains under accelerate's fp16 mixed precision, NS2:1710-1711; train_precision="mixed"
+# runs the GEMMs of forward, dgrad and wgrad as one IEEE-half product + fp8 correction terms on FMT_H8 operands under a loss scale)
+from naturalspeech2_pytorch_amd import ops, training  # noqa: E402
+from tests.emu_backend import EP, EmuBackend, mixed_mm, rup  # noqa: E402
+
+HB4 = training.HipBackend(4)
+EB = EmuBackend()
+
+
+def pjoin(p):
+    return ops.join(p).cpu()
+
+
+def tjoin(tp):
+    return ops.join(ops.Planes(tp.buf, tp.rows, tp.ld, True, "h8" if tp.precision == 4 else "bf16")).cpu()
+
+
+@pytest.mark.parametrize("M,C,seq_len", [(256, 64, 64), (200, 72, 40), (1024, 1365, 256), (96, 512, 96)])
+def test_mixed_grad_prep_writes_h8_rows_and_their_exact_transposition(M, C, seq_len):
+    x = make_input("gp", (M, C), seed=1) * 3.0
+    ld = rup(C, 4) + 4
+    xp = torch.full((M, ld), float("nan"))
+    xp[:, :C] = x
+    row, tp, cs = HB4.grad_prep(xp.to(DEV), C, want_row=True, want_t=True, want_colsum=True, t_rows=rup(C, 256))
+    assert row.fmt == "h8" and tp.precision == 4
+    rj, tj = pjoin(row), tjoin(tp)
+    assert rel(rj[:, :C], x) < 1e-4 and float(rj[:, C:].abs().max()) == 0.0               # half + e5m2 remainder: ~2^-14 per element
+    assert tj.shape == (rup(C, 256), rup(M, 32))
+    assert torch.equal(tj[:C, :M], rj[:, :C].t())                                          # the SAME three parts, transposed: exact
+    assert float(tj[C:].abs().max()) == 0.0 and float(tj[:, M:].abs().max()) == 0.0
+    assert rel(cs.cpu(), x.sum(0)) < 1e-5
+    if C % 8 == 0:                                                                         # attention operands stay bf16 hi / lo
+        r2, t2, _ = HB4.grad_prep(xp.to(DEV), C, want_row=True, want_t=True, seq_len=seq_len, per_batch=True, attn=True)
+        assert r2.fmt == "bf16" and t2.precision == 3 and rel(pjoin(r2)[:, :C], x) < 1e-5
+
+
+@pytest.mark.parametrize("M,C,seq_len,shifts", [(256, 64, 64, (2, 1, 0)), (240, 96, 40, (8, 4, 0)), (512, 1376, 256, (2, 1, 0)),
+                                               (2048, 128, 1024, (256, 128, 0)), (192, 64, 0, (0,))])
+def test_mixed_planes_transpose_moves_h8_lines_exactly(M, C, seq_len, shifts):
+    x = make_input("pt", (M, C + 32), seed=2)
+    p = HB4.split(x.to(DEV))
+    assert p.fmt == "h8"
+    xr = pjoin(p)
+    tp = HB4.transpose(p, 32, C, seq_len, shifts)
+    et = EB.transpose(EP(xr), 32, C, seq_len, shifts)
+    tj = tjoin(tp)
+    assert tj.shape == et.t.shape and torch.equal(tj, et.t)
+
+
+@pytest.mark.parametrize("R,K,T,M", [(512, 512, 1, 4096), (64, 64, 3, 480), (1365, 1365, 3, 2048), (1536, 512, 1, 32768)])
+def test_mixed_wgrad(R, K, T, M):
+    dy = make_input("wg_dy", (M, R), seed=3) * 0.5
+    x = make_input("wg_x", (M, rup(K, 32)), seed=4)
+    x[:, K:] = 0
+    seq = M // 2 if T > 1 else 0
+    shifts = tuple((T - 1 - t) * 2 for t in range(T))
+    _, dyt, _ = HB4.grad_prep(dy.to(DEV), R, want_t=True)
+    xt = HB4.transpose(HB4.split(x.to(DEV)), 0, rup(K, 32), seq, shifts)
+    dw = HB4.wgrad(dyt, xt, R, T, K).cpu()
+    _, edyt, _ = EB.grad_prep(dy, R, want_t=True)
+    ext = EB.transpose(EP(x), 0, rup(K, 32), seq, shifts)
+    ref = EB.wgrad(edyt, ext, R, T, K)
+    assert dw.shape == (R, K, T) and rel(dw, ref) < 1e-4, rel(dw, ref)
+    assert torch.equal(dw, HB4.wgrad(dyt, xt, R, T, K).cpu())
+
+
+def test_mixed_attention_output_and_qkv_formats():
+    """the attention stays bf16 x3 on bf16 operands (written by the precision-4 q | k | v GEMM through ns2_linear_split_as); its
+    output is the FMT_H8 operand of the out-projection, and delta reads it back"""
+    B, H, N, d = 2, 8, 256, 512
+    a = H * 64
+    xn = HB4.split((make_input("xa", (B * N, d), seed=5)).to(DEV))
+    w = torch.nn.Parameter((make_input("wa", (3 * a, d), seed=6) * d ** -0.5).to(DEV))
+    pw = HB4.pack(("t", id(w)), (w,), lambda: w)
+    qkv = HB4.gemm_split(pw, xn, attn=True)
+    assert qkv.fmt == "bf16" and qkv.has_lo
+    ref = mixed_mm(pjoin(xn), w.detach().cpu().t())
+    assert rel(pjoin(qkv), ref) < 2e-5
+    vt = HB4.transpose(qkv, 2 * a, a, N, per_batch=True)
+    o, lse = HB4.attention(qkv, 0, qkv, a, vt, B, H, N, N)
+    assert o.fmt == "h8"
+    qr = pjoin(qkv)
+    eo, else_ = EB.attention(EP(qr[:, :a].clone()), 0, EP(qr[:, a:2 * a].clone()), 0, EB.transpose(EP(qr[:, 2 * a:].clone()), 0, a, N, per_batch=True),
+                             B, H, N, N)
+    assert rel(pjoin(o), eo.t) < 1e-4 and (lse.cpu() - else_).abs().max() < 1e-4
+    do = make_input("do", (B * N, a), seed=7)
+    delta = HB4.attention_delta(do.to(DEV), o, B, H, N)
+    assert rel(delta.cpu(), EB.attention_delta(do, EP(pjoin(o)), B, H, N)) < 1e-5
+
+
+@needs_ref
+@pytest.mark.parametrize("tag,kw,b,n", [("d128_L6_b4_n1024", dict(dim=128, depth=6), 4, 1024), ("d512_L12_b2_n512", dict(dim=512, depth=12), 2, 512),
+                                       ("d64_L2_b3_n200", dict(dim=64, depth=2), 3, 200)])
+def test_every_gradient_in_the_mixed_training_arithmetic_matches_the_reference_autograd(tag, kw, b, n):
+    """train_precision="mixed" against the reference's own fp32 autograd, every parameter and x, with an upstream gradient of the
+    magnitude a mean-reduced loss produces (1e-7 per element: unusable in IEEE half without the loss scale)"""
+    from naturalspeech2_pytorch_amd.ops import saturation_count
+    ns2 = load_reference()
+    m = Model(**kw, precision="hybrid")
+    sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=61)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    m.train_precision = "mixed"
+    ref = ns2.Model(**kw)
+    ref.load_state_dict(sd)
+    ref = ref.to(DEV).train()
+    x = make_input("x", (b, n, kw["dim"]), seed=62).to(DEV)
+    t = make_input("times", (b,), seed=62, uniform=True).to(DEV)
+
+    def grads(mod):
+        for p in mod.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        y = mod(xx, t)
+        (y * make_input("gw", tuple(y.shape), seed=11).to(DEV) * 1e-7).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach(), xx.grad.clone(), {k: p.grad.clone() for k, p in mod.named_parameters()}
+
+    sat0 = saturation_count(reset=False, device=DEV)
+    y1, dx1, g1 = grads(m)
+    assert saturation_count(reset=False, device=DEV) == sat0, "a value left the IEEE-half range under the chosen loss scale"
+    y0, dx0, g0 = grads(ref)
+    errs = {k: rel(g1[k], g0[k]) for k in g0}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    rec = dict(n_tensors=len(errs), worst_param=worst[0], worst_rel=worst[1], x_grad_rel=rel(dx1, dx0), out_rel=rel(y1, y0),
+               median_rel=sorted(errs.values())[len(errs) // 2], loss_scale=float(m._last_loss_scale.s))
+    record(f"backward_vs_reference_autograd/mixed/{tag}", rec)
+    print(tag, rec)
+    assert rec["out_rel"] < 2.5e-4 and rec["x_grad_rel"] < 1e-3, rec
+    bad = {k: e for k, e in errs.items() if not e < 1e-3}
+    assert not bad, bad
+    _, dx2, g2 = grads(m)                                  # deterministic also here: fixed slots, and the scale is a function of the input
+    assert torch.equal(dx1, dx2) and all(torch.equal(g1[k], g2[k]) for k in g1)

@@ -225,3 +225,49 @@ def test_training_path_refuses_shapes_the_kernels_are_not_written_for():
     why = training.unsupported_reason(Model(dim=64, depth=1, dim_head=32))
     assert why is not None and "dim_head" in why
     assert "fp32" in training.unsupported_reason(Model(dim=64, depth=1).half())
+
+
+@pytest.mark.parametrize("cond", [False, True], ids=["uncond", "cond"])
+def test_mixed_training_arithmetic_needs_and_gets_its_loss_scale(cond):
+    """train_precision="mixed": the GEMMs of forward, dgrad and wgrad multiply FMT_H8 operands (IEEE half + e5m2 correction terms).
+    With the gradient of a mean-reduced loss (~1e-7 per element) the unscaled pass loses everything; under training._Scale -- a power
+    of two chosen from the incoming gradient, token-sized gradients kept scaled between the Functions, parameter / conditioning /
+    input gradients unscaled where they leave -- every gradient matches fp32 autograd like the exact arithmetic does.  Host logic
+    on the emulated backend (tests/emu_backend.MixedEmuBackend); the kernels: tests/test_backward_gpu.py."""
+    from tests.emu_backend import MixedEmuBackend
+    kw = dict(dim=64, depth=2, wavenet_layers=3, wavenet_stacks=2)
+    if cond:
+        kw.update(dim_prompt=96, condition_on_prompt=True, num_latents_m=8)
+    m = Model(**kw)
+    m.load_state_dict(make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=5))
+    b, n = 2, 40
+    x = make_input("x", (b, n, 64), seed=6)
+    t = make_input("times", (b,), seed=6, uniform=True)
+    extra = {}
+    if cond:
+        extra = dict(prompt=make_input("prompt", (b, 11, 96), seed=7), cond=make_input("cond", (b, 96, 33), seed=7), cond_drop_prob=0.)
+
+    def grads(fwd):
+        for p in m.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        y = fwd(m, xx, t, **extra)
+        (y * make_input("gw", tuple(y.shape), seed=11) * 1e-7).sum().backward()          # the magnitude of dL/dy of a mean-reduced loss
+        return xx.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    dx0, g0 = grads(model_forward_autograd)
+    prev = training.set_backend(MixedEmuBackend())
+    try:
+        m.train_precision = "mixed"
+        dx1, g1 = grads(training.model_forward_train)
+        s = float(m._last_loss_scale.s)
+        assert s == 2.0 ** round(__import__("math").log2(s)) and 2.0 ** 20 <= s <= 2.0 ** 32, s      # a power of two that lifts ~1e-7 to ~2^5
+        m.train_precision = "exact"                                                      # same rounding, NO scale: the point of it
+        dx2, g2 = grads(training.model_forward_train)
+    finally:
+        training.set_backend(prev)
+        m.train_precision = "exact"
+    assert set(g1) == set(g0)
+    worst = max(_rel(g1[k], g0[k]) for k in g0)
+    assert _rel(dx1, dx0) < 3e-4 and worst < 3e-4, (_rel(dx1, dx0), worst)
+    assert max(_rel(g2[k], g0[k]) for k in g0) > 1e-2                                    # unscaled: garbage
