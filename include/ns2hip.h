@@ -21,7 +21,8 @@
  *     (ns2_*_workspace_bytes), constants live in per-device __device__ storage, so one host thread per device (or one
  *     process per device) may drive several devices concurrently, also under stream capture.  What it does keep, all of it
  *     write-once or atomic: per-device "attribute raised" / occupancy answers, the environment switches NS2_GEMM,
- *     NS2_LSTM_PERSISTENT and NS2_LSTM_FUSED (read once per process), and the test hooks ns2_debug_*.  One thread-local
+ *     NS2_COL_GROUP (0: column-tile-fastest order for every product of the 256 x 256 kernel; A/B), NS2_LSTM_PERSISTENT and
+ *     NS2_LSTM_FUSED (read once per process), and the test hooks ns2_debug_*.  One thread-local
  *     pointer exists for the duration of a ns2_model_forward* / ns2_model_prepare_cond call: the split-K region of the
  *     workspace that call was given (set on entry, restored on return).
  *   - layout of a split-plane matrix (x_hi, x_lo, ld): `ld` is the LOGICAL column count, a multiple of 32.

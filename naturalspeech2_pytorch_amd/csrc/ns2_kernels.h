@@ -80,6 +80,10 @@ struct GemmArgs {
   // one slice covers (slice z: input columns [z * ksplit * 32, ...) of each tap); 0 = the plain launch.
   float* sk_ws; long sk_ws_floats;
   int ksplit;
+  // gemm2.hip, set by launch_gemm: 0 = column tile fastest (the workgroups an XCD runs together = a few row tiles x ALL column
+  // tiles: right while the W rows of all column tiles fit the XCD's 4 MiB L2); > 0 = column groups of this width: an XCD runs
+  // 32 / width row tiles x `width` column tiles together and keeps that W slice in its L2 for a whole pass over its row tiles
+  int col_group;
 };
 
 // precision: 3 = bf16 x3 ("exact"), 1 = bf16 ("fast"), 2 = one IEEE-half product ("half"), 4 = half product + both

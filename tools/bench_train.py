@@ -16,7 +16,7 @@ SHAPES = {"d128": (dict(dim=128, depth=6), 4, 1024, 26.74e9), "d128_b32": (dict(
           "d512": (dict(dim=512, depth=12), 32, 1024, 316.37e9), "d512_b8": (dict(dim=512, depth=12), 8, 1024, 316.37e9)}
 
 
-def run(name, backend, iters, warm=2, opt_step=True, train_precision="exact", fused_adam=False, graph=False):
+def run(name, backend, iters, warm=2, opt_step=True, train_precision="exact", fused_adam=False):
     kw, b, n, gflop_utt = SHAPES[name]
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -24,9 +24,8 @@ def run(name, backend, iters, warm=2, opt_step=True, train_precision="exact", fu
     m.train_backend = backend
     m.train_precision = train_precision
     d = NaturalSpeech2(m, codec=None, target_sample_hz=24000).to(dev)
-    # fused=True: PyTorch's single-pass Adam (the default "foreach" form makes ~6 passes over parameters and states);
-    # capturable=True: needed to replay the optimizer from a HIP graph
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=fused_adam or None, capturable=graph)
+    # fused=True: PyTorch's single-pass Adam (the default "foreach" form makes ~6 passes over parameters and states)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=fused_adam or None)
     g = torch.Generator(device="cpu").manual_seed(1)
     audio = torch.randn(b, n, kw["dim"], generator=g).to(dev)
     times = torch.rand(b, generator=g).to(dev)
@@ -43,36 +42,13 @@ def run(name, backend, iters, warm=2, opt_step=True, train_precision="exact", fu
     for _ in range(warm):
         loss = step()
     torch.cuda.synchronize()
-    if graph:
-        # the whole step -- loss, backward through the HIP Functions, optimizer -- as ONE HIP graph: every launch of the path is
-        # stream-ordered and allocation-free on the library side, torch's allocator serves the Functions' tensors from the graph's
-        # private pool.  For host-bound shapes (Model(dim=128): ~2500 launches per step).
-        def gstep():
-            opt.zero_grad(set_to_none=False)
-            l = d(audio, times=times, noise=noise)
-            l.backward()
-            if opt_step:
-                opt.step()
-            return l
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                gstep()
-        torch.cuda.current_stream().wait_stream(side)
-        cg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cg):
-            loss = gstep()
-        step = lambda: (cg.replay(), loss)[1]              # noqa: E731
-        step()
-        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
         loss = step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
     flops = 3 * gflop_utt * b * n / 1024
-    return dict(shape=name, backend=backend, train_precision=train_precision, fused_adam=fused_adam, graph=graph, batch=b, frames=n, ms_per_step=ms,
+    return dict(shape=name, backend=backend, train_precision=train_precision, fused_adam=fused_adam, batch=b, frames=n, ms_per_step=ms,
                 loss=float(loss), algorithmic_tflops=flops / (ms * 1e-3) / 1e12, peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30)
 
 
@@ -83,7 +59,6 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--train-precision", default="exact", help="comma separated: exact (bf16 x3), mixed (half product + fp8 terms, loss-scaled)")
     ap.add_argument("--fused-adam", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the whole step from a HIP graph")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     res = []
@@ -92,7 +67,7 @@ if __name__ == "__main__":
             for tp in (a.train_precision.split(",") if bk == "hip" else ["exact"]):
                 torch.cuda.reset_peak_memory_stats()
                 try:
-                    r = run(s, bk, a.iters, train_precision=tp, fused_adam=a.fused_adam, graph=a.graph)
+                    r = run(s, bk, a.iters, train_precision=tp, fused_adam=a.fused_adam)
                 except Exception as e:                              # noqa: BLE001
                     r = dict(shape=s, backend=bk, train_precision=tp, error=repr(e)[:300])
                 print(json.dumps(r), flush=True)
