@@ -21,8 +21,7 @@
  *     (ns2_*_workspace_bytes), constants live in per-device __device__ storage, so one host thread per device (or one
  *     process per device) may drive several devices concurrently, also under stream capture.  What it does keep, all of it
  *     write-once or atomic: per-device "attribute raised" / occupancy answers, the environment switches NS2_GEMM,
- *     NS2_COL_GROUP (0: column-tile-fastest order for every product of the 256 x 256 kernel; A/B), NS2_LSTM_PERSISTENT and
- *     NS2_LSTM_FUSED (read once per process), and the test hooks ns2_debug_*.  One thread-local
+ *     NS2_LSTM_PERSISTENT and NS2_LSTM_FUSED (read once per process), and the test hooks ns2_debug_*.  One thread-local
  *     pointer exists for the duration of a ns2_model_forward* / ns2_model_prepare_cond call: the split-K region of the
  *     workspace that call was given (set on entry, restored on return).
  *   - layout of a split-plane matrix (x_hi, x_lo, ld): `ld` is the LOGICAL column count, a multiple of 32.
@@ -184,6 +183,15 @@ int ns2_seanet_prep2(const float* x, int ldx, int in_prefix, int B, int64_t T, i
  *   for any other shape: the caller takes the GEMM path. */
 int ns2_seanet_conv_narrow(const float* x, int64_t ldx, int in_prefix, int B, int64_t T, int ci, int co, int k, int elu, const float* w,
                            const float* bias, float* out, int64_t ldo, void* stream);
+/* ns2_seanet_resblock_narrow: EnCodec's residual block (HFENC:268-301) y = shortcut(x) + conv2(elu(conv1(elu(x)))) -- conv1 k = 3
+ *   causal, dilation 1, reflect padded, C -> C / 2; conv2 and the shortcut 1 x 1 -- in ONE fp32 pass on the vector ALUs for the narrow
+ *   end of the SEANet stacks (C = 32: the blocks that run at the full sample rate), instead of two operand-plane passes + two GEMMs.
+ *   x fp32 [B, in_prefix + T, C] (row stride ldx) -> out fp32 [B * T, C] (row stride ldo).  Weights pre-arranged in consumption order:
+ *   w1p [3][C][C / 2] = conv1.weight[h][c][t] at (t, c, h); w2p [C / 2][C] = conv2.weight[c][h] at (h, c); wsp [C][C] =
+ *   shortcut.weight[o][c] at (c, o); b1 = conv1.bias; b2s = conv2.bias + shortcut.bias.  Returns NS2_UNAVAILABLE (nothing launched)
+ *   for any other shape: the caller takes the GEMM path. */
+int ns2_seanet_resblock_narrow(const float* x, int64_t ldx, int in_prefix, int B, int64_t T, int C, const float* w1p, const float* b1,
+                               const float* w2p, const float* wsp, const float* b2s, float* out, int64_t ldo, void* stream);
 int ns2_seanet_unpad(const float* src, int64_t ld_src, int prefix, float* dst, int64_t ld_dst, int B, int64_t T, int C, void* stream);
 int64_t ns2_lstm_state_floats(int B, int H);
 int ns2_lstm_layer(const float* xproj, int64_t ld_x, const float* w_hh, const float* b_hh, float* state, int64_t state_floats,

@@ -74,6 +74,7 @@ SIGNATURES = {
     "ns2_seanet_prep": (I, [P, I, I, P, I, I, L, I, I, I, I, P, P, I, I, P]),
     "ns2_seanet_prep2": (I, [P, I, I, I, L, I, I, P, P, I, I, I, P, P, I, I, I, I, P]),
     "ns2_seanet_conv_narrow": (I, [P, L, I, I, L, I, I, I, I, P, P, P, L, P]),
+    "ns2_seanet_resblock_narrow": (I, [P, L, I, I, L, I, P, P, P, P, P, P, L, P]),
     "ns2_seanet_unpad": (I, [P, L, I, P, L, I, L, I, P]),
     "ns2_lstm_state_floats": (L, [I, I]),
     "ns2_lstm_layer": (I, [P, L, P, P, P, L, P, L, P, L, I, L, I, P]),

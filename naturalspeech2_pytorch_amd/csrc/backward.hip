@@ -475,35 +475,53 @@ hipError_t launch_rmsnorm_bwd(const NormBwdArgs& a, hipStream_t s) {
 
 // ================================================================================================ attention backward (ATT:77-155)
 // delta[b, h, q] = sum_d dO[q, 64 h + d] * O[q, 64 h + d]   (O from its operand planes, hi + lo)
+// One wave per token row, a lane owns 8 consecutive features (lane = 8 * head-in-group + part; 64 lanes = 512 features, wider rows
+// take several passes): two float4 of dO and the matching 16-byte chunks of the o line per lane, 3 xor-shuffles inside the 8 lanes of
+// a head.  (Round 4's kernel gave every (row, head) ONE thread reading 64 strided floats: 475 us per call, 5.7 ms of a training
+// step, for 128 MB of traffic; this one streams.)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* dO, long lddo, const bf16_t* o_hi, int ldo, int B, int H, int Nq,
                                                          float* delta, int o_fmt) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long tot = (long)B * Nq * H;
-  if (idx >= tot) return;
-  const int h = (int)(idx % H);
-  const long m = idx / H;
-  const float* g = dO + m * lddo + 64 * h;
-  float s = 0.f;
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    const bf16_t* line = o_hi + m * 2L * ldo + pcol(64 * h + 32 * blk, true);
-#pragma unroll 8
-    for (int e = 0; e < 32; ++e) {
-      // the value the out-projection multiplies: hi + lo (bf16 lines) or half + remainder (FMT_H8 lines; the e5m2 remainder is 2^12-scaled)
-      const float o = o_fmt == FMT_H8 ? h2f(line[e]) + bf8_to_f(reinterpret_cast<const unsigned char*>(line)[96 + e]) * (1.0f / H8_LO_SCALE)
-                                      : bf2f(line[e]) + bf2f(line[32 + e]);
-      s += g[32 * blk + e] * o;
-    }
-  }
+  const int lane = threadIdx.x & 63;
+  const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long M = (long)B * Nq;
+  if (m >= M) return;
   const long b = m / Nq, q = m - b * Nq;
-  delta[(b * H + h) * Nq + q] = s;
+  for (int f0 = 8 * lane; f0 < 64 * H; f0 += 512) {           // wave-uniform trip count (64 H is a multiple of 64)
+    const float4 g0 = *reinterpret_cast<const float4*>(dO + m * lddo + f0), g1 = *reinterpret_cast<const float4*>(dO + m * lddo + f0 + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const bf16_t* line = o_hi + m * 2L * ldo + ((f0 & ~31) << 1);     // the 128-byte line of 32 features
+    const int e0 = f0 & 31;
+    const uint4 hv = *reinterpret_cast<const uint4*>(line + e0);
+    const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
+    float o[8];
+    if (o_fmt == FMT_H8) {
+      // the value the out-projection multiplies: half + the e5m2 remainder (2^12-scaled), FMT_H8 line = [half32 | e5m2(x) | remainder]
+      const uint2 lv = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(line) + 96 + e0);
+      const uint32_t lw[2] = {lv.x, lv.y};
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o[e] = h2f((bf16_t)((hw[e >> 1] >> (16 * (e & 1))) & 0xffffu)) + bf8_to_f((lw[e >> 2] >> (8 * (e & 3))) & 0xffu) * (1.0f / H8_LO_SCALE);
+    } else {
+      const uint4 lv = *reinterpret_cast<const uint4*>(line + 32 + e0);
+      const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o[e] = bf2f((bf16_t)((hw[e >> 1] >> (16 * (e & 1))) & 0xffffu)) + bf2f((bf16_t)((lw[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(g[e], o[e], s);
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if ((lane & 7) == 0) delta[(b * H + (f0 >> 6)) * Nq + q] = s;
+  }
 }
 hipError_t launch_attn_delta(const float* dO, long lddo, const bf16_t* o_hi, const bf16_t* o_lo, int ldo, int B, int H, int Nq, float* delta,
                              hipStream_t s, int o_fmt) {
   if (B <= 0 || H <= 0 || Nq <= 0 || !o_lo || o_lo != o_hi + 32 || (ldo & 31) || ldo < 64 * H) return hipErrorInvalidValue;
   if (o_fmt != FMT_BF16 && o_fmt != FMT_H8) return hipErrorInvalidValue;
-  const long n = (long)B * Nq * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dO, lddo, o_hi, ldo, B, H, Nq, delta, o_fmt);
+  if ((lddo & 3) || (reinterpret_cast<uintptr_t>(dO) & 15) || (reinterpret_cast<uintptr_t>(o_hi) & 15)) return hipErrorInvalidValue;
+  const long n = (long)B * Nq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, dO, lddo, o_hi, ldo, B, H, Nq, delta, o_fmt);
   return hipGetLastError();
 }
 

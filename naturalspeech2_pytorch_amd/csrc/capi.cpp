@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 111; }   // 111: training entry points take a precision (3 = bf16 x3, 4 = mixed on FMT_H8 lines), ns2_linear_split_as; 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 112; }   // 112: ns2_seanet_resblock_narrow; 111: training entry points take a precision (3 = bf16 x3, 4 = mixed on FMT_H8 lines), ns2_linear_split_as; 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 3, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel, 3 = auto without split-K");
   force_gemm_kernel(kernel);
@@ -268,6 +268,16 @@ extern "C" int ns2_seanet_conv_narrow(const float* x, int64_t ldx, int in_prefix
   ARGCHK(x && w && out && B > 0 && T > 0 && ci > 0 && co > 0 && k > 0 && in_prefix >= 0, "ns2_seanet_conv_narrow: bad arguments");
   const hipError_t e = launch_seanet_conv_narrow(x, (long)ldx, in_prefix, B, (long)T, ci, co, k, elu, w, bias, out, (long)ldo,
                                                  (hipStream_t)stream);
+  if (e == hipErrorNotReady) return NS2_UNAVAILABLE;
+  HIPRET(e);
+  return NS2_OK;
+}
+extern "C" int ns2_seanet_resblock_narrow(const float* x, int64_t ldx, int in_prefix, int B, int64_t T, int C, const float* w1p,
+                                          const float* b1, const float* w2p, const float* wsp, const float* b2s, float* out, int64_t ldo,
+                                          void* stream) {
+  ARGCHK(x && w1p && b1 && w2p && wsp && b2s && out && B > 0 && T > 0 && C > 0 && in_prefix >= 0, "ns2_seanet_resblock_narrow: bad arguments");
+  const hipError_t e = launch_seanet_resblock_narrow(x, (long)ldx, in_prefix, B, (long)T, C, w1p, b1, w2p, wsp, b2s, out, (long)ldo,
+                                                     (hipStream_t)stream);
   if (e == hipErrorNotReady) return NS2_UNAVAILABLE;
   HIPRET(e);
   return NS2_OK;

@@ -785,6 +785,150 @@ hipError_t launch_seanet_conv_narrow(const float* x, long ldx, int in_prefix, in
   return hipErrorNotReady;
 }
 
+// ---- EnCodec's residual block at its narrow end (HFENC:268-301: y = shortcut(x) + conv2(elu(conv1(elu(x)))), conv1 k = 3 causal with
+// reflect padding, conv2 and the shortcut 1 x 1; hidden = C / 2) as ONE pass on the vector ALUs.  At C = 32 the block runs at the
+// full 24 kHz rate -- 10.5 M rows for 32 utterances of 13.6 s -- and as GEMMs it was four HBM round trips of 1.3 GB each (two
+// operand-plane passes + two products that use 16 / 32 of the 64 columns of a wave tile): 3.4 ms.  Here a workgroup stages 256 + 2
+// fp32 rows in LDS with coalesced loads (row stride 144 B: the per-thread 16-byte reads down a column are conflict-free), a thread
+// computes one output row -- 3 C H + H C + C C = 3072 fp32 FMAs at C = 32 -- with the weights as SCALAR operands (they are the same
+// for every lane: packed in consumption order, s_load straight into the FMA), the row goes back through LDS and leaves coalesced:
+// x is read once and y written once.  Plain fp32 FMAs: closer to HF's own arithmetic than the bf16 x3 products.
+// w1p [3][C][H] (tap, in, hidden), w2p [H][C] (hidden, out), wsp [C][C] (in, out); rows of x: [B, in_prefix + T, ldx]
+// ELU for the VALU-bound kernel below: v_exp_f32 instead of the library's expm1f (a ~40-instruction polynomial: 112 of them per row
+// would outweigh the 3072 FMAs).  exp(x) - 1 cancels for small |x|; there the cubic Taylor form takes over (|error| < 1e-9 below 2^-6),
+// so the absolute error stays at fp32 rounding level everywhere.
+NS2_DEVINL float elu_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f) - 1.0f;
+  const float p = x * fmaf(x, fmaf(x, 0.16666667f, 0.5f), 1.0f);
+  const float neg = x > -0.015625f ? p : e;
+  return x > 0.f ? x : neg;
+}
+
+template <int C, int RPT>
+__global__ __launch_bounds__(256) void seanet_resblock_narrow_kernel(const float* __restrict__ x, long ldx, int in_prefix, int B, long T,
+                                                                     const float* __restrict__ w1p, const float* __restrict__ b1,
+                                                                     const float* __restrict__ w2p, const float* __restrict__ wsp,
+                                                                     const float* __restrict__ b2s, float* __restrict__ out, long ldo) {
+  // RPT rows per thread (rows tid, tid + 256, ...): every weight fetched from the scalar cache serves RPT FMAs
+  constexpr int H = C / 2, RS = C + 4, NR = 256 * RPT; // LDS row stride in floats: 16-byte aligned, 4-bank skew per row
+  extern __shared__ __attribute__((aligned(16))) float tile[];      // (NR + 2) * RS floats
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * NR;               // first output row (flattened b * T + n) of this workgroup
+  const long rows_total = (long)B * T;
+  auto src_row = [&](long r) -> const float* {         // flattened row -> its fp32 row in the input layout
+    const long b = r / T, n = r - b * T;
+    return x + (b * (in_prefix + T) + in_prefix + n) * ldx;
+  };
+  // ---- stage rows r0 - 2 ... r0 + NR - 1 (tile row j = row r0 - 2 + j), C / 4 float4 per row, coalesced
+  for (int i = tid; i < (NR + 2) * (C / 4); i += 256) {
+    const int j = i / (C / 4), q = i - j * (C / 4);
+    const long r = r0 - 2 + j;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= 0 && r < rows_total) v = *reinterpret_cast<const float4*>(src_row(r) + 4 * q);
+    *reinterpret_cast<float4*>(&tile[j * RS + 4 * q]) = v;
+  }
+  __syncthreads();
+  float y[RPT][C], h[RPT][H];
+  bool live[RPT];
+  long nn[RPT], bb[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const long r = r0 + tid + 256 * k;
+    live[k] = r < rows_total;
+    const long rc = live[k] ? r : rows_total - 1;      // (a dead row computes on valid data and is not stored)
+    bb[k] = rc / T; nn[k] = rc - bb[k] * T;
+#pragma unroll
+    for (int o = 0; o < H; ++o) h[k][o] = b1[o];
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    // tap t reads x[n - 2 + t]; before the utterance start EnCodec reflects (x[-i] = x[i], HFENC:142-175): those two rows per
+    // utterance come from global memory, everything else from the staged tile
+    float xv[RPT][C];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const long i = nn[k] - 2 + t;
+      const float* p = (i >= 0 && live[k]) ? &tile[(tid + 256 * k + t) * RS] : x + (bb[k] * (in_prefix + T) + in_prefix + (i >= 0 ? i : -i)) * ldx;
+      if (i >= 0 && live[k]) {
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);                 // (LDS)
+          xv[k][4 * q] = v.x; xv[k][4 * q + 1] = v.y; xv[k][4 * q + 2] = v.z; xv[k][4 * q + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);                 // (global)
+          xv[k][4 * q] = v.x; xv[k][4 * q + 1] = v.y; xv[k][4 * q + 2] = v.z; xv[k][4 * q + 3] = v.w;
+        }
+      }
+    }
+    if (t == 2) {                                      // the unshifted row: also the shortcut's input (raw)
+#pragma unroll
+      for (int k = 0; k < RPT; ++k)
+#pragma unroll
+        for (int o = 0; o < C; ++o) y[k][o] = b2s[o];
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int o = 0; o < C; ++o) {
+          const float w = wsp[c * C + o];
+#pragma unroll
+          for (int k = 0; k < RPT; ++k) y[k][o] = fmaf(w, xv[k][c], y[k][o]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float e[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) e[k] = elu_fast(xv[k][c]);
+#pragma unroll
+      for (int o = 0; o < H; ++o) {
+        const float w = w1p[(t * C + c) * H + o];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) h[k][o] = fmaf(w, e[k], h[k][o]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < H; ++o) {
+    float e[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) e[k] = elu_fast(h[k][o]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float w = w2p[o * C + c];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) y[k][c] = fmaf(w, e[k], y[k][c]);
+    }
+  }
+  __syncthreads();                                     // every read of the staged input is done: the tile becomes the output stage
+#pragma unroll
+  for (int k = 0; k < RPT; ++k)
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q)
+      *reinterpret_cast<float4*>(&tile[(tid + 256 * k) * RS + 4 * q]) = make_float4(y[k][4 * q], y[k][4 * q + 1], y[k][4 * q + 2], y[k][4 * q + 3]);
+  __syncthreads();
+  for (int i = tid; i < NR * (C / 4); i += 256) {
+    const int j = i / (C / 4), q = i - j * (C / 4);
+    if (r0 + j < rows_total) *reinterpret_cast<float4*>(out + (r0 + j) * ldo + 4 * q) = *reinterpret_cast<const float4*>(&tile[j * RS + 4 * q]);
+  }
+}
+// hipErrorNotReady: not a shape this kernel serves (the caller takes the GEMM path)
+hipError_t launch_seanet_resblock_narrow(const float* x, long ldx, int in_prefix, int B, long T, int C, const float* w1p, const float* b1,
+                                         const float* w2p, const float* wsp, const float* b2s, float* out, long ldo, hipStream_t s) {
+  if (B <= 0 || T <= 0 || in_prefix < 0 || !x || !w1p || !b1 || !w2p || !wsp || !b2s || !out) return hipErrorInvalidValue;
+  if (C != 32 || T < 3 || (ldx & 3) || (ldo & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15)) return hipErrorNotReady;
+  constexpr int RPT = 1;                             // (2 rows per thread measured no fewer instructions per row: the packed FMAs become plain ones)
+  const long blocks = ((long)B * T + 256 * RPT - 1) / (256 * RPT);
+  const size_t lds = (size_t)(256 * RPT + 2) * (32 + 4) * sizeof(float);       // 36.3 KiB
+  static DynLdsAttr attr;
+  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&seanet_resblock_narrow_kernel<32, RPT>), (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((seanet_resblock_narrow_kernel<32, RPT>), dim3((unsigned)blocks), dim3(256), lds, s, x, ldx, in_prefix, B, T, w1p, b1, w2p, wsp, b2s, out, ldo);
+  return hipGetLastError();
+}
+
 hipError_t launch_seanet_unpad(const float* src, long ld_src, int prefix, float* dst, long ld_dst, int B, long T, int C, hipStream_t s) {
   const long n = (long)B * T * C;
   hipLaunchKernelGGL(seanet_unpad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld_src, prefix, dst, ld_dst, B, T, C);

@@ -103,25 +103,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const int ntn = (g.N + G2_BN - 1) / G2_BN;
   const int ntm = (g.M + G2_BM - 1) / G2_BM;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
-  int tn, tm;
-  const int z = bid / (ntn * ntm);
-  bid -= z * ntn * ntm;
-  if (g.col_group > 0) {
-    // Column-grouped order (FF conv: 6 column tiles x 4128 K = 12.7 MB of W against a 4 MiB L2 per XCD).  Chunks of RG row tiles;
-    // inside a chunk the column tiles are visited in groups of CG, row tiles inside a group, the group's columns fastest -- so
-    // the 32 workgroups an XCD runs together are 32 / CG row tiles x CG column tiles: W of a group stays in L2 for a whole pass,
-    // an A row tile is shared by the CG workgroups next to each other (a bijection for ragged edges: the last group is narrower).
-    const int CG = g.col_group, RG = 32 / CG;
-    const int chunk = bid / (RG * ntn), idx = bid - chunk * RG * ntn;
-    const int R = min(RG, ntm - chunk * RG);                 // row tiles of this chunk
-    const int p = idx / (CG * R), rem = idx - p * CG * R;
-    const int cw = min(CG, ntn - p * CG);
-    tn = p * CG + rem % cw;
-    tm = chunk * RG + rem / cw;
-  } else {
-    tn = bid % ntn;
-    tm = bid / ntn;
-  }
+  const int tn = bid % ntn;
+  bid /= ntn;
+  const int tm = bid % ntm;
+  const int z = bid / ntm;
   const int dil = g.dil_z ? (g.dil << z) : g.dil;
 
   // operand layouts (ns2_common.h): exact mode requires interleaved operands (checked by launch_gemm); the fast kernel
@@ -870,12 +855,6 @@ static int forced_kernel() {
   return f;
 }
 
-// A/B switch of the column-grouped tile order (NS2_COL_GROUP=0: column tile fastest everywhere, rounds 1-4), read once
-static bool col_group_enabled() {
-  static const bool on = [] { const char* e = getenv("NS2_COL_GROUP"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 // Split-K plan of a product M x N over nkt K tiles of 32 (kt_per_tap per tap): S slices of c K tiles of EVERY tap, S = 1 = do not
 // split.  A product is split when it has fewer 128 x 128 output tiles than the chip has CUs -- a handful of tiles, each a long
 // serial K loop on one CU while the others idle -- and a K loop long enough to pay for the second launch: K >= 512, or K >= 352
@@ -924,13 +903,6 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
   }
   // a product that would put at most 64 blocks of 256 x 256 on the 256 CUs runs on the 128 x 128 kernel (4 x the blocks, a
   // quarter of the serial work each): 1 x 1024-frame steps measured 4 % faster with it, 4 x 1024 slower (exp_small_m_kernel.py)
-  // tile order of the 256 x 256 kernel (GemmArgs::col_group): column groups of 2 once the W rows of all column tiles exceed what an
-  // XCD's L2 holds next to the A rows (> 3 MiB) and the grid is several waves of workgroups deep
-  {
-    const long ntn = (g.N + 255) / 256, ntm = (g.M + 255) / 256;
-    const long w_bytes = ntn * 256 * (long)g.nkt * 32 * ((g.w_lo != nullptr) ? 4 : 2);
-    g.col_group = (col_group_enabled() && ntn > 2 && ntm >= 64 && w_bytes > (3L << 20)) ? 2 : 0;
-  }
   const long blocks256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.nz > 0 ? g.nz : 1);
   const bool big = (f == 2) || (f != 1 && g.N > 128 && !((f == 0 || f == 3) && blocks256 <= 64));
   if (!big) return launch_gemm1(g, precision, s);

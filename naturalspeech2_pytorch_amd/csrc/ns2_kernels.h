@@ -80,10 +80,6 @@ struct GemmArgs {
   // one slice covers (slice z: input columns [z * ksplit * 32, ...) of each tap); 0 = the plain launch.
   float* sk_ws; long sk_ws_floats;
   int ksplit;
-  // gemm2.hip, set by launch_gemm: 0 = column tile fastest (the workgroups an XCD runs together = a few row tiles x ALL column
-  // tiles: right while the W rows of all column tiles fit the XCD's 4 MiB L2); > 0 = column groups of this width: an XCD runs
-  // 32 / width row tiles x `width` column tiles together and keeps that W slice in its L2 for a whole pass over its row tiles
-  int col_group;
 };
 
 // precision: 3 = bf16 x3 ("exact"), 1 = bf16 ("fast"), 2 = one IEEE-half product ("half"), 4 = half product + both
@@ -191,6 +187,8 @@ hipError_t launch_seanet_prep2(const float* x, int ldx, int in_prefix, int B, lo
                                int raw_cols, int fmt, hipStream_t s);
 hipError_t launch_seanet_conv_narrow(const float* x, long ldx, int in_prefix, int B, long T, int ci, int co, int k, int elu, const float* w,
                                      const float* bias, float* out, long ldo, hipStream_t s);
+hipError_t launch_seanet_resblock_narrow(const float* x, long ldx, int in_prefix, int B, long T, int C, const float* w1p, const float* b1,
+                                         const float* w2p, const float* wsp, const float* b2s, float* out, long ldo, hipStream_t s);
 hipError_t launch_seanet_unpad(const float* src, long ld_src, int prefix, float* dst, long ld_dst, int B, long T, int C, hipStream_t s);
 long lstm_state_floats(int B, int H);     // caller scratch of launch_lstm_layer (h exchange, cell state / barrier counter)
 hipError_t launch_lstm_layer(const float* xproj, long ld_x, const float* w_hh, const float* b_hh, float* h_a, float* h_b,

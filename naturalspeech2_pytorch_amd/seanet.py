@@ -31,6 +31,7 @@ from .model import _PRECISIONS
 
 _NARROW_CONV = os.environ.get("NS2_SEANET_NARROW_CONV", "1") != "0"          # 0: the two 1-channel ends as GEMMs (A/B, tests)
 _FUSED_RESBLOCK = os.environ.get("NS2_SEANET_FUSED_RESBLOCK", "1") != "0"    # 0: conv1, shortcut, conv2 as three GEMMs (A/B, tests)
+_NARROW_RESBLOCK = os.environ.get("NS2_SEANET_NARROW_RESBLOCK", "1") != "0"  # 0: the 32-channel residual blocks as GEMMs too (A/B, tests)
 
 
 def _stream():
@@ -152,6 +153,13 @@ class _SEANetHIP(nn.Module):
             zero = torch.zeros(co, dtype=torch.float32, device=w2.device)
             p["cat"] = dict(w=ops.PackedWeight(wcat, precision=_PRECISIONS[self.precision]), hs=hs, xs=xs, co=co,
                             b=(b2 if b2 is not None else zero) + (bs if bs is not None else zero))
+            (w1, b1) = self._w(convs[0])
+            if c1["k"] == 3 and c1["dil"] == 1 and cx == co and ch * 2 == cx and w1.shape[1] == cx:
+                # the one-pass fp32 kernel for the narrow end of the stacks (ns2_seanet_resblock_narrow serves C = 32: the blocks at the
+                # full sample rate): weights in its consumption order -- w1p [t][c][h], w2p [h][c], wsp [c][o]
+                p["narrow"] = dict(C=cx, w1p=w1.permute(2, 1, 0).contiguous(), b1=(b1 if b1 is not None else torch.zeros(ch, device=w1.device)),
+                                   w2p=w2[:, :, 0].t().contiguous(), wsp=ws[:, :, 0].t().contiguous(),
+                                   b2s=((b2 if b2 is not None else zero) + (bs if bs is not None else zero)).contiguous())
         return p
 
     def _pack_lstm(self, m):
@@ -237,6 +245,16 @@ class _SEANetHIP(nn.Module):
         ever copied just to drop prefix rows, and the shortcut's output never exists in memory."""
         prec = _PRECISIONS[self.precision]
         c1, c2, sc, cat = p["c1"], p["c2"], p["sc"], p.get("cat")
+        nr = p.get("narrow")
+        if nr is not None and _NARROW_RESBLOCK:
+            # x read once, y written once: conv1 (k = 3, reflect), both ELUs, conv2 and the shortcut on the vector ALUs in fp32
+            y = torch.empty(a.B * a.T, nr["C"], dtype=torch.float32, device=a.x.device)
+            rc = _lib.load().ns2_seanet_resblock_narrow(a.x.data_ptr(), a.x.shape[-1], a.prefix, a.B, a.T, nr["C"], nr["w1p"].data_ptr(),
+                                                        nr["b1"].data_ptr(), nr["w2p"].data_ptr(), nr["wsp"].data_ptr(), nr["b2s"].data_ptr(),
+                                                        y.data_ptr(), nr["C"], _stream())
+            if rc != _lib.NS2_UNAVAILABLE:
+                check(rc, "ns2_seanet_resblock_narrow")
+                return _Act(y, a.B, a.T, nr["C"], 0)
         if cat is None or not _FUSED_RESBLOCK:
             a = a.clean() if a.prefix else a                      # any other block shape: layer by layer
             h = self._conv(a, c1, elu=True)

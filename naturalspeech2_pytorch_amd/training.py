@@ -401,9 +401,16 @@ def _enter(t):
 
 
 def _un(ctx, *ts):
-    """parameter / conditioning gradients of a Function leave the scaled domain"""
+    """parameter / conditioning gradients of a Function leave the scaled domain (one multi-tensor launch per Function: the per-tensor
+    multiplications were 325 launches of a d512 / L12 step)"""
     sc = ctx.sc
-    return ts if sc is None else tuple(sc.unscale(t) for t in ts)
+    if sc is None:
+        return ts
+    live = [t for t in ts if t is not None]
+    if not live:
+        return ts
+    done = iter(torch._foreach_mul(live, sc.inv))
+    return tuple(None if t is None else next(done) for t in ts)
 
 
 # =============================================================================================== weight sources of the two packs

@@ -658,3 +658,32 @@ def test_eval_module_without_no_grad_warns_once_and_force_autograd_selects_the_c
     assert T.needs_autograd(tr.train(), x) is True
     with torch.no_grad():
         assert T.needs_autograd(tr, x) is False
+
+
+def test_seanet_narrow_resblock_weight_arrangement(monkeypatch):
+    """_pack_resblock's operands for ns2_seanet_resblock_narrow (w1p [t][c][h], w2p [h][c], wsp [c][o], b2s): the kernel's arithmetic
+    restated with them -- reflect-padded k = 3 conv on elu(x), elu, 1 x 1 conv, + 1 x 1 shortcut of x -- equals HF's block (HFENC:268-301)"""
+    tf = pytest.importorskip("transformers")
+    from transformers.models.encodec.modeling_encodec import EncodecResnetBlock
+    from naturalspeech2_pytorch_amd import seanet, ops
+
+    class Holder:
+        def __init__(self, w, precision=3):
+            self.w = w
+    monkeypatch.setattr(ops, "PackedWeight", Holder)
+    torch.manual_seed(1)
+    blk = EncodecResnetBlock(tf.EncodecConfig(), dim=32, dilations=[1, 1]).eval()
+    net = seanet._SEANetHIP.__new__(seanet._SEANetHIP)
+    torch.nn.Module.__init__(net)
+    net.precision = "exact"
+    nr = net._pack_resblock(blk)["narrow"]
+    assert nr["C"] == 32 and nr["w1p"].shape == (3, 32, 16) and nr["w2p"].shape == (16, 32) and nr["wsp"].shape == (32, 32)
+    T = 21
+    x = torch.randn(T, 32)
+    with torch.no_grad():
+        ref = blk(x.t()[None])[0].t()                                # [T, 32]
+        ex = torch.nn.functional.elu(x)
+        idx = lambda n: n if n >= 0 else -n                          # noqa: E731  (reflect: x[-i] = x[i])
+        h = torch.stack([nr["b1"] + sum(ex[idx(n - 2 + t)] @ nr["w1p"][t] for t in range(3)) for n in range(T)])
+        got = nr["b2s"] + torch.nn.functional.elu(h) @ nr["w2p"] + x @ nr["wsp"]
+    assert torch.allclose(got, ref, atol=1e-5), (got - ref).abs().max()

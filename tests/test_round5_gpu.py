@@ -233,3 +233,34 @@ def test_every_gradient_in_the_mixed_training_arithmetic_matches_the_reference_a
     assert not bad, bad
     _, dx2, g2 = grads(m)                                  # deterministic also here: fixed slots, and the scale is a function of the input
     assert torch.equal(dx1, dx2) and all(torch.equal(g1[k], g2[k]) for k in g1)
+
+
+# ------------------------------------------------------------------------------------------------ the codec's narrow residual block
+@pytest.mark.parametrize("B,T,inp", [(2, 300, 0), (3, 77, 2), (1, 1000, 0), (5, 3, 1), (2, 256, 0), (1, 257, 3)])
+def test_seanet_resblock_narrow_matches_hf(B, T, inp):
+    """ns2_seanet_resblock_narrow (EnCodec's residual block at C = 32 in one fp32 pass: conv1 k = 3 with reflect padding, both ELUs,
+    conv2 and the shortcut) against HF's own EncodecResnetBlock on the same weights: rows across workgroup borders, utterance starts
+    inside a workgroup, an input layout with prefix rows, T = 3 (the two reflected rows are the whole past)"""
+    tf = pytest.importorskip("transformers")
+    from transformers.models.encodec.modeling_encodec import EncodecResnetBlock
+    from naturalspeech2_pytorch_amd import _lib, seanet
+    torch.manual_seed(3)
+    blk = EncodecResnetBlock(tf.EncodecConfig(), dim=32, dilations=[1, 1]).eval().to(DEV)
+    net = seanet._SEANetHIP.__new__(seanet._SEANetHIP)
+    torch.nn.Module.__init__(net)
+    net.precision = "exact"
+    nr = net._pack_resblock(blk)["narrow"]
+    x = (make_input("rb", (B * (inp + T), 32), seed=31) * 1.5).to(DEV)
+    y = torch.full((B * T, 32), float("nan"), device=DEV)
+    lib = _lib.load()
+    rc = lib.ns2_seanet_resblock_narrow(x.data_ptr(), 32, inp, B, T, 32, nr["w1p"].data_ptr(), nr["b1"].data_ptr(), nr["w2p"].data_ptr(),
+                                        nr["wsp"].data_ptr(), nr["b2s"].data_ptr(), y.data_ptr(), 32, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+    xv = x.reshape(B, inp + T, 32)[:, inp:]
+    with torch.no_grad():
+        ref = blk(xv.transpose(1, 2)).transpose(1, 2).reshape(B * T, 32)
+    e = rel(y, ref)
+    assert e < 3e-6, e
+    # another width is not served: nothing launched, the caller takes the GEMM path
+    assert lib.ns2_seanet_resblock_narrow(x.data_ptr(), 32, inp, B, T, 48, nr["w1p"].data_ptr(), nr["b1"].data_ptr(), nr["w2p"].data_ptr(),
+                                          nr["wsp"].data_ptr(), nr["b2s"].data_ptr(), y.data_ptr(), 32, torch.cuda.current_stream().cuda_stream) == _lib.NS2_UNAVAILABLE
