@@ -41,7 +41,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_TRAFFIC = "r04_pmc_traffic.json"  # profiles/: committed PMC profile of the dominant kernel (tools/final_profile_r4.sh)
+PMC_TRAFFIC = "r05_pmc_traffic.json"  # profiles/: committed PMC profile of the dominant kernel (tools/pmc_mfma_bench.sh, r05_pmc_mfma.json)
 PARITY_RECORD = "r05_parity.json"    # profiles/: the tracked key-wise parity record (tests/parity_record.py)
 PEAK_16BIT_TFLOPS = 2500.0         # dense bf16 / f16 MFMA peak, MI355X_MICROARCH.md (spec; 2495 measured)
 PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (RVQ)
@@ -351,7 +351,7 @@ def main():
         fl, nl = dominant_flops(B, N, dim, depth, 4, 8, conv_only=(precision in ("hybrid", "hybrid_ff")), conditioned=conditioned)
         avg_ms = kern_ms_v / kern_n_v
         ach = (fl / nl) / (avg_ms * 1e-3) / 1e12
-        traffic, tsrc = None, None
+        traffic, tsrc, busy = None, None, None
         pj = os.path.join(ROOT, "profiles", PMC_TRAFFIC)
         if os.path.exists(pj) and (dim, depth) == (512, 12):
             tj = json.load(open(pj))
@@ -360,12 +360,13 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
             if traffic is not None:
                 tsrc = (f"profiles/{PMC_TRAFFIC}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command "
-                        "(tools/pmc_bench.sh), read side doubled per MI355X_MICROARCH.md; a committed profile, NOT measured in this run")
+                        "(tools/pmc_mfma_bench.sh), read side doubled per MI355X_MICROARCH.md; a committed profile, NOT measured in this run")
+                busy = tj.get("mfma_pipe_busy_frac")
         what = f"FF causal conv k3 x{depth}" + ("" if precision in ("hybrid", "hybrid_ff") else ", wavenet init conv, skip-sum GEMM") + \
                (f", cross-attention q projection x{depth}" if conditioned and precision not in ("hybrid", "hybrid_ff") else "")
         return dict(bound="mfma", kernel=f"ns2::{KERNEL_NAME[precision]} = EPI_SPLIT ({what})",
                     achieved=round(ach, 2), peak=PEAK_16BIT_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_16BIT_TFLOPS, 4),
-                    traffic=traffic, traffic_source=tsrc, avg_launch_ms=round(avg_ms, 4), launches=kern_n_v,
+                    traffic=traffic, traffic_source=tsrc, mfma_pipe_busy_frac_profiled=busy, avg_launch_ms=round(avg_ms, 4), launches=kern_n_v,
                     algorithmic_gflop_per_launch=round(fl / nl / 1e9, 2),
                     mfma_time_units_per_algorithmic_flop=MFMA_UNITS[precision],
                     frac_of_mfma_pipe_time=round(MFMA_UNITS[precision] * ach / PEAK_16BIT_TFLOPS, 4))

@@ -84,14 +84,23 @@ extern "C" int ns2_reduce_slices(const float* partial, int64_t outer, int S, int
 }
 
 // ---- weight gradient: dW[r, k, t] = sum_m dY[m, r] * X_t[m, k]  as ONE GEMM over transposed planes, split-K into fixed slots
+// Slices of the token axis: every slice is a grid-z layer of output tiles writing its own slot.  The 256 x 256 kernel runs ONE workgroup
+// per CU, so a launch costs ceil(tiles * S / 256) rounds of (nkt / S) K tiles each; among the divisors of nkt that leave >= 8 K tiles
+// per slice take the cheapest -- a slice also pays for storing its fp32 slot and for the fixed-order sum reading it (~12 K-tile
+// times) -- and of equally cheap ones the smallest.  (Round 4 aimed at ~2.5 workgroups per CU whatever the shape: a 512 x 512 gradient
+// got 128 slots = 128 MB of partial sums for two rounds of 8-tile blocks; now 64 slots, one round of 16-tile blocks.)
 static int wgrad_split(int R, int ncols, int64_t ld_t) {
   const int nkt = (int)(ld_t / 32);
-  const long tiles = ncols > 128 ? (long)((R + 255) / 256) * ((ncols + 255) / 256) : (long)((R + 127) / 128);
-  long want = (640 + tiles - 1) / tiles;                 // >= ~2.5 workgroups per CU in flight
-  want = std::min<long>(want, std::max(1, nkt / 8));     // ... of at least 8 K tiles each
+  const bool big = ncols > 128;
+  const long tiles = big ? (long)((R + 255) / 256) * ((ncols + 255) / 256) : (long)((R + 127) / 128);
+  const long per_round = big ? 256 : 512;                // workgroups the chip runs at once (the 128 x 128 kernel: two per CU)
   int S = 1;
-  for (int d = 1; d <= nkt && d <= want; ++d)
-    if (nkt % d == 0) S = d;                             // slices must cover whole K tiles evenly
+  long best = -1;
+  for (int d = 1; d <= nkt && d <= std::max(1, nkt / 8); ++d) {
+    if (nkt % d) continue;                               // slices must cover whole K tiles evenly
+    const long cost = ((tiles * d + per_round - 1) / per_round) * (nkt / d + 12);     // + a slot's fp32 store and its later read, in K-tile times
+    if (best < 0 || cost < best) { best = cost; S = d; }
+  }
   return S;
 }
 extern "C" int64_t ns2_wgrad_workspace_bytes(int R, int ncols, int64_t ld_t) {
