@@ -23,11 +23,14 @@ namespace ns2 {
 // ================================================================================================ tplanes
 // One 64 x 64 tile per workgroup: load (fp32 -> split, or planes), optional row-plane store, transpose through LDS, store
 // transposed interleaved lines along the token axis.  H8 = false: bf16 lines [hi32 | lo32] (the exact arithmetic); H8 = true: FMT_H8
-// lines [half32 | e5m2(x) 32 B | e5m2((x - half(x)) 2^12) 32 B] (the mixed training arithmetic).  In LDS an element is two 16-bit
-// words either way: th = hi / half, tl = lo / (h8 | l8 << 8).
+// lines [half32 | e5m2(x) 32 B | e5m2((x - half(x)) 2^12) 32 B] (the mixed training arithmetic).
+// In LDS an element is ONE 32-bit word -- hi | lo << 16, resp. half | e5m2(x) << 16 | remainder << 24 -- so the tile is written with
+// ds_write_b32 and read back down its columns with ds_read_b32 (row stride 65 words: conflict-free both ways), and the thread that
+// gathers 8 tokens of a column writes BOTH parts of the output line from the same 8 words.  (Round 4 kept two 16-bit arrays: twice
+// the LDS instructions, 2-byte accesses; the kernels ran at 2.7-3.2 TB/s of their traffic and were 17 ms of a training step.)
 template <bool IN_F32, bool H8>
 __global__ __launch_bounds__(256) void tplanes_kernel(const TPlanesArgs a) {
-  __shared__ uint16_t th[64][66], tl[64][66];
+  __shared__ uint32_t tw[64][65];
   __shared__ float cs[16][64];
   const int tid = threadIdx.x;
   const int c0 = blockIdx.x * 64;
@@ -51,8 +54,8 @@ __global__ __launch_bounds__(256) void tplanes_kernel(const TPlanesArgs a) {
     return m - a.shift;
   };
 
-  float csum[4] = {0.f, 0.f, 0.f, 0.f};
   if constexpr (IN_F32) {
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
     const int ch = tid & 15;                    // 4 columns c0 + 4 ch ..
     const bool vec = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.xf) & 15) == 0);
 #pragma unroll
@@ -70,22 +73,21 @@ __global__ __launch_bounds__(256) void tplanes_kernel(const TPlanesArgs a) {
           for (int e = 0; e < 4; ++e) if (c + e < a.C) v[e] = a.xf[sr * a.ldx + c + e];
         }
       }
-      if constexpr (H8) {
 #pragma unroll
-        for (int e2 = 0; e2 < 2; ++e2) {
+      for (int e2 = 0; e2 < 2; ++e2) {
+        uint32_t w0, w1;
+        if constexpr (H8) {
           uint32_t h16, h8, l8;
           cvt2_h8(v[2 * e2], v[2 * e2 + 1], h16, h8, l8);          // (counts values beyond the half range: the loss-scale overflow check)
-          th[i][4 * ch + 2 * e2] = (uint16_t)(h16 & 0xffffu); th[i][4 * ch + 2 * e2 + 1] = (uint16_t)(h16 >> 16);
-          tl[i][4 * ch + 2 * e2] = (uint16_t)((h8 & 0xffu) | ((l8 & 0xffu) << 8));
-          tl[i][4 * ch + 2 * e2 + 1] = (uint16_t)(((h8 >> 8) & 0xffu) | (((l8 >> 8) & 0xffu) << 8));
+          w0 = (h16 & 0xffffu) | ((h8 & 0xffu) << 16) | ((l8 & 0xffu) << 24);
+          w1 = (h16 >> 16) | (((h8 >> 8) & 0xffu) << 16) | (((l8 >> 8) & 0xffu) << 24);
+        } else {
+          uint32_t ph, pl;
+          split2(v[2 * e2], v[2 * e2 + 1], ph, pl);
+          w0 = (ph & 0xffffu) | (pl << 16);
+          w1 = (ph >> 16) | (pl & 0xffff0000u);
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          bf16_t h, l;
-          split_bf16(v[e], h, l);
-          th[i][4 * ch + e] = h; tl[i][4 * ch + e] = l;
-        }
+        tw[i][4 * ch + 2 * e2] = w0; tw[i][4 * ch + 2 * e2 + 1] = w1;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) csum[e] += v[e];
@@ -101,33 +103,37 @@ __global__ __launch_bounds__(256) void tplanes_kernel(const TPlanesArgs a) {
       for (int e = 0; e < 4; ++e) cs[tid >> 4][4 * ch + e] = csum[e];
     }
   } else {
-    const int ch = tid & 15;                    // 16-B chunk of the two 128-B lines covering columns c0 .. c0 + 63
-    const int line = ch >> 3, q = ch & 7;
+    // plane input: a thread takes 8 columns of one row -- the 16-byte chunk of the first part and the matching bytes of the second
+    const int g8 = tid & 7;                     // columns c0 + 8 g8 .. (+ 7)
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int i = (tid >> 4) + 16 * pass;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int i = (tid >> 3) + 32 * pass;
       const long sr = src_row(i);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (sr >= 0 && c0 + 32 * line < a.C) {     // C is a multiple of 8 for plane inputs (checked by the launcher); lines are whole
-        const bf16_t* p = a.in_hi + sr * 2L * a.ld_in + pcol(a.in_col0 + c0 + 32 * line, true) + 8 * q;      // 16-B chunk q of the line
-        v = *reinterpret_cast<const uint4*>(p);
-      }
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-      if (!H8 || q < 4) {
-        // 8 16-bit values: bf16 hi (q < 4) / lo (q >= 4) of columns 8 (q & 3) .., or the halves of columns 8 q ..
-        uint16_t* dst = ((!H8 && q >= 4) ? &tl[i][0] : &th[i][0]) + 32 * line + 8 * (q & 3);
-        const bool okc = c0 + 32 * line + 8 * (q & 3) < a.C;
+      const int c = c0 + 8 * g8;
+      uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+      if (sr >= 0 && c < a.C) {                  // C is a multiple of 8 for plane inputs (checked by the launcher)
+        const bf16_t* line = a.in_hi + sr * 2L * a.ld_in + pcol((a.in_col0 + c) & ~31, true);      // the 128-byte line of this column group
+        const int e0 = (a.in_col0 + c) & 31;
+        const uint4 p0 = *reinterpret_cast<const uint4*>(line + e0);
+        const uint32_t hw[4] = {p0.x, p0.y, p0.z, p0.w};
+        if constexpr (H8) {
+          const unsigned char* bytes = reinterpret_cast<const unsigned char*>(line);
+          const uint2 b8 = *reinterpret_cast<const uint2*>(bytes + 64 + e0), l8 = *reinterpret_cast<const uint2*>(bytes + 96 + e0);
+          const uint32_t bw[2] = {b8.x, b8.y}, lw[2] = {l8.x, l8.y};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dst[2 * e] = okc ? (uint16_t)(w[e] & 0xffffu) : 0; dst[2 * e + 1] = okc ? (uint16_t)(w[e] >> 16) : 0; }
-      } else {
-        // 16 bytes: e5m2(x) (q = 4, 5) or the scaled remainders (q = 6, 7) of columns 16 (q & 1) ..: byte halves of tl
-        uint8_t* dstb = reinterpret_cast<uint8_t*>(&tl[i][32 * line + 16 * (q & 1)]) + (q >= 6 ? 1 : 0);
+          for (int e = 0; e < 8; ++e)
+            w[e] = ((hw[e >> 1] >> (16 * (e & 1))) & 0xffffu) | (((bw[e >> 2] >> (8 * (e & 3))) & 0xffu) << 16) |
+                   (((lw[e >> 2] >> (8 * (e & 3))) & 0xffu) << 24);
+        } else {
+          const uint4 p1 = *reinterpret_cast<const uint4*>(line + 32 + e0);
+          const uint32_t lw[4] = {p1.x, p1.y, p1.z, p1.w};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const bool okc = c0 + 32 * line + 16 * (q & 1) + e < a.C;
-          dstb[2 * e] = okc ? (uint8_t)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) : (uint8_t)0;
+          for (int e = 0; e < 8; ++e)
+            w[e] = ((hw[e >> 1] >> (16 * (e & 1))) & 0xffffu) | (((lw[e >> 1] >> (16 * (e & 1))) & 0xffffu) << 16);
         }
       }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tw[i][8 * g8 + e] = w[e];
     }
   }
   __syncthreads();
@@ -138,38 +144,42 @@ __global__ __launch_bounds__(256) void tplanes_kernel(const TPlanesArgs a) {
     if (c0 + tid < a.C) a.colsum_partial[(long)blockIdx.y * a.C + c0 + tid] = s;
   }
   if (!a.t_hi) return;
-  // ---- transposed store: output row = column c of the tile, 64 token positions = two interleaved lines; a thread writes the
-  // 16-byte chunk q of a line
-  const int ch = tid & 15;
-  const int line = ch >> 3, q = ch & 7;
+  // ---- transposed store: output row = column c of the tile; a thread gathers 8 token positions of one column (8 words) and writes
+  // both parts of them: bf16 16 + 16 bytes, FMT_H8 16 + 8 + 8 bytes
+  const int g8 = tid & 7;                       // tokens n0 + 8 g8 .. (+ 7)
   const int rows_out = a.per_batch ? a.t_rows_per_batch : a.t_rows;
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int cr = (tid >> 4) + 16 * pass;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cr = (tid >> 3) + 32 * pass;
     const int c = c0 + cr;
-    const long col = n0 + 32 * line;            // first token position of this output line
-    if (c >= rows_out || col >= a.ld_t) continue;
-    uint32_t w[4];
-    if (!H8 || q < 4) {
-      const bool lo_plane = !H8 && q >= 4;
+    const long col = n0 + 8 * g8;               // first token position
+    if (c >= rows_out || (col & ~31L) >= a.ld_t) continue;
+    uint32_t w[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i0 = 32 * line + 8 * (q & 3) + 2 * e;
-        const uint16_t lo16 = lo_plane ? tl[i0][cr] : th[i0][cr], hi16 = lo_plane ? tl[i0 + 1][cr] : th[i0 + 1][cr];
-        w[e] = (uint32_t)lo16 | ((uint32_t)hi16 << 16);
-      }
-    } else {
-      const int sh = q >= 6 ? 8 : 0;            // e5m2(x) = low byte, scaled remainder = high byte of tl
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i0 = 32 * line + 16 * (q & 1) + 4 * e;
-        w[e] = ((uint32_t)(tl[i0][cr] >> sh) & 0xffu) | (((uint32_t)(tl[i0 + 1][cr] >> sh) & 0xffu) << 8) |
-               (((uint32_t)(tl[i0 + 2][cr] >> sh) & 0xffu) << 16) | (((uint32_t)(tl[i0 + 3][cr] >> sh) & 0xffu) << 24);
-      }
-    }
+    for (int e = 0; e < 8; ++e) w[e] = tw[8 * g8 + e][cr];
     const long orow = a.per_batch ? (long)b * a.t_rows_per_batch + c : c;
-    bf16_t* dst = a.t_hi + orow * 2L * a.ld_t + 2L * col + 8 * q;
-    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+    bf16_t* line = a.t_hi + orow * 2L * a.ld_t + 2L * (col & ~31L);          // the 128-byte line of these token positions
+    const int e0 = (int)(col & 31);
+    uint32_t p0[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p0[e] = (w[2 * e] & 0xffffu) | (w[2 * e + 1] << 16);
+    *reinterpret_cast<uint4*>(line + e0) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+    if constexpr (H8) {
+      unsigned char* bytes = reinterpret_cast<unsigned char*>(line);
+      uint32_t hb[2], lb[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        hb[e] = ((w[4 * e] >> 16) & 0xffu) | (((w[4 * e + 1] >> 16) & 0xffu) << 8) | (((w[4 * e + 2] >> 16) & 0xffu) << 16) | (((w[4 * e + 3] >> 16) & 0xffu) << 24);
+        lb[e] = (w[4 * e] >> 24) | ((w[4 * e + 1] >> 24) << 8) | ((w[4 * e + 2] >> 24) << 16) | ((w[4 * e + 3] >> 24) << 24);
+      }
+      *reinterpret_cast<uint2*>(bytes + 64 + e0) = make_uint2(hb[0], hb[1]);
+      *reinterpret_cast<uint2*>(bytes + 96 + e0) = make_uint2(lb[0], lb[1]);
+    } else {
+      uint32_t p1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p1[e] = (w[2 * e] >> 16) | (w[2 * e + 1] & 0xffff0000u);
+      *reinterpret_cast<uint4*>(line + 32 + e0) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+    }
   }
 }
 
