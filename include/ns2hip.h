@@ -343,6 +343,17 @@ int64_t ns2_wgrad_workspace_bytes(int R, int ncols, int64_t ld_t);
 int ns2_wgrad(const uint16_t* dyt_hi, const uint16_t* dyt_lo, const uint16_t* xt_hi, const uint16_t* xt_lo, int64_t ld_t, int R, int T,
               int Kp, int K, float* dw, void* workspace, int64_t workspace_bytes, int precision, void* stream);
 
+/* The same gradient from the TOKEN-MAJOR operand planes themselves: dy [M, ld_dy] (the row planes ns2_grad_prep writes for the dgrad
+ * GEMM), x [M, ld_x] (the operand planes the forward GEMM read).  Tap t of a causal conv's gradient reads x[m - (T - 1 - t) * dil]
+ * inside the utterance of m (seq_len tokens, >= 32, M a multiple of it); T = 1: nn.Linear (dil / seq_len ignored).  The kernel forms
+ * its MFMA fragments with gfx950's LDS transpose reads, so neither transposed nor shifted copies of the operands exist in memory.
+ * Any shape is computed; ns2_wgrad_rows_preferred says whether this route is the faster one (the 256 x 256 kernel must fill the chip:
+ * the dim = 128 model's narrow gradients stay on ns2_wgrad, which picks the 128 x 128 kernel).  workspace = ns2_wgrad_workspace_bytes(R, T * Kp, round_up(M, 32)). */
+int ns2_wgrad_rows_preferred(int R, int ncols, int64_t M);
+int ns2_wgrad_rows(const uint16_t* dy_hi, const uint16_t* dy_lo, int ld_dy, const uint16_t* x_hi, const uint16_t* x_lo, int ld_x, int64_t M,
+                   int R, int T, int Kp, int K, int dil, int seq_len, float* dw, void* workspace, int64_t workspace_bytes, int precision,
+                   void* stream);
+
 /* WavenetResBlock's FiLM + gate (NS2:629-636) for the unfused training forward: out = tanh(z) * sigmoid(z), z = h * gamma_b + beta_b,
  * film[b] = [gamma (d) | beta (d)]; and its backward: dh = dg g'(z) gamma, partial[(b * slices + s)] = [sum dg g'(z) h | sum dg g'(z)]
  * over the s-th group of tokens of utterance b (ns2_film_gate_slices(seq_len) groups; ns2_reduce_slices gives d film [B, 2 d]) */

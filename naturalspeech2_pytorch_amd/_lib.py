@@ -113,6 +113,8 @@ SIGNATURES = {
     "ns2_reduce_slices": (I, [P, L, I, L, P, I, P]),
     "ns2_wgrad_workspace_bytes": (L, [I, I, L]),
     "ns2_wgrad": (I, [P, P, P, P, L, I, I, I, I, P, P, L, I, P]),
+    "ns2_wgrad_rows_preferred": (I, [I, I, L]),
+    "ns2_wgrad_rows": (I, [P, P, I, P, P, I, L, I, I, I, I, I, I, P, P, L, I, P]),
     "ns2_film_gate_fwd": (I, [P, L, P, I, I, L, I, P, L, P]),
     "ns2_film_gate_slices": (I, [I]),
     "ns2_film_gate_bwd": (I, [P, L, P, L, P, I, I, I, I, P, L, P, P]),

@@ -129,6 +129,43 @@ extern "C" int ns2_wgrad(const uint16_t* dyt_hi, const uint16_t* dyt_lo, const u
   return NS2_OK;
 }
 
+// The same gradient straight from the TOKEN-MAJOR planes (gemm2.hip TR: LDS transpose reads form the fragments; no transposed
+// copies, no shifted copies of a conv's input).  Same slots, same fixed-order sum.
+// The TR kernel is the 256 x 256 kernel: gradients it would run on a handful of half-empty tiles (the dim = 128 model, short batches) keep
+// the transposed route, where launch_gemm picks the 128 x 128 kernel by the same rule (gemm2.hip launch_gemm: <= 64 blocks of 256 x 256).
+extern "C" int ns2_wgrad_rows_preferred(int R, int ncols, int64_t M) {
+  if (R <= 128 || ncols <= 128 || M <= 0) return 0;
+  const int64_t ld_t = (M + 31) / 32 * 32;
+  const long blocks256 = (long)((R + 255) / 256) * ((ncols + 255) / 256) * wgrad_split(R, ncols, ld_t);
+  return blocks256 > 64;
+}
+extern "C" int ns2_wgrad_rows(const uint16_t* dy_hi, const uint16_t* dy_lo, int ld_dy, const uint16_t* x_hi, const uint16_t* x_lo, int ld_x,
+                              int64_t M, int R, int T, int Kp, int K, int dil, int seq_len, float* dw, void* workspace, int64_t workspace_bytes,
+                              int precision, void* stream) {
+  ARGCHK(dy_hi && dy_lo == dy_hi + 32 && x_hi && x_lo == x_hi + 32 && dw && workspace, "ns2_wgrad_rows: null pointer / operands must be interleaved lines (lo = hi + 32)");
+  ARGCHK(precision == 3 || precision == 4, "ns2_wgrad_rows: precision 3 (bf16 x3) or 4 (half product + fp8 correction terms on FMT_H8 lines)");
+  ARGCHK(M > 0 && M < (1LL << 30) && R > 0 && T > 0 && K > 0 && Kp >= K && (Kp & 31) == 0 && (ld_dy & 31) == 0 && (ld_x & 31) == 0 && ld_dy >= R && ld_x >= Kp,
+         "ns2_wgrad_rows: bad shapes (Kp, ld_dy, ld_x multiples of 32; ld_dy >= R; ld_x >= Kp)");
+  ARGCHK(T == 1 || (seq_len >= 32 && dil >= 1 && M % seq_len == 0), "ns2_wgrad_rows: a conv's gradient needs utterances of seq_len >= 32 tokens");
+  const int ncols = T * Kp;
+  const int64_t ld_t = (M + 31) / 32 * 32;
+  const int S = wgrad_split(R, ncols, ld_t);
+  ARGCHK(workspace_bytes >= (int64_t)S * R * ncols * (int64_t)sizeof(float), "ns2_wgrad_rows: workspace too small (ns2_wgrad_workspace_bytes(R, T * Kp, round_up(M, 32)))");
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  const int nkt = (int)(ld_t / 32) / S;
+  g.a_hi = dy_hi; g.a_lo = dy_lo; g.lda = ld_dy;
+  g.w_hi = x_hi; g.w_lo = x_lo; g.ldw = ld_x;
+  g.M = R; g.N = ncols; g.nkt = nkt; g.kt_per_tap = nkt; g.conv_taps = 0; g.dil = dil > 0 ? dil : 1; g.seq_len = T > 1 ? seq_len : 0; g.mid_kt = -1;
+  g.nz = S; g.out_f_zs = (long)R * ncols;
+  g.pad_left = -1; g.out_fmt = -1; g.vt_fmt = -1;
+  g.epi = EPI_F32; g.out_f = (float*)workspace; g.ldo_f = ncols;
+  g.tr_tokens = (int)M; g.tr_kp = Kp; g.tr_taps = T > 1 ? T : 0;
+  HIPRET(launch_gemm_tr(g, precision, (hipStream_t)stream));
+  HIPRET(launch_wgrad_reduce((const float*)workspace, S, R, ncols, T, Kp, K, dw, (hipStream_t)stream));
+  return NS2_OK;
+}
+
 extern "C" int ns2_film_gate_fwd(const float* h, int64_t ldh, const float* film, int film_ld, int seq_len, int64_t M, int d, float* out,
                                  int64_t ldo, void* stream) {
   ARGCHK(h && film && out, "ns2_film_gate_fwd: null pointer");

@@ -67,12 +67,70 @@ struct KMode {
   static constexpr int kch = bk / 16;                    // 16-deep MFMA K chunks per tile (2 / 4)
 };
 
+// LDS transpose reads of the TR kernel as inline assembly.  Through the builtins (or any load the compiler knows to be an LDS read)
+// the waitcnt pass puts `s_waitcnt vmcnt(0)` in front of reads that follow LDS-DMA instructions -- it cannot tell which DMA wrote
+// what -- and that drains the prefetched half tiles of the NEXT K tiles every phase: the kernel measured 1.4-1.55 x the time of its
+// non-transposed twin (tools/bench_wgrad.py; same time with plain ds_read_b64 in place of the transpose reads).  As assembly the
+// reads are opaque: ordering against the DMA is the phased loop's own counted vmcnt + barrier discipline, and the wait for the
+// reads themselves is one explicit `s_waitcnt lgkmcnt(0)` tied to the accumulators of the quadrant (tr_wait below), so no MFMA can
+// be scheduled above it.
+typedef __attribute__((ext_vector_type(2))) int tr_i2;
+template <int OFF>
+NS2_DEVINL bf16x8 tr16_pair(unsigned a0, unsigned a1) {            // tokens 4 q .. of two 4-token blocks -> one 8-deep MFMA fragment
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  tr_i2 lo, hi2;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi2) : "v"(a1), "n"(OFF) : "memory");
+  return __builtin_bit_cast(bf16x8, make_int4(lo[0], lo[1], hi2[0], hi2[1]));
+}
+template <int OFF>
+NS2_DEVINL bf16x8 tr8_pair(unsigned a) {                           // 2 x 8 tokens of fp8 bytes
+  static_assert(OFF >= 0 && OFF + 1024 < 65536, "ds offset field");
+  tr_i2 lo, hi2;
+  asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(OFF) : "memory");
+  asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(hi2) : "v"(a), "n"(OFF + 1024) : "memory");
+  return __builtin_bit_cast(bf16x8, make_int4(lo[0], lo[1], hi2[0], hi2[1]));
+}
+// fragment J (0..3) of the 32-channel group RT groups (4 KiB each) above the lane addresses a16[plane][q] / a8
+template <int NS, int RT, int J>
+NS2_DEVINL bf16x8 tr_frag_asm(const unsigned (&a16)[2][2], unsigned a8) {
+  if constexpr (NS == 2 && J >= 2) {
+    return tr8_pair<RT * 4096 + (J - 2) * 2048>(a8);
+  } else {
+    constexpr int p = NS == 3 ? (J >> 1) : 0, kc = NS == 3 ? (J & 1) : J;
+    return tr16_pair<RT * 4096 + kc * 2048>(a16[p][0], a16[p][1]);
+  }
+}
+template <int NS, int RT>
+NS2_DEVINL void tr_frag4(bf16x8 (&f)[4], const unsigned (&a16)[2][2], unsigned a8) {
+  f[0] = tr_frag_asm<NS, RT, 0>(a16, a8); f[1] = tr_frag_asm<NS, RT, 1>(a16, a8);
+  f[2] = tr_frag_asm<NS, RT, 2>(a16, a8); f[3] = tr_frag_asm<NS, RT, 3>(a16, a8);
+}
+NS2_DEVINL void tr_wait(f32x16& c0, f32x16& c1) {                 // every transpose read of this wave has landed.  The wait names the two
+  // accumulators of the quadrant, which every MFMA that consumes the fragments reads and writes: none of them can be scheduled above
+  // it.  (Naming the twelve fragment tuples instead cost ~30 register copies per quadrant: the tie of each 4-register tuple fights the
+  // 8-register tuple the fp8 MFMA wants its two halves in.)
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1) :: "memory");
+}
+
 // P1 != 0 (EPI_WAVENET only): the first K phase -- the dilated conv taps -- runs in arithmetic P1 instead of NSPLIT, reading
 // the SAME operands: P1 = 1 under NSPLIT = 2 multiplies the IEEE-half parts of the FMT_H8 lines as one product per
 // contraction (64-deep tiles gathered from two lines), the second phase (res_conv) keeps the correction terms.
-template <int NSPLIT, int EPI, bool F16, int P1 = 0>
+//
+// TR (round 5, weight gradients): BOTH operands are read TRANSPOSED.  dW[r, n] = sum_m dY[m, r] X[m - shift(n), k(n)] contracts over
+// the TOKENS, and the operand planes of the training path are token-major ([M tokens, channels], one 128-B line per token and 32
+// channels) -- rounds 4's wgrad ran this kernel on transposed COPIES written by tplanes passes (18 ms of a 117 ms step at the
+// HBM roof).  Here the source lines go into LDS as they are (LDS row = one token's line of one 32-channel group, row index =
+// channel group * 32 + token, so the half-tile / DMA-piece structure of the phased loop is unchanged) and the fragments are formed
+// by gfx950's LDS transpose reads: ds_read_b64_tr_b16 hands a lane 4 tokens of ITS channel from a [4 tokens][16 channels] block of
+// 16-bit values, ds_read_b64_tr_b8 8 tokens from an [8 tokens][16 channels] block of bytes (semantics probed on the device:
+// tools/probe/tr_probe.hip) -- two reads per 16-deep MFMA fragment, four per 32 fp8 bytes; A and B use the same token -> k
+// assignment, so the permutation inside a k block cancels.  The conv taps of a weight gradient are column blocks of N (tap =
+// n / tr_kp) whose source rows are shifted by (tr_taps - 1 - tap) * dil TOKENS inside the utterance: no shifted copies either.
+template <int NSPLIT, int EPI, bool F16, int P1 = 0, bool TR = false>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const bf16_t* zero_page = g2_zero_page;
+  static_assert(!TR || (EPI == EPI_F32 && P1 == 0 && NSPLIT != 1), "transposed operands: weight gradients (fp32 slots) on interleaved lines");
   static_assert(NSPLIT != 2 || F16, "the mixed mode multiplies IEEE-half operands");
   static_assert(P1 == 0 || (EPI == EPI_WAVENET && P1 == 1 && NSPLIT == 2), "phase-1 override: half product under the mixed mode");
   using ModeMain = KMode<NSPLIT>;
@@ -367,6 +425,21 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const bf16_t* psrc[4][2];      // [A0, A1, B0, B1][piece]: source row pointer at K offset 0
   int pnseq[2][2];               // A pieces: position inside the utterance (-2^30 = row >= M)
   int pldst[4][2];               // LDS byte offset inside a stage (wave-uniform)
+  // TR: a piece = 8 tokens (lane row lrow) of ONE 32-channel group: row group rg = 4 * channel group + token block; psrc = the
+  // channel group's column in this lane's token row of the slice's first K tile (the zero page when the group lies beyond the operand), pnseq = the piece's first token inside a K
+  // tile (A and B), ptshift = the tap shift of a B piece's channel group in tokens
+  int ptok[4][2], ptshift[2][2];
+  bool pvalid[4][2];             // (wave-uniform) the piece's channel group exists in the operand
+  // TR LDS image of a piece (1 KiB = 8 tokens x the 128-B line of one channel group): eight 128-B BLOCKS, each exactly what one
+  // 16-lane transpose group reads as 16 x 8 contiguous bytes, and the two groups of a 32-lane half side by side (256 contiguous
+  // bytes = every bank once: the layout MI355X_MICROARCH.md lists as conflict free for these reads):
+  //   bf16 x3:  block 4 p + 2 tb + tg = [4 tokens 4 tb ..][16 channels 16 tg ..] of plane p (hi / lo)
+  //   FMT_H8:   blocks 0-3 = 2 tb + tg of the half part as above;  blocks 4 + 2 part + tg = [8 tokens][16 channels] bytes of h8 / l8
+  // A DMA lane (block b = lane >> 3, 16-byte unit w = lane & 7) therefore fetches token tr_tokp, logical chunk tr_lchunk of the line:
+  const int tr_b = lane >> 3, tr_w = lane & 7;
+  const bool tr_bytes = (NSPLIT == 2) && tr_b >= 4;
+  const int tr_tokp = tr_bytes ? tr_w : 4 * ((tr_b >> 1) & 1) + (tr_w >> 1);
+  const int tr_lchunk = tr_bytes ? tr_b : ((NSPLIT == 3 ? 4 * (tr_b >> 2) : 0) + 2 * (tr_b & 1) + (tr_w & 1));
 #pragma unroll
   for (int h = 0; h < 4; ++h)
 #pragma unroll
@@ -375,6 +448,25 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       const int rg = (h < 2) ? ((k & 7) + 16 * (k >> 3) + 8 * h) : ((k & 3) + 8 * (k >> 2) + 4 * (h - 2));   // row group: parity == e
       const int row = rg * RPI + lrow;
       pldst[h][e] = (h < 2 ? 0 : REGION) + rg * 1024;
+      if constexpr (TR) {
+        const int cg = rg >> 2;                        // 32-channel group inside the tile: rows cg * 32 ... of the output tile
+        ptok[h][e] = (rg & 3) * 8 + tr_tokp;
+        const long tok = (long)z * g.nkt * 32 + ptok[h][e];      // this lane's token in the slice's first K tile
+        if (h < 2) {
+          const int c0 = (tm * 8 + cg) * 32;           // output row (channel of dY)
+          pvalid[h][e] = c0 < g.lda;
+          psrc[h][e] = pvalid[h][e] ? g.a_hi + pcol(c0, true) + tok * a_rs + tr_lchunk * 8 : zero_page;
+        } else {
+          const int n0 = (tn * 8 + cg) * 32;           // output column: tap * tr_kp + channel of X
+          const int tap = n0 / g.tr_kp, ch = n0 - tap * g.tr_kp;
+          const int sh = g.tr_taps > 0 ? (g.tr_taps - 1 - tap) * dil : 0;
+          ptshift[h - 2][e] = sh;
+          pvalid[h][e] = n0 < g.N;
+          psrc[h][e] = pvalid[h][e] ? g.w_hi + pcol(ch, true) + (tok - sh) * w_rs + tr_lchunk * 8 : zero_page;
+          if (!pvalid[h][e]) ptshift[h - 2][e] = 0;
+        }
+        continue;
+      }
       if (h < 2) {
         const long m = (long)tm * G2_BM + row;
         psrc[h][e] = g.a_hi + pcol((int)(z * g.a_zs), ail) + m * a_rs;
@@ -384,6 +476,14 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       }
     }
 
+  int tr_tok0[4], tr_n0[4];      // TR: per half tile, the first token of the NEXT tile to request and its position inside the utterance
+  long tr_off[4];                //     ... and the element offset of that tile from the slice's first (added to psrc)
+  if constexpr (TR) {
+    const int t0 = z * g.nkt * 32;
+    const int nb = g.seq_len > 0 ? t0 % g.seq_len : 0;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { tr_tok0[h] = t0; tr_n0[h] = nb; tr_off[h] = 0; }
+  }
   struct TileCoord { int tap, it; };
   auto tile_coord = [&](auto mode, int kt) __attribute__((always_inline)) {
     const int tpt = tiles_per_tap(mode);
@@ -402,6 +502,42 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     const bool half = !M::line32 && (g.kt_per_tap & 1) && (c.it == tpt - 1);
     const bool il = (H < 2) ? ail : wil;
     unsigned char* sbase = smem + stage * STAGE;
+    if constexpr (TR) {
+      // Half tile H is requested once per K tile, in tile order: its tokens [tok0, tok0 + 32) and their position n0 inside the
+      // utterance are running (wave-uniform) counters -- no division in the loop -- and the piece pointers advance by 32 token rows.
+      // Almost every tile is "full" (all 32 tokens exist and none of them precedes its utterance's start by less than the tap
+      // shift): its lanes need no test; the others take the per-lane path to the zero page.
+      const int tok0 = tr_tok0[H], n0 = tr_n0[H];
+      const long off = tr_off[H];
+      // wave-uniform: every token of the tile exists and (B side) none of them sits closer to its utterance's start than the largest
+      // tap shift of the two pieces
+      bool full = tok0 + 32 <= g.tr_tokens;
+      if constexpr (H >= 2) {
+        const int shmax = max(ptshift[H - 2][0], ptshift[H - 2][1]);
+        full = full && (shmax == 0 || (n0 >= shmax && n0 + 32 <= g.seq_len));
+      }
+      const bf16_t* p[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) p[e] = psrc[H][e] + (pvalid[H][e] ? off : 0L);      // psrc of a missing channel group = the zero page
+      if (!full) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          bool ok = tok0 + ptok[H][e] < g.tr_tokens;
+          if constexpr (H >= 2) {
+            int n = n0 + ptok[H][e];                                 // position inside the utterance (seq_len >= 32: wraps at most once)
+            if (g.seq_len > 0 && n >= g.seq_len) n -= g.seq_len;
+            ok = ok && (ptshift[H - 2][e] == 0 || n >= ptshift[H - 2][e]);
+          }
+          if (!ok) p[e] = zero_page;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) glds16(p[e], sbase + pldst[H][e]);
+      tr_tok0[H] = tok0 + 32;
+      tr_off[H] = off + 32 * (H < 2 ? a_rs : w_rs);
+      if (g.seq_len > 0) { const int n1 = n0 + 32; tr_n0[H] = n1 >= g.seq_len ? n1 - g.seq_len : n1; }
+      return;
+    }
     int coff[2];
     bool chi[2];
 #pragma unroll
@@ -439,20 +575,60 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     else if constexpr (M::ns == 3) return 4 * (j >> 1) + 2 * (j & 1) + hi;   // plane j >> 1, k chunk j & 1
     else return (j < 2) ? (2 * j + hi) : (w_side ? (6 - 2 * hi + (j - 2)) : (4 + 2 * hi + (j - 2)));   // half k chunks, then [h8|l8] / [l8|h8]
   };
+  // ---- TR fragments.  i16 = lane & 15 = the lane's place in its 16-lane transpose group, tg = (lane >> 4) & 1 = which 16 channels of
+  // the 32-channel group (lanes l31 < 16 / >= 16 = MFMA rows 0-15 / 16-31), hi = the MFMA's k half.
+  //   16-bit read q (0, 1) of k chunk kc of plane p: the group reads block 4 p + 2 q + tg of piece 2 kc + hi (tokens 16 kc + 8 hi + 4 q ..+3);
+  //     the lane receives those 4 tokens of channel 16 tg + i16;
+  //   byte read q (0 .. 3) of part P: block 4 + 2 P + tg of piece q (tokens 8 q .. +7); the lane receives 8 tokens of its channel.
+  // Offsets inside a channel group's 4 pieces (4 KiB): tr16_off[p][q] + kc * 2048, tr8_off[w_side] + q * 1024.
+  int tr16_off[2][2], tr8_off[2];
+  if constexpr (TR) {
+    const int i16 = lane & 15, tg = (lane >> 4) & 1;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) tr16_off[p][q] = hi * 1024 + (4 * p + 2 * q + tg) * 128 + i16 * 8;
+#pragma unroll
+    for (int ws = 0; ws < 2; ++ws) {
+      const int part = ws ? 1 - hi : hi;                                // A: lanes 0-31 h8, 32-63 l8;  W: lanes 0-31 l8, 32-63 h8
+      tr8_off[ws] = (4 + 2 * part + tg) * 128 + i16 * 8;
+    }
+  }
   auto load_a = [&](auto mode, const unsigned char* sa, const int a_off, const int fz, int a, AHalf& A) __attribute__((always_inline)) {
+    if constexpr (TR) {
+      constexpr int NS = decltype(mode)::ns;
+      const unsigned base = (unsigned)(size_t)sa + wm * (4 * 32 * RB);           // LDS byte address of this wave's first channel group
+      const unsigned a16[2][2] = {{base + tr16_off[0][0], base + tr16_off[0][1]}, {base + tr16_off[1][0], base + tr16_off[1][1]}};
+      const unsigned a8 = base + tr8_off[0];
+      if (a == 0) { tr_frag4<NS, 0>(A.f[0], a16, a8); tr_frag4<NS, 1>(A.f[1], a16, a8); }
+      else { tr_frag4<NS, 2>(A.f[0], a16, a8); tr_frag4<NS, 3>(A.f[1], a16, a8); }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
         A.f[i][j] = *reinterpret_cast<const bf16x8*>(sa + a_off + (2 * a + i) * 32 * RB + ((frag_chunk(mode, j, false) ^ fz) * 16));
+      }
   };
   auto load_w = [&](auto mode, const unsigned char* sw, const int w_off, const int fz, int b, WHalf& W) __attribute__((always_inline)) {
+    if constexpr (TR) {
+      constexpr int NS = decltype(mode)::ns;
+      const unsigned base = (unsigned)(size_t)sw + REGION + wn * (2 * 32 * RB);
+      const unsigned a16[2][2] = {{base + tr16_off[0][0], base + tr16_off[0][1]}, {base + tr16_off[1][0], base + tr16_off[1][1]}};
+      const unsigned a8 = base + tr8_off[1];
+      if (b == 0) tr_frag4<NS, 0>(W.f, a16, a8);
+      else tr_frag4<NS, 1>(W.f, a16, a8);
+      return;
+    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
       W.f[j] = *reinterpret_cast<const bf16x8*>(sw + w_off + b * 32 * RB + ((frag_chunk(mode, j, true) ^ fz) * 16));
+    }
   };
   auto mma_quadrant = [&](auto mode, int a, int b, const AHalf& A, const WHalf& W) __attribute__((always_inline)) {
     using M = decltype(mode);
+    if constexpr (TR) tr_wait(acc[2 * a][b], acc[2 * a + 1][b]);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -812,16 +988,29 @@ extern "C" int ns2_debug_read_blocks(unsigned long long* out, int nblk) {
 }
 #endif
 
-template <int NSPLIT, int EPI, bool F16, int P1 = 0>
+template <int NSPLIT, int EPI, bool F16, int P1 = 0, bool TR = false>
 static hipError_t launch2_one(const GemmArgs& g, hipStream_t s) {
   const int ntn = (g.N + G2_BN - 1) / G2_BN, ntm = (g.M + G2_BM - 1) / G2_BM;
   const int nz = g.nz > 0 ? g.nz : 1;
   const size_t lds = 8 * EPI_LDS_WAVE_BYTES;          // 144 KiB: 2 x 64 KiB K stages, reused as 8 x 18 KiB epilogue regions
   static DynLdsAttr attr;
-  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, F16, P1>), (int)lds);
+  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, F16, P1, TR>), (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, F16, P1>), dim3(ntn * ntm * nz), dim3(512), lds, s, g);
+  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, F16, P1, TR>), dim3(ntn * ntm * nz), dim3(512), lds, s, g);
   return hipGetLastError();
+}
+
+// Weight gradient straight from the token-major operand planes (the TR kernel above): out_f[z][r][n] = sum over the tokens of K
+// slice z of dY[m, r] X[m - shift(n), k(n)].  g: a = dY planes [tr_tokens, lda], w = X planes [tr_tokens, ldw], M = R output rows,
+// N = taps * tr_kp output columns, nkt = 32-token K tiles PER SLICE, nz = slices, out_f / out_f_zs / ldo_f = the fp32 slots.
+hipError_t launch_gemm_tr(const GemmArgs& g, int precision, hipStream_t s) {
+  if (precision != 3 && precision != 4) return hipErrorInvalidValue;
+  if (!g.a_hi || g.a_lo != g.a_hi + 32 || !g.w_hi || g.w_lo != g.w_hi + 32 || !g.out_f) return hipErrorInvalidValue;
+  if (g.M <= 0 || g.N <= 0 || g.nkt <= 0 || g.kt_per_tap != g.nkt || g.conv_taps != 0 || g.epi != EPI_F32 || g.nz < 1) return hipErrorInvalidValue;
+  if (g.tr_tokens <= 0 || g.tr_kp <= 0 || (g.tr_kp & 31) || (g.lda & 31) || (g.ldw & 31) || g.tr_taps < 0) return hipErrorInvalidValue;
+  if (g.tr_taps > 1 && (g.seq_len < 32 || g.dil < 1)) return hipErrorInvalidValue;      // the in-tile utterance position wraps at most once
+  if ((long)g.nz * g.nkt * 32 < g.tr_tokens) return hipErrorInvalidValue;                // the slices cover every token
+  return precision == 3 ? launch2_one<3, EPI_F32, false, 0, true>(g, s) : launch2_one<2, EPI_F32, true, 0, true>(g, s);
 }
 
 template <int NSPLIT, bool F16>

@@ -256,6 +256,23 @@ class HipBackend:
                                  nbytes, self.prec, _s()), "ns2_wgrad")
         return dw
 
+    def wgrad_rows_ok(self, R, T, K, seq_len, M):
+        """does ns2_wgrad_rows form this gradient from the token-major planes (else: transposed copies + ns2_wgrad)"""
+        return (T == 1 or seq_len >= 32) and bool(self.lib.ns2_wgrad_rows_preferred(R, T * round_up(K, 32), M))
+
+    def wgrad_rows(self, dy, x, R, T, K, dil=1, seq_len=0):
+        """dW [R, K, T] = sum_m dY[m, r] X[m - (T - 1 - t) dil, k] from the ROW planes dy [M, >= R] and x [M, >= round_up(K, 32)] themselves
+        (gemm2.hip TR: LDS transpose reads; the shifts of a conv's taps are row offsets of the loads)"""
+        Kp = round_up(K, 32)
+        assert dy.precision == x.precision == self.prec and dy.rows == x.rows, "wgrad operands must be planes of the same tokens in the backend's GEMM format"
+        M = dy.rows
+        nbytes = self.lib.ns2_wgrad_workspace_bytes(R, T * Kp, round_up(M, 32))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+        dw = torch.empty(R, K, T, dtype=torch.float32, device=dy.device)
+        check(self.lib.ns2_wgrad_rows(dy.hi, dy.lo, dy.ld, x.hi, x.lo, x.ld, M, R, T, Kp, K, dil, seq_len if T > 1 else 0, dw.data_ptr(), ws.data_ptr(),
+                                      nbytes, self.prec, _s()), "ns2_wgrad_rows")
+        return dw
+
     def film_gate_bwd(self, dg, h, film, B, seq_len, d):
         S = self.lib.ns2_film_gate_slices(seq_len)
         dh = torch.empty(h.shape[0], d, dtype=torch.float32, device=h.device)
@@ -439,6 +456,23 @@ def _dw(dw, w):
     return dw if w.ndim == 3 else dw[:, :, 0]
 
 
+def _grads(bk, dy, C, xp, K, taps=0, dil=1, seq_len=0, need_row=True, need_w=True, need_b=False):
+    """what the backward of y = conv_or_linear(x) (+ b) needs from dy fp32 [M, >= C]: its row planes (the dgrad GEMM's operand), the
+    weight gradient dW [C, K, T] against xp = the operand planes the forward GEMM read, the bias gradient.  The weight gradient comes
+    from the row planes themselves where the kernel can (ns2_wgrad_rows: LDS transpose reads), else through transposed copies
+    (narrow gradients: the dim = 128 model).  -> (dy_row or None, dW or None, db or None)"""
+    T = max(taps, 1)
+    if need_w and bk.wgrad_rows_ok(C, T, K, seq_len, dy.shape[0]):
+        row, _, db = bk.grad_prep(dy, C, want_row=True, want_colsum=need_b)
+        return row, bk.wgrad_rows(row, xp, C, T, K, dil, seq_len), db
+    row, dy_t, db = bk.grad_prep(dy, C, want_row=need_row, want_t=need_w, want_colsum=need_b)
+    dw = None
+    if need_w:
+        xt = bk.transpose(xp, 0, round_up(K, 32), seq_len if taps else 0, _shifts(taps, dil))
+        dw = bk.wgrad(dy_t, xt, C, T, K)
+    return row, dw, db
+
+
 # =============================================================================================== Functions
 class GemmFn(torch.autograd.Function):
     """y = conv_or_linear(x) + b (+ resid);  x [M, Cin] fp32, w [Cout, Cin(, k)], causal with dilation `dil` inside utterances of
@@ -464,11 +498,8 @@ class GemmFn(torch.autograd.Function):
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
         # (frozen weights / a gradient wanted for the input only -- guidance: no wgrad GEMM, no transposes, no workspace: ADVICE r4)
         need_w, need_b = ctx.needs_input_grad[1], b is not None and ctx.needs_input_grad[2]
-        dy_row, dy_t, db = bk.grad_prep(dy, cout, want_row=ctx.needs_input_grad[0], want_t=need_w, want_colsum=need_b)
-        dw = None
-        if need_w:
-            xt = bk.transpose(ctx.xp, 0, cin, seq_len if taps else 0, _shifts(taps, dil))
-            dw = _dw(bk.wgrad(dy_t, xt, cout, max(taps, 1), cin), w)
+        dy_row, dw, db = _grads(bk, dy, cout, ctx.xp, cin, taps, dil, seq_len, need_row=ctx.needs_input_grad[0], need_w=need_w, need_b=need_b)
+        dw = _dw(dw, w) if need_w else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = bk.gemm_f32(_bwd_pack(bk, w), dy_row, taps=taps, dil=dil, seq_len=seq_len if taps else 0, pad_left=0 if taps else -1)[:, :cin]
@@ -499,16 +530,21 @@ class WavenetBlockFn(torch.autograd.Function):
         B = dout.shape[0] // seq_len
         dout = dout if dout.stride(1) == 1 else dout.contiguous()
         ng = ctx.needs_input_grad                                           # (u, film, wc, bc, wr, br, -, -)
-        dout_row, dout_t, dbr = bk.grad_prep(dout, d, want_row=True, want_t=ng[4], want_colsum=ng[5])
-        dhc, dfilm = bk.film_gate_bwd(dout, hc, film, B, seq_len, d)
-        dhc_row, dhc_t, dbc = bk.grad_prep(dhc, d, want_row=True, want_t=ng[2], want_colsum=ng[3])
-        dwc = dwr = None
-        if ng[2] or ng[4]:
-            xt = bk.transpose(ctx.up, 0, d, seq_len, _shifts(3, dil))       # taps 0, 1, 2: shifts 2 dil, dil, 0
-            if ng[2]:
-                dwc = bk.wgrad(dhc_t, xt, d, 3, d)
-            if ng[4]:
-                dwr = bk.wgrad(dout_t, xt, d, 1, d, row_off=2 * round_up(d, 32))    # res_conv reads the unshifted block (tap 2)
+        if bk.wgrad_rows_ok(d, 3, d, seq_len, dout.shape[0]) and bk.wgrad_rows_ok(d, 1, d, seq_len, dout.shape[0]):
+            dout_row, dwr, dbr = _grads(bk, dout, d, ctx.up, d, 1, 1, seq_len, need_w=ng[4], need_b=ng[5])
+            dhc, dfilm = bk.film_gate_bwd(dout, hc, film, B, seq_len, d)
+            dhc_row, dwc, dbc = _grads(bk, dhc, d, ctx.up, d, 3, dil, seq_len, need_w=ng[2], need_b=ng[3])
+        else:                                                               # narrow model: transposed copies, one set for both gradients
+            dout_row, dout_t, dbr = bk.grad_prep(dout, d, want_row=True, want_t=ng[4], want_colsum=ng[5])
+            dhc, dfilm = bk.film_gate_bwd(dout, hc, film, B, seq_len, d)
+            dhc_row, dhc_t, dbc = bk.grad_prep(dhc, d, want_row=True, want_t=ng[2], want_colsum=ng[3])
+            dwc = dwr = None
+            if ng[2] or ng[4]:
+                xt = bk.transpose(ctx.up, 0, d, seq_len, _shifts(3, dil))       # taps 0, 1, 2: shifts 2 dil, dil, 0
+                if ng[2]:
+                    dwc = bk.wgrad(dhc_t, xt, d, 3, d)
+                if ng[4]:
+                    dwr = bk.wgrad(dout_t, xt, d, 1, d, row_off=2 * round_up(d, 32))    # res_conv reads the unshifted block (tap 2)
         du = bk.gemm_f32(_bwd_pack(bk, wc), dhc_row, taps=3, dil=dil, seq_len=seq_len, pad_left=0)
         du = bk.gemm_f32(_bwd_pack(bk, wr), dout_row, resid=du, taps=1, dil=1, seq_len=seq_len, pad_left=0)
         return du[:, :d], *_un(ctx, dfilm, dwc, dbc, dwr, dbr), None, None
@@ -553,8 +589,8 @@ class AttnFn(torch.autograd.Function):
         B, a = M // seq_len, heads * 64
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
         ng = ctx.needs_input_grad                                           # (h, film, ctxt, wq, wkv, wout, ...)
-        dy_row, dy_t, _ = bk.grad_prep(dy, d, want_row=True, want_t=ng[5])
-        dwout = bk.wgrad(dy_t, bk.transpose(o, 0, a, 0), d, 1, a)[:, :, 0] if ng[5] else None
+        dy_row, dwout, _ = _grads(bk, dy, d, o, a, need_w=ng[5])
+        dwout = dwout[:, :, 0] if ng[5] else None
         do = bk.gemm_f32(_bwd_pack(bk, wout), dy_row)                       # [M, a]
         delta = bk.attention_delta(do, o, B, heads, seq_len)
         do_row, do_tb, _ = bk.grad_prep(do, a, want_row=True, want_t=True, seq_len=seq_len, per_batch=True, attn=True)
@@ -564,11 +600,10 @@ class AttnFn(torch.autograd.Function):
             dqkv = torch.empty(M, 3 * a, dtype=torch.float32, device=h.device)
             bk.attention_bwd(q, qc, k, kc, v, vc, do_row, kt, qt, do_tb, lse, delta, B, heads, seq_len, Nk, dq=(dqkv, 0), dkv=(dqkv, a, 2 * a))
             need_w = ng[3] or ng[4]
-            g_row, g_t, _ = bk.grad_prep(dqkv, 3 * a, want_row=True, want_t=need_w)
+            g_row, dwqkv, _ = _grads(bk, dqkv, 3 * a, xn, d, need_w=need_w)
             dwq = dwkv = None
             if need_w:
-                dwqkv = bk.wgrad(g_t, bk.transpose(xn, 0, d, 0), 3 * a, 1, d)[:, :, 0]
-                dwq, dwkv = dwqkv[:a], dwqkv[a:]
+                dwq, dwkv = dwqkv[:a, :, 0], dwqkv[a:, :, 0]
             wqkv = bk.pack(("qkv_b", id(wq), id(wkv)), (wq, wkv), lambda: torch.cat((wq.detach(), wkv.detach()), 0).t())
             dxn = bk.gemm_f32(wqkv, g_row)
             dctx = None
@@ -576,11 +611,11 @@ class AttnFn(torch.autograd.Function):
             dq = torch.empty(M, a, dtype=torch.float32, device=h.device)
             dkv = torch.empty(B * Nk, 2 * a, dtype=torch.float32, device=h.device)
             bk.attention_bwd(q, qc, k, kc, v, vc, do_row, kt, qt, do_tb, lse, delta, B, heads, seq_len, Nk, dq=(dq, 0), dkv=(dkv, 0, a))
-            q_row, q_t, _ = bk.grad_prep(dq, a, want_row=True, want_t=ng[3])
-            dwq = bk.wgrad(q_t, bk.transpose(xn, 0, d, 0), a, 1, d)[:, :, 0] if ng[3] else None
+            q_row, dwq, _ = _grads(bk, dq, a, xn, d, need_w=ng[3])
+            dwq = dwq[:, :, 0] if ng[3] else None
             dxn = bk.gemm_f32(_bwd_pack(bk, wq), q_row)
-            kv_row, kv_t, _ = bk.grad_prep(dkv, 2 * a, want_row=ng[2], want_t=ng[4])
-            dwkv = bk.wgrad(kv_t, bk.transpose(cp, 0, d, 0), 2 * a, 1, d)[:, :, 0] if ng[4] else None
+            kv_row, dwkv, _ = _grads(bk, dkv, 2 * a, cp, d, need_row=ng[2], need_w=ng[4])
+            dwkv = dwkv[:, :, 0] if ng[4] else None
             dctx = bk.gemm_f32(_bwd_pack(bk, wkv), kv_row)[:, :d] if ng[2] else None
         if film is None:
             dh, dfilm = dy[:, :d] + dxn[:, :d], None
@@ -619,19 +654,18 @@ class FeedForwardFn(torch.autograd.Function):
         B = M // seq_len
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
         ng = ctx.needs_input_grad                                           # (h, film, w1, b1, wc, bc, w2, b2, -)
-        dy_row, dy_t, db2 = bk.grad_prep(dy, d, want_row=True, want_t=ng[6], want_colsum=ng[7])
-        dw2 = bk.wgrad(dy_t, bk.transpose(cp, 0, round_up(f, 32), 0), d, 1, f)[:, :, 0] if ng[6] else None
+        dy_row, dw2, db2 = _grads(bk, dy, d, cp, f, need_w=ng[6], need_b=ng[7])
+        dw2 = dw2[:, :, 0] if ng[6] else None
         dc = bk.gemm_f32(_bwd_pack(bk, w2), dy_row)                         # [M, f]
         dwc = dbc = None
         if wc is not None:
-            dc_row, dc_t, dbc = bk.grad_prep(dc, f, want_row=True, want_t=ng[4], want_colsum=ng[5])
-            dwc = bk.wgrad(dc_t, bk.transpose(hp, 0, round_up(f, 32), seq_len, _shifts(3, 1)), f, 3, f) if ng[4] else None
+            dc_row, dwc, dbc = _grads(bk, dc, f, hp, f, 3, 1, seq_len, need_w=ng[4], need_b=ng[5])
             dhh = bk.gemm_f32(_bwd_pack(bk, wc), dc_row, taps=3, dil=1, seq_len=seq_len, pad_left=0)
         else:
             dhh = dc
         dpre = bk.geglu_bwd(dhh, pre, f)                                    # [M, 2 f]
-        p_row, p_t, db1 = bk.grad_prep(dpre, 2 * f, want_row=True, want_t=ng[2], want_colsum=ng[3])
-        dw1 = bk.wgrad(p_t, bk.transpose(xn, 0, d, 0), 2 * f, 1, d)[:, :, 0] if ng[2] else None
+        p_row, dw1, db1 = _grads(bk, dpre, 2 * f, xn, d, need_w=ng[2], need_b=ng[3])
+        dw1 = dw1[:, :, 0] if ng[2] else None
         dxn = bk.gemm_f32(_bwd_pack(bk, w1), p_row)
         if film is None:
             dh, dfilm = dy[:, :d] + dxn[:, :d], None
@@ -659,8 +693,8 @@ class NormLinearFn(torch.autograd.Function):
         h, gamma, w = ctx.saved_tensors
         M, d = h.shape
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
-        dy_row, dy_t, _ = bk.grad_prep(dy, w.shape[0], want_row=True, want_t=ctx.needs_input_grad[2])
-        dw = bk.wgrad(dy_t, bk.transpose(ctx.xn, 0, d, 0), w.shape[0], 1, d)[:, :, 0] if ctx.needs_input_grad[2] else None
+        dy_row, dw, _ = _grads(bk, dy, w.shape[0], ctx.xn, d, need_w=ctx.needs_input_grad[2])
+        dw = dw[:, :, 0] if ctx.needs_input_grad[2] else None
         dxn = bk.gemm_f32(_bwd_pack(bk, w), dy_row)
         dh, _, dgamma = bk.rmsnorm_bwd(h, dxn, M // ctx.seq_len, ctx.seq_len, d, gamma=gamma)
         return dh, *_un(ctx, dgamma, dw), None

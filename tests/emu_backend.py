@@ -191,6 +191,20 @@ class EmuBackend:
             dw[:, :, t] = dyt.t[:R] @ xt.t[row_off + t * Kp:row_off + t * Kp + K].t()
         return dw
 
+    # the emulation forms weight gradients from the row planes only for wide gradients, like the library (ns2_wgrad_rows_preferred)
+    def wgrad_rows_ok(self, R, T, K, seq_len, M):
+        return T * rup(K, 32) > 128 and (T == 1 or seq_len >= 32)       # (the library also asks for enough 256 x 256 tiles: a speed rule)
+
+    def _mm_t(self, a_t, b):
+        return a_t @ b
+
+    def wgrad_rows(self, dy, x, R, T, K, dil=1, seq_len=0):
+        assert dy.rows == x.rows
+        dw = torch.zeros(R, K, T)
+        for t in range(T):
+            dw[:, :, t] = self._mm_t(dy.t[:, :R].t(), self._shifted(x.t[:, :K], seq_len if T > 1 else 0, (T - 1 - t) * dil))
+        return dw
+
     def film_gate_bwd(self, dg, h, film, B, seq_len, d):
         hh = h[:, :d].reshape(B, seq_len, d)
         z = hh * film[:, None, :d] + film[:, None, d:2 * d]
@@ -296,3 +310,6 @@ class MixedEmuBackend(EmuBackend):
         for t in range(T):
             dw[:, :, t] = self._mm(dyt.t[:R], xt.t[row_off + t * Kp:row_off + t * Kp + K].t())
         return dw
+
+    def _mm_t(self, a_t, b):
+        return self._mm(a_t, b)

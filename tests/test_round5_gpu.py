@@ -264,3 +264,36 @@ def test_seanet_resblock_narrow_matches_hf(B, T, inp):
     # another width is not served: nothing launched, the caller takes the GEMM path
     assert lib.ns2_seanet_resblock_narrow(x.data_ptr(), 32, inp, B, T, 48, nr["w1p"].data_ptr(), nr["b1"].data_ptr(), nr["w2p"].data_ptr(),
                                           nr["wsp"].data_ptr(), nr["b2s"].data_ptr(), y.data_ptr(), 32, torch.cuda.current_stream().cuda_stream) == _lib.NS2_UNAVAILABLE
+
+
+# ------------------------------------------------------------------------------------------------ weight gradients from the row planes
+# ("wgrad operands through LDS transpose loads ... delete the tplanes passes".  gemm2.hip TR reads both operands of
+# dW = dY^T X from the token-major planes with ds_read_b64_tr_b16 / _tr_b8; the conv taps are row offsets of the loads.)
+HB3 = training.HipBackend(3)
+
+
+@pytest.mark.parametrize("prec", [3, 4])
+@pytest.mark.parametrize("R,K,T,M,dil,seq", [(512, 512, 1, 4096, 1, 0), (300, 200, 1, 1000, 1, 0), (64, 64, 3, 480, 2, 160), (1365, 1365, 3, 2048, 1, 1024),
+                                             (512, 512, 3, 4096, 64, 1024), (128, 512, 1, 2048, 1, 0), (1536, 512, 1, 32768, 1, 0),
+                                             (96, 96, 3, 777 * 2, 5, 777)])
+def test_wgrad_from_row_planes(prec, R, K, T, M, dil, seq):
+    hb = HB3 if prec == 3 else HB4
+    dy = make_input("wr_dy", (M, R), seed=5) * 0.5
+    x = make_input("wr_x", (M, rup(K, 32) + 32), seed=6)                 # operand planes wider than K: the columns beyond are another tensor's
+    x[:, K:rup(K, 32)] = 0
+    dyp, xp = hb.split(dy.to(DEV)), hb.split(x.to(DEV))
+    dw = hb.wgrad_rows(dyp, xp, R, T, K, dil, seq).cpu()
+    # reference: the same rounded operand values (what the planes hold), wide accumulation
+    dyr, xr = pjoin(dyp)[:, :R], pjoin(xp)[:, :K]
+    ref = torch.zeros(R, K, T, dtype=torch.float64)
+    for t in range(T):
+        ref[:, :, t] = dyr.double().t() @ EB._shifted(xr, seq if T > 1 else 0, (T - 1 - t) * dil).double()
+    assert dw.shape == (R, K, T)
+    e = rel(dw, ref)
+    assert e < (2e-5 if prec == 3 else 1e-4), e                           # bf16 x3: ~2^-16 per product; mixed: first-order terms in e5m2
+    assert torch.equal(dw, hb.wgrad_rows(dyp, xp, R, T, K, dil, seq).cpu())            # fixed slots, fixed order
+    # and against the transposed route (same operands, same arithmetic, another order of the fp32 sums)
+    _, dyt, _ = hb.grad_prep(dy.to(DEV), R, want_t=True)
+    xt = hb.transpose(xp, 0, rup(K, 32), seq if T > 1 else 0, tuple((T - 1 - t) * dil for t in range(T)))
+    old = hb.wgrad(dyt, xt, R, T, K).cpu()
+    assert rel(dw, old) < (2e-6 if prec == 3 else 2e-5), rel(dw, old)
