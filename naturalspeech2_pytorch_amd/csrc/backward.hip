@@ -15,6 +15,7 @@
 //     (dQ: a workgroup owns 128 queries and walks the keys; dK/dV: owns 128 keys and walks the queries), the same swapped
 //     MFMA products and LDS tile shapes as attention.hip.
 // Arithmetic: bf16 hi/lo planes, hi*hi + hi*lo + lo*hi (precision 3, "exact"): gradients are fp32-class like the forward.
+#include <cstdlib>
 #include "ns2_common.h"
 #include "ns2_kernels.h"
 
@@ -755,6 +756,282 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnBwdArgs a) {
     }
 }
 
+// ---- Flash backward, round 5: the same arithmetic as attn_bwd_kernel above (products, operand order, fp32 sums: results are bit
+// identical), other data movement.  The round-4 kernel staged FOUR tiles per 64 walked rows through registers into a single LDS
+// buffer -- Y, Yg row-major and Y1T (, Y2T) from TRANSPOSED copies of the same tensors that tplanes passes had written per utterance
+// -- between two barriers: nothing overlapped the loads but the other workgroup of the CU, and the kernel ran at 5 x the forward.
+// Here: (1) only the row-major tiles are fetched; the transposed fragments (K^T for dQ; Q^T, dO^T for dK / dV) are read out of the SAME
+// LDS tiles with ds_read_b64_tr_b16 (a lane receives 4 walked rows of ITS d column from a [4 rows][16 d] block; two reads = one 8-deep
+// MFMA fragment) -- half the bytes per tile, and the per-utterance transposes of q, k and dO disappear from the step; (2) the tiles
+// go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers) into TWO stages: the tile t + 1 is requested before
+// the products of tile t and has their whole duration to land; one barrier per tile.
+// LDS image of a tile: 64 rows x 256 B, a row = the head's 64 columns of one token exactly as they lie in memory
+// [hi 0-31 | lo 0-31 | hi 32-63 | lo 32-63] = 16 chunks of 16 B; chunk c of row r is stored at c ^ f(r), f(r) = ((r & 3) << 2) |
+// ((r >> 2) & 3): the 16 rows of a ds_read_b128 group (same chunk) spread over all 16 positions, and the 4 rows of a transpose
+// block (4 adjacent chunks) over the four 64-B quarters -- both conflict free.  A DMA instruction moves 4 rows (8 full lines).
+__device__ __attribute__((aligned(256))) bf16_t ab2_zero_page[128];
+__device__ float ab2_inf_zero[2] = {INFINITY, 0.f};      // the statistics of a query beyond Nq: lse = +inf (P = 0), delta = 0
+typedef __attribute__((address_space(3))) void ab2_lds_void_t;
+typedef const __attribute__((address_space(1))) void ab2_gbl_void_t;
+typedef __attribute__((ext_vector_type(4))) short ab2_v4s;
+typedef __attribute__((address_space(3))) ab2_v4s ab2_lds_v4s_t;
+constexpr int AB2_ROW = 256, AB2_MAT = 64 * AB2_ROW, AB2_STAGE = 2 * AB2_MAT;
+NS2_DEVINL int ab2_f(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+template <int ROLE>
+__global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_stat = reinterpret_cast<float*>(smem + 2 * AB2_STAGE);       // [stage][lse 64 | delta 64] (role 1)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int Nown = ROLE == 0 ? a.Nq : a.Nk, Nwalk = ROLE == 0 ? a.Nk : a.Nq;
+  const int nown_t = (Nown + 127) / 128;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ot = bid % nown_t;
+  bid /= nown_t;
+  const int h = bid % a.H, b = bid / a.H;
+  const int orow = ot * 128 + wave * 32 + l31;
+  const bool own_ok = orow < Nown;
+
+  // own-side fragments (B operands): X = Q (role 0) / K (role 1); G = dO (role 0) / V (role 1)
+  const bf16_t* xb = ROLE == 0 ? a.q_hi : a.k_hi;
+  const int ldx = ROLE == 0 ? a.ldq : a.ldk, xcol = ROLE == 0 ? a.q_col0 : a.k_col0;
+  const bf16_t* gb = ROLE == 0 ? a.do_hi : a.v_hi;
+  const int ldg = ROLE == 0 ? a.lddo : a.ldv, gcol = ROLE == 0 ? 0 : a.v_col0;
+  bf16x8 xf[2][4], gf[2][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint4 vx = make_uint4(0u, 0u, 0u, 0u), vg = make_uint4(0u, 0u, 0u, 0u);
+      if (own_ok) {
+        vx = *reinterpret_cast<const uint4*>(xb + ((long)b * Nown + orow) * 2L * ldx + pcol(xcol + h * 64 + 16 * c + 8 * hi, true) + 32 * p);
+        vg = *reinterpret_cast<const uint4*>(gb + ((long)b * Nown + orow) * 2L * ldg + pcol(gcol + h * 64 + 16 * c + 8 * hi, true) + 32 * p);
+      }
+      xf[p][c] = *reinterpret_cast<bf16x8*>(&vx);
+      gf[p][c] = *reinterpret_cast<bf16x8*>(&vg);
+    }
+  float lse_own = INFINITY, del_own = 0.f;
+  if (ROLE == 0 && own_ok) {
+    lse_own = a.lse[((long)b * a.H + h) * a.Nq + orow];
+    del_own = a.delta[((long)b * a.H + h) * a.Nq + orow];
+  }
+
+  // walked-side sources (row-major): Y (scores; transposed for acc1), Yg (dP; role 1: transposed for acc2)
+  const bf16_t* yb = ROLE == 0 ? a.k_hi : a.q_hi;
+  const int ldy = ROLE == 0 ? a.ldk : a.ldq, ycol = ROLE == 0 ? a.k_col0 : a.q_col0;
+  const bf16_t* ygb = ROLE == 0 ? a.v_hi : a.do_hi;
+  const int ldyg = ROLE == 0 ? a.ldv : a.lddo, ygcol = ROLE == 0 ? a.v_col0 : 0;
+
+  // ---- DMA pieces: instruction j = 8 wave + i of the tile's 32 (matrix j >> 4, tile rows 4 (j & 15) ...); the lane's row = .. + (lane >> 4),
+  // stored position lane & 15, i.e. it fetches logical chunk (lane & 15) ^ f(row); f(row) = ((lane >> 4) << 2) | (i & 3)
+  const int drow = lane >> 4, dpos = lane & 15;
+  const bf16_t* dsrc[8];           // source of tile 0 (advanced by 64 rows per tile)
+  int dtr[8];                      // tile row of the lane
+  const long ystep = 64L * 2 * ldy, ygstep = 64L * 2 * ldyg;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = 8 * wave + i, mat = j >> 4;
+    const int tr = 4 * (j & 15) + drow;
+    const int lc = dpos ^ ((drow << 2) | (i & 3));
+    dtr[i] = tr;
+    dsrc[i] = mat == 0 ? yb + ((long)b * Nwalk + tr) * 2L * ldy + pcol(ycol + h * 64, true) + lc * 8
+                       : ygb + ((long)b * Nwalk + tr) * 2L * ldyg + pcol(ygcol + h * 64, true) + lc * 8;
+  }
+  auto issue_tile = [&](int t, int stage) __attribute__((always_inline)) {
+    const int r0 = t * 64;
+    const bool full = r0 + 64 <= Nwalk;
+    unsigned char* sb = smem + stage * AB2_STAGE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = 8 * wave + i;
+      const bf16_t* p = dsrc[i] + (long)t * ((j >> 4) == 0 ? ystep : ygstep);
+      if (!full && r0 + dtr[i] >= Nwalk) p = ab2_zero_page;                       // rows beyond Nwalk are zeros (as in the staged kernel)
+      // As inline assembly: behind the builtin the waitcnt pass assumes every later LDS read may alias the DMA's destination and puts
+      // `s_waitcnt vmcnt(0)` in front of the first read of the tile being multiplied -- the prefetch would be waited for at once.
+      // The ordering that matters (this wave's vmcnt(0) + the barrier at the top of the next iteration) is explicit below.
+      const unsigned dst = (unsigned)(size_t)(sb + (j >> 4) * AB2_MAT + (j & 15) * 1024);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(p), "s"(dst) : "memory", "m0");
+    }
+    if constexpr (ROLE == 1) {
+      // the 64 queries' lse (wave 0) and delta (wave 1) travel the same way, 4 bytes per lane: an ordinary load here would sit in the
+      // same in-order queue BEHIND the pieces above, and the compiler's wait for it would wait for them too
+      if (wave < 2) {
+        const int q = r0 + lane;
+        const float* p = q < a.Nq ? (wave == 0 ? a.lse : a.delta) + ((long)b * a.H + h) * a.Nq + q : ab2_inf_zero + wave;
+        const unsigned dst = (unsigned)(size_t)(s_stat + stage * 128 + wave * 64);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(p), "s"(dst) : "memory", "m0");
+      }
+    }
+  };
+
+  // ---- fragment addressing
+  const int pi_row = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+  const int fy = ab2_f(pi_row);                    // (js * 32 does not touch bits 0-3)
+  const int y_row_off = pi_row * AB2_ROW;
+  // transpose reads: i16 = the lane's place in its 16-lane group, tg = which 16 d columns of the 32 (l31 = 16 tg + i16 = the d it receives).
+  // read q (0, 1) of (js, g1): supplies row 32 js + 16 g1 + 8 hi + 4 q + (i16 >> 2), d columns 16 tg + 4 (i16 & 3) .. + 3 of plane p, 32-column half dt
+  const int i16 = lane & 15, tg = (lane >> 4) & 1;
+  int t_off[2][2][2];                              // [q][dt][p]: byte offset inside a matrix, rows 32 js + 16 g1 to be added
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = 8 * hi + 4 * q + (i16 >> 2);
+    const int f = ab2_f(row);                      // (32 js + 16 g1 does not touch bits 0-3)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int lc = dt * 8 + p * 4 + 2 * tg + ((i16 >> 1) & 1);
+        t_off[q][dt][p] = row * AB2_ROW + ((lc ^ f) << 4) + (i16 & 1) * 8;
+      }
+  }
+  auto tfrag = [&](const unsigned char* mat, int js, int g1, int dt, int p) __attribute__((always_inline)) {
+    const unsigned char* base = mat + (32 * js + 16 * g1) * AB2_ROW;
+    const ab2_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ab2_lds_v4s_t*)(base + t_off[0][dt][p]));
+    const ab2_v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ab2_lds_v4s_t*)(base + t_off[1][dt][p]));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+  };
+
+  f32x16 acc1[2], acc2[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc1[dt][r] = 0.f; acc2[dt][r] = 0.f; }
+  const float sl2 = a.scale * 1.4426950408889634f;
+  const int ntiles = (Nwalk + 63) / 64;
+
+  // ---- prologue: tile 0 (and its per-query statistics, role 1)
+  // The own-side fragments are complete BEFORE the loop, as far as the compiler can see: a wait of its own for one of these loads
+  // inside the loop (it places them lazily, in front of the first use) would be `vmcnt(small)` -- and would drain the prefetched tile
+  // in every iteration, since the DMA pieces are younger entries of the same in-order queue that it does not know about.
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) asm volatile("" :: "v"(xf[p][c]), "v"(gf[p][c]));
+  issue_tile(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int r0 = t * 64, st = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t have landed
+    __syncthreads();                                       // ... everybody's have; everybody is done with tile t - 1 (stage st ^ 1 is free)
+    if (t + 1 < ntiles) issue_tile(t + 1, st ^ 1);
+    const unsigned char* my = smem + st * AB2_STAGE;      // Y
+    const unsigned char* myg = my + AB2_MAT;               // Yg
+    const float* c_lse = s_stat + st * 128;
+    const float* c_del = c_lse + 64;
+
+#pragma unroll
+    for (int js = 0; js < 2; ++js) {
+      f32x16 stt, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { stt[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x8 yf[2], ygf[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int off = js * 32 * AB2_ROW + y_row_off + ((((c >> 1) * 8 + p * 4 + 2 * (c & 1) + hi) ^ fy) << 4);
+          yf[p] = *reinterpret_cast<const bf16x8*>(my + off);
+          ygf[p] = *reinterpret_cast<const bf16x8*>(myg + off);
+        }
+        stt = mma16<false>(yf[1], xf[0][c], stt);
+        stt = mma16<false>(yf[0], xf[1][c], stt);
+        stt = mma16<false>(yf[0], xf[0][c], stt);
+        dp = mma16<false>(ygf[1], gf[0][c], dp);
+        dp = mma16<false>(ygf[0], gf[1][c], dp);
+        dp = mma16<false>(ygf[0], gf[0][c], dp);
+      }
+      // ---- P and dS for (own row = lane, walked row = register): register r <-> walked row r0 + 32 js + 16 (r >> 3) + 8 hi + (r & 7)
+      float pv[16], dsv[16];
+#pragma unroll
+      for (int g1 = 0; g1 < 2; ++g1) {
+        float ls[8], dl[8];
+        if constexpr (ROLE == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ls[e] = lse_own; dl[e] = del_own; }
+        } else {
+          const int w0 = 32 * js + 16 * g1 + 8 * hi;
+          const float4 l0 = *reinterpret_cast<const float4*>(c_lse + w0), l1 = *reinterpret_cast<const float4*>(c_lse + w0 + 4);
+          const float4 d0 = *reinterpret_cast<const float4*>(c_del + w0), d1 = *reinterpret_cast<const float4*>(c_del + w0 + 4);
+          ls[0] = l0.x; ls[1] = l0.y; ls[2] = l0.z; ls[3] = l0.w; ls[4] = l1.x; ls[5] = l1.y; ls[6] = l1.z; ls[7] = l1.w;
+          dl[0] = d0.x; dl[1] = d0.y; dl[2] = d0.z; dl[3] = d0.w; dl[4] = d1.x; dl[5] = d1.y; dl[6] = d1.z; dl[7] = d1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = 8 * g1 + e;
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(stt[r], sl2, -ls[e]));
+          if (ROLE == 0 && r0 + 32 * js + 16 * g1 + 8 * hi + e >= Nwalk) p = 0.f;      // keys beyond Nk (role 1: lse = +inf did it)
+          pv[r] = p;
+          dsv[r] = p * (dp[r] - dl[e]);
+        }
+      }
+      // ---- accumulate: acc1 += Y^T dS^T (dQ^T or dK^T), acc2 += Yg^T P^T (dV^T, role 1); the transposed fragments come out of the row-major tiles
+#pragma unroll
+      for (int g1 = 0; g1 < 2; ++g1) {
+        bf16x8 dsf[2], pf[2];
+        {
+          uint32_t ph[4], pl[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2(dsv[8 * g1 + 2 * e], dsv[8 * g1 + 2 * e + 1], ph[e], pl[e]);
+          const uint4 uh = make_uint4(ph[0], ph[1], ph[2], ph[3]), ul = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+          dsf[0] = *reinterpret_cast<const bf16x8*>(&uh);
+          dsf[1] = *reinterpret_cast<const bf16x8*>(&ul);
+        }
+        if constexpr (ROLE == 1) {
+          uint32_t ph[4], pl[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2(pv[8 * g1 + 2 * e], pv[8 * g1 + 2 * e + 1], ph[e], pl[e]);
+          const uint4 uh = make_uint4(ph[0], ph[1], ph[2], ph[3]), ul = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+          pf[0] = *reinterpret_cast<const bf16x8*>(&uh);
+          pf[1] = *reinterpret_cast<const bf16x8*>(&ul);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 t1h = tfrag(my, js, g1, dt, 0), t1l = tfrag(my, js, g1, dt, 1);
+          acc1[dt] = mma16<false>(t1l, dsf[0], acc1[dt]);
+          acc1[dt] = mma16<false>(t1h, dsf[1], acc1[dt]);
+          acc1[dt] = mma16<false>(t1h, dsf[0], acc1[dt]);
+          if constexpr (ROLE == 1) {
+            const bf16x8 t2h = tfrag(myg, js, g1, dt, 0), t2l = tfrag(myg, js, g1, dt, 1);
+            acc2[dt] = mma16<false>(t2l, pf[0], acc2[dt]);
+            acc2[dt] = mma16<false>(t2h, pf[1], acc2[dt]);
+            acc2[dt] = mma16<false>(t2h, pf[0], acc2[dt]);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- store: lane holds d = 32 dt + 8 gq + 4 hi + e of its own row
+  if (!own_ok) return;
+  float* o1 = ROLE == 0 ? a.dq + ((long)b * a.Nq + orow) * a.lddq + a.dq_col0 + h * 64
+                        : a.dk + ((long)b * a.Nk + orow) * a.lddk + a.dk_col0 + h * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int dcol = 32 * dt + 8 * gq + 4 * hi;
+      *reinterpret_cast<float4*>(o1 + dcol) = make_float4(acc1[dt][4 * gq] * a.scale, acc1[dt][4 * gq + 1] * a.scale,
+                                                          acc1[dt][4 * gq + 2] * a.scale, acc1[dt][4 * gq + 3] * a.scale);
+      if constexpr (ROLE == 1) {
+        float* o2 = a.dv + ((long)b * a.Nk + orow) * a.lddv + a.dv_col0 + h * 64;
+        *reinterpret_cast<float4*>(o2 + dcol) = make_float4(acc2[dt][4 * gq], acc2[dt][4 * gq + 1], acc2[dt][4 * gq + 2], acc2[dt][4 * gq + 3]);
+      }
+    }
+}
+
+template <int ROLE>
+static hipError_t launch_attn_bwd2_role(const AttnBwdArgs& a, hipStream_t s) {
+  const size_t lds = 2 * AB2_STAGE + 2 * 128 * sizeof(float);
+  static DynLdsAttr attr;
+  hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attn_bwd2_kernel<ROLE>), (int)lds);
+  if (e != hipSuccess) return e;
+  const int nown = ROLE == 0 ? a.Nq : a.Nk;
+  dim3 grid(((nown + 127) / 128) * a.H * a.B);
+  hipLaunchKernelGGL((attn_bwd2_kernel<ROLE>), grid, dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
 template <int ROLE>
 static hipError_t launch_attn_bwd_role(const AttnBwdArgs& a, hipStream_t s) {
   const size_t lds = (ROLE == 0 ? 3 : 4) * 2 * AB_PLANE + 128 * sizeof(float);
@@ -773,6 +1050,16 @@ hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
   if (((a.ldq | a.ldk | a.ldv | a.lddo) & 31) || ((a.q_col0 | a.k_col0 | a.v_col0) & 31)) return hipErrorInvalidValue;
   const bool want_q = a.dq != nullptr, want_kv = a.dk != nullptr || a.dv != nullptr;
   if (!want_q && !want_kv) return hipErrorInvalidValue;
+  // NS2_ATTN_BWD_V1=1: the round-4 kernel on transposed copies (A/B switch, read once); default: the LDS-DMA / transpose-read kernel,
+  // which takes no transposed operand (kt / qt / dot are ignored)
+  static const bool v1 = [] { const char* e = getenv("NS2_ATTN_BWD_V1"); return e && atoi(e) != 0; }();
+  if (!v1) {
+    if (want_kv && (!a.dk || !a.dv || ((a.lddk | a.lddv | a.dk_col0 | a.dv_col0) & 3))) return hipErrorInvalidValue;
+    if (want_q && ((a.lddq & 3) || (a.dq_col0 & 3))) return hipErrorInvalidValue;
+    if (want_q) { hipError_t e = launch_attn_bwd2_role<0>(a, s); if (e != hipSuccess) return e; }
+    if (want_kv) { hipError_t e = launch_attn_bwd2_role<1>(a, s); if (e != hipSuccess) return e; }
+    return hipSuccess;
+  }
   if (want_q) {
     if (!il(a.kt_hi, a.kt_lo) || (a.kt_ld & 31) || a.kt_ld < a.Nk || (a.lddq & 3) || (a.dq_col0 & 3)) return hipErrorInvalidValue;
     hipError_t e = launch_attn_bwd_role<0>(a, s);

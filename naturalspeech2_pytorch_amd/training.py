@@ -30,6 +30,7 @@ chain rule, tap flips, shifts and layouts of THIS file are checked against torch
 `HipBackend` are checked one by one and end to end on the MI355X (`tests/test_backward_gpu.py`).
 """
 import ctypes
+import os
 import math
 import weakref
 
@@ -215,7 +216,7 @@ class HipBackend:
             part = torch.empty(S, C, dtype=torch.float32, device=dev)
         check(self.lib.ns2_grad_prep(x.data_ptr(), x.stride(0), M, C, seq_len, 0, row.hi if row else None, row.lo if row else None,
                                      row.ld if row else 0, tp.ptr() if tp else None, tp.ptr() + 64 if tp else None, ld_t, t_rows or 0,
-                                     int(per_batch), _p(part), prec, _s()), "ns2_grad_prep")
+                                     int(per_batch and want_t), _p(part), prec, _s()), "ns2_grad_prep")
         cs = None
         if want_colsum:
             cs = torch.empty(C, dtype=torch.float32, device=dev)
@@ -339,6 +340,7 @@ class HipBackend:
         check(self.lib.ns2_attention_bwd(ctypes.byref(a), _s()), "ns2_attention_bwd")
 
 
+_ATTN_BWD_V1 = os.environ.get("NS2_ATTN_BWD_V1", "0") not in ("", "0")      # A/B: the round-4 attention backward on transposed copies
 _BACKEND = None            # a substitute installed by the tests (tests/emu_backend.py)
 _HIP = {}                  # precision -> HipBackend (each with its own packed-weight cache)
 _CUR_PREC = 3              # the arithmetic of the graph being BUILT (model_forward_train sets it around its Functions' forwards)
@@ -593,9 +595,11 @@ class AttnFn(torch.autograd.Function):
         dwout = dwout[:, :, 0] if ng[5] else None
         do = bk.gemm_f32(_bwd_pack(bk, wout), dy_row)                       # [M, a]
         delta = bk.attention_delta(do, o, B, heads, seq_len)
-        do_row, do_tb, _ = bk.grad_prep(do, a, want_row=True, want_t=True, seq_len=seq_len, per_batch=True, attn=True)
-        kt = bk.transpose(k, kc, a, Nk, per_batch=True)
-        qt = bk.transpose(q, qc, a, seq_len, per_batch=True)
+        # the backward kernels form K^T, Q^T and dO^T inside the CU (LDS transpose reads of the row-major tiles); only the round-4
+        # kernel (NS2_ATTN_BWD_V1=1, A/B) reads per-utterance transposed copies
+        do_row, do_tb, _ = bk.grad_prep(do, a, want_row=True, want_t=_ATTN_BWD_V1, seq_len=seq_len, per_batch=True, attn=True)
+        kt = bk.transpose(k, kc, a, Nk, per_batch=True) if _ATTN_BWD_V1 else None
+        qt = bk.transpose(q, qc, a, seq_len, per_batch=True) if _ATTN_BWD_V1 else None
         if not cross:
             dqkv = torch.empty(M, 3 * a, dtype=torch.float32, device=h.device)
             bk.attention_bwd(q, qc, k, kc, v, vc, do_row, kt, qt, do_tb, lse, delta, B, heads, seq_len, Nk, dq=(dqkv, 0), dkv=(dqkv, a, 2 * a))

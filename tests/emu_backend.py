@@ -251,8 +251,9 @@ class EmuBackend:
         qq, kk, vv = hd(q.t, q_col0, Nq), hd(k.t, k_col0, Nk), hd(v.t, v_col0, Nk)
         dO = hd(do_row.t, 0, Nq)
         # the transposed operands must agree with the row-major ones (what the kernel multiplies)
-        assert torch.equal(kt.t.reshape(B, H, 64, -1)[..., :Nk], kk.transpose(2, 3))
-        if dkv is not None:
+        if kt is not None:
+            assert torch.equal(kt.t.reshape(B, H, 64, -1)[..., :Nk], kk.transpose(2, 3))
+        if dkv is not None and qt is not None:
             assert torch.equal(qt.t.reshape(B, H, 64, -1)[..., :Nq], qq.transpose(2, 3))
             assert torch.equal(dot.t.reshape(B, H, 64, -1)[..., :Nq], dO.transpose(2, 3))
         s = qq @ kk.transpose(2, 3) * 0.125

@@ -211,6 +211,13 @@ def test_attention_forward_lse_and_backward(B, H, Nq, Nk, cross):
     dq2 = torch.empty(B * Nq, a, device=DEV)
     HB.attention_bwd(qp, qc, kp, kc, vp, vc, do_row, kt, None, None, lse, delta, B, H, Nq, Nk, dq=(dq2, 0))
     assert torch.equal(dq2, dq[:, 32:])
+    # round 5: the kernels take NO transposed operand (K^T, Q^T, dO^T are LDS transpose reads of the row-major tiles); same bits
+    import os
+    if os.environ.get("NS2_ATTN_BWD_V1", "0") in ("", "0"):
+        dq3 = torch.empty(B * Nq, a, device=DEV)
+        dkv3 = torch.full((B * Nk, 2 * a), float("nan"), device=DEV)
+        HB.attention_bwd(qp, qc, kp, kc, vp, vc, do_row, None, None, None, lse, delta, B, H, Nq, Nk, dq=(dq3, 0), dkv=(dkv3, 0, a))
+        assert torch.equal(dq3, dq2) and torch.equal(dkv3, dkv)
 
 
 def test_weight_update_in_place():
