@@ -382,17 +382,14 @@ int ns2_attention_lse(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q
 int ns2_attention_delta(const float* d_out, int64_t ld_dout, const uint16_t* o_hi, const uint16_t* o_lo, int ldo, int B, int H, int Nq,
                         float* delta, int o_precision, void* stream);
 /* flash-attention backward, head dim 64: dq = scale * dS k, dk = scale * dS^T q, dv = P^T dO with P recomputed from lse and
- * dS = P (dO v^T - delta).  q / k / v / d_out: row-major planes (head h at columns col0 + 64 h); kt / qt / dot: per-utterance
- * transposed planes [B][H * 64][ld] (ns2_planes_transpose / ns2_grad_prep with per_batch = 1).  dq == NULL or dk == dv == NULL
- * skips that half (cross-attention to a context that needs no gradient). */
+ * dS = P (dO v^T - delta).  q / k / v / d_out: row-major planes (head h at columns col0 + 64 h) -- the kernels form K^T, Q^T and
+ * dO^T themselves (LDS transpose reads of the row-major tiles: round 4 took per-utterance transposed copies here).  dq == NULL or
+ * dk == dv == NULL skips that half (cross-attention to a context that needs no gradient). */
 typedef struct {
   const uint16_t* q_hi; const uint16_t* q_lo; int ldq, q_col0;
   const uint16_t* k_hi; const uint16_t* k_lo; int ldk, k_col0;
   const uint16_t* v_hi; const uint16_t* v_lo; int ldv, v_col0;
   const uint16_t* do_hi; const uint16_t* do_lo; int lddo;
-  const uint16_t* kt_hi; const uint16_t* kt_lo; int kt_ld;
-  const uint16_t* qt_hi; const uint16_t* qt_lo; int qt_ld;
-  const uint16_t* dot_hi; const uint16_t* dot_lo; int dot_ld;
   const float* lse; const float* delta;
   float* dq; int lddq, dq_col0;
   float* dk; int lddk, dk_col0;

@@ -33,9 +33,6 @@ class AttnBwdArgs(ctypes.Structure):
                 ("k_hi", P), ("k_lo", P), ("ldk", I), ("k_col0", I),
                 ("v_hi", P), ("v_lo", P), ("ldv", I), ("v_col0", I),
                 ("do_hi", P), ("do_lo", P), ("lddo", I),
-                ("kt_hi", P), ("kt_lo", P), ("kt_ld", I),
-                ("qt_hi", P), ("qt_lo", P), ("qt_ld", I),
-                ("dot_hi", P), ("dot_lo", P), ("dot_ld", I),
                 ("lse", P), ("delta", P),
                 ("dq", P), ("lddq", I), ("dq_col0", I),
                 ("dk", P), ("lddk", I), ("dk_col0", I),

@@ -235,9 +235,6 @@ extern "C" int ns2_attention_bwd(const ns2_attn_bwd_args* p, void* stream) {
   a.k_hi = p->k_hi; a.k_lo = p->k_lo; a.ldk = p->ldk; a.k_col0 = p->k_col0;
   a.v_hi = p->v_hi; a.v_lo = p->v_lo; a.ldv = p->ldv; a.v_col0 = p->v_col0;
   a.do_hi = p->do_hi; a.do_lo = p->do_lo; a.lddo = p->lddo;
-  a.kt_hi = p->kt_hi; a.kt_lo = p->kt_lo; a.kt_ld = p->kt_ld;
-  a.qt_hi = p->qt_hi; a.qt_lo = p->qt_lo; a.qt_ld = p->qt_ld;
-  a.dot_hi = p->dot_hi; a.dot_lo = p->dot_lo; a.dot_ld = p->dot_ld;
   a.lse = p->lse; a.delta = p->delta;
   a.dq = p->dq; a.lddq = p->lddq; a.dq_col0 = p->dq_col0;
   a.dk = p->dk; a.lddk = p->lddk; a.dk_col0 = p->dk_col0;

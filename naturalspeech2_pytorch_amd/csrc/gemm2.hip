@@ -484,6 +484,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) { tr_tok0[h] = t0; tr_n0[h] = nb; tr_off[h] = 0; }
   }
+  // (not in the single-product EPI_SPLIT instantiation = the FF causal conv of the hybrid plan, the dominant kernel: it runs the
+  // tap-shared loop below, and a second issue path in its unused general loop cost it 2.6 % through register allocation)
+  constexpr bool A_LIN = !(EPI == EPI_SPLIT && NSPLIT == 1);
+  const bool a_lin_full = A_LIN && g.conv_taps == 0 && tm * G2_BM + G2_BM <= g.M;      // see issue_half
   struct TileCoord { int tap, it; };
   auto tile_coord = [&](auto mode, int kt) __attribute__((always_inline)) {
     const int tpt = tiles_per_tap(mode);
@@ -546,6 +550,15 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
       chi[e] = lchunk_par[e] >= 4;
     }
     if constexpr (H < 2) {
+      if (a_lin_full && !half) {
+        // plain linear product on a row tile that lies inside the operand (wave-uniform): no lane can need the zero page and there is
+        // no tap shift to apply -- the pieces cost one 64-bit add each instead of the shift arithmetic + compare + two selects (round 5:
+        // the K loops are sensitive to the scalar / vector work around their DMA issue, see the TR kernel's notes)
+        const long off = pcol(c.it * BK, ail);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) glds16(psrc[H][e] + off + coff[e], sbase + pldst[H][e]);
+        return;
+      }
       const int pl = g.pad_left < 0 ? g.conv_taps - 1 : g.pad_left;
       const int shift = (c.tap < g.conv_taps) ? (pl - c.tap) * dil : 0;
       const unsigned slim = g.seq_len > 0 ? (unsigned)g.seq_len : 0x7fffffffu;

@@ -275,9 +275,6 @@ struct AttnBwdArgs {
   const bf16_t* k_hi; const bf16_t* k_lo; int ldk, k_col0;        // [B*Nk, ldk]
   const bf16_t* v_hi; const bf16_t* v_lo; int ldv, v_col0;        // [B*Nk, ldv] values, ROW-major
   const bf16_t* do_hi; const bf16_t* do_lo; int lddo;             // [B*Nq, lddo] gradient of the attention output, head h at 64 h
-  const bf16_t* kt_hi; const bf16_t* kt_lo; int kt_ld;            // transposed [B][H*64][kt_ld] (dQ)
-  const bf16_t* qt_hi; const bf16_t* qt_lo; int qt_ld;            // transposed [B][H*64][qt_ld] (dK)
-  const bf16_t* dot_hi; const bf16_t* dot_lo; int dot_ld;         // transposed [B][H*64][dot_ld] (dV)
   const float* lse; const float* delta;                           // [B, H, Nq]
   float* dq; int lddq, dq_col0;                                   // fp32 outputs (null = not wanted; dk and dv come together)
   float* dk; int lddk, dk_col0;

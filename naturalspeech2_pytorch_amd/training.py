@@ -30,7 +30,6 @@ chain rule, tap flips, shifts and layouts of THIS file are checked against torch
 `HipBackend` are checked one by one and end to end on the MI355X (`tests/test_backward_gpu.py`).
 """
 import ctypes
-import os
 import math
 import weakref
 
@@ -318,18 +317,13 @@ class HipBackend:
               "ns2_attention_delta")
         return delta
 
-    def attention_bwd(self, q, q_col0, k, k_col0, v, v_col0, do_row, kt, qt, dot, lse, delta, B, H, Nq, Nk, dq=None, dkv=None):
+    def attention_bwd(self, q, q_col0, k, k_col0, v, v_col0, do_row, lse, delta, B, H, Nq, Nk, dq=None, dkv=None):
         """dq: (fp32 tensor [B*Nq, ld], col0) or None; dkv: (tensor [B*Nk, ld], k col0, v col0) or None"""
         a = _lib.AttnBwdArgs()
         a.q_hi, a.q_lo, a.ldq, a.q_col0 = q.hi, q.lo, q.ld, q_col0
         a.k_hi, a.k_lo, a.ldk, a.k_col0 = k.hi, k.lo, k.ld, k_col0
         a.v_hi, a.v_lo, a.ldv, a.v_col0 = v.hi, v.lo, v.ld, v_col0
         a.do_hi, a.do_lo, a.lddo = do_row.hi, do_row.lo, do_row.ld
-        if kt is not None:
-            a.kt_hi, a.kt_lo, a.kt_ld = kt.ptr(), kt.ptr() + 64, kt.ld
-        if qt is not None:
-            a.qt_hi, a.qt_lo, a.qt_ld = qt.ptr(), qt.ptr() + 64, qt.ld
-            a.dot_hi, a.dot_lo, a.dot_ld = dot.ptr(), dot.ptr() + 64, dot.ld
         a.lse, a.delta = lse.data_ptr(), delta.data_ptr()
         if dq is not None:
             a.dq, a.lddq, a.dq_col0 = dq[0].data_ptr(), dq[0].stride(0), dq[1]
@@ -340,7 +334,6 @@ class HipBackend:
         check(self.lib.ns2_attention_bwd(ctypes.byref(a), _s()), "ns2_attention_bwd")
 
 
-_ATTN_BWD_V1 = os.environ.get("NS2_ATTN_BWD_V1", "0") not in ("", "0")      # A/B: the round-4 attention backward on transposed copies
 _BACKEND = None            # a substitute installed by the tests (tests/emu_backend.py)
 _HIP = {}                  # precision -> HipBackend (each with its own packed-weight cache)
 _CUR_PREC = 3              # the arithmetic of the graph being BUILT (model_forward_train sets it around its Functions' forwards)
@@ -595,14 +588,11 @@ class AttnFn(torch.autograd.Function):
         dwout = dwout[:, :, 0] if ng[5] else None
         do = bk.gemm_f32(_bwd_pack(bk, wout), dy_row)                       # [M, a]
         delta = bk.attention_delta(do, o, B, heads, seq_len)
-        # the backward kernels form K^T, Q^T and dO^T inside the CU (LDS transpose reads of the row-major tiles); only the round-4
-        # kernel (NS2_ATTN_BWD_V1=1, A/B) reads per-utterance transposed copies
-        do_row, do_tb, _ = bk.grad_prep(do, a, want_row=True, want_t=_ATTN_BWD_V1, seq_len=seq_len, per_batch=True, attn=True)
-        kt = bk.transpose(k, kc, a, Nk, per_batch=True) if _ATTN_BWD_V1 else None
-        qt = bk.transpose(q, qc, a, seq_len, per_batch=True) if _ATTN_BWD_V1 else None
+        # (the backward kernels form K^T, Q^T and dO^T inside the CU: LDS transpose reads of the row-major tiles)
+        do_row, _, _ = bk.grad_prep(do, a, want_row=True, attn=True)
         if not cross:
             dqkv = torch.empty(M, 3 * a, dtype=torch.float32, device=h.device)
-            bk.attention_bwd(q, qc, k, kc, v, vc, do_row, kt, qt, do_tb, lse, delta, B, heads, seq_len, Nk, dq=(dqkv, 0), dkv=(dqkv, a, 2 * a))
+            bk.attention_bwd(q, qc, k, kc, v, vc, do_row, lse, delta, B, heads, seq_len, Nk, dq=(dqkv, 0), dkv=(dqkv, a, 2 * a))
             need_w = ng[3] or ng[4]
             g_row, dwqkv, _ = _grads(bk, dqkv, 3 * a, xn, d, need_w=need_w)
             dwq = dwkv = None
@@ -614,7 +604,7 @@ class AttnFn(torch.autograd.Function):
         else:
             dq = torch.empty(M, a, dtype=torch.float32, device=h.device)
             dkv = torch.empty(B * Nk, 2 * a, dtype=torch.float32, device=h.device)
-            bk.attention_bwd(q, qc, k, kc, v, vc, do_row, kt, qt, do_tb, lse, delta, B, heads, seq_len, Nk, dq=(dq, 0), dkv=(dkv, 0, a))
+            bk.attention_bwd(q, qc, k, kc, v, vc, do_row, lse, delta, B, heads, seq_len, Nk, dq=(dq, 0), dkv=(dkv, 0, a))
             q_row, dwq, _ = _grads(bk, dq, a, xn, d, need_w=ng[3])
             dwq = dwq[:, :, 0] if ng[3] else None
             dxn = bk.gemm_f32(_bwd_pack(bk, wq), q_row)
