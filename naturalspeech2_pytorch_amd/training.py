@@ -65,11 +65,20 @@ def _p(t):
 
 class _PackedCache:
     """Packed weights of a training run: packed once, refreshed IN PLACE (`ns2_weight_update`: no allocation, no
-    synchronisation) when the parameter's version counter moved -- an optimizer step bumps it."""
+    synchronisation).  When: the first request of every training PASS (`begin_pass`, called by `model_forward_train`) for a weight
+    that requires grad -- and whenever a version counter moved.  The version counter alone is not enough: PyTorch's fused optimizers
+    (`torch.optim.Adam(fused=True)`, what `accelerate` picks on GPUs) update the parameters in place WITHOUT bumping it, and the
+    forward would go on multiplying the weights of step 0 (round 5: found through bench.py's `loss_mixed` / `loss_composite` of the
+    same iteration, 0.3700 against 0.3630; tests/test_round5_gpu.py::test_fused_optimizer_steps_reach_the_packed_weights).
+    A frozen weight is re-packed only when its version moves."""
 
     def __init__(self, precision=3):
         self.map = {}
         self.precision = precision
+        self.pass_id = 0
+
+    def begin_pass(self):
+        self.pass_id += 1
 
     def _purge(self):
         dead = [k for k, v in self.map.items() if any(r() is None for r in v[4])]
@@ -86,17 +95,17 @@ class _PackedCache:
         refs = tuple(weakref.ref(p) for p in params)
         if hit is None:
             self._purge()                    # a miss is rare (first step of a model): drop the packs of models that no longer exist
-        if hit is not None and hit[1] == sig:
+        if hit is not None and hit[1] == sig and (hit[5] == self.pass_id or not any(p.requires_grad for p in params)):
             return hit[0]
         src = make_src()
         src = src if isinstance(src, tuple) else (src, None)
         w, extra = (t.detach().float().contiguous() if t is not None else None for t in src)
         if hit is not None and hit[2] == (tuple(w.shape), None if extra is None else tuple(extra.shape)):
             check(_lib.load().ns2_weight_update(hit[0].handle, w.data_ptr(), _p(extra), _s()), "ns2_weight_update")
-            self.map[key] = (hit[0], sig, hit[2], (w, extra), refs)  # keep the sources alive until the stream has consumed them
+            self.map[key] = (hit[0], sig, hit[2], (w, extra), refs, self.pass_id)  # keep the sources alive until the stream has consumed them
             return hit[0]
         pw = ops.PackedWeight(w, extra1x1=extra, precision=self.precision, **pack_kw)
-        self.map[key] = (pw, sig, (tuple(w.shape), None if extra is None else tuple(extra.shape)), (w, extra), refs)
+        self.map[key] = (pw, sig, (tuple(w.shape), None if extra is None else tuple(extra.shape)), (w, extra), refs, self.pass_id)
         return pw
 
 
@@ -811,6 +820,9 @@ def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None
     prev = (_CUR_PREC, _CUR_SCALE)
     _CUR_PREC = TRAIN_PRECISIONS[tp]
     _CUR_SCALE = _Scale() if tp == "mixed" else None
+    bk = backend()
+    if hasattr(bk, "packs"):
+        bk.packs.begin_pass()                        # every trainable weight is re-packed at its first use of this pass (see _PackedCache)
     try:
         out = _forward_train(m, x, times, prompt, cond, cond_drop_prob)
         if _CUR_SCALE is not None:

@@ -297,3 +297,36 @@ def test_wgrad_from_row_planes(prec, R, K, T, M, dil, seq):
     xt = hb.transpose(xp, 0, rup(K, 32), seq if T > 1 else 0, tuple((T - 1 - t) * dil for t in range(T)))
     old = hb.wgrad(dyt, xt, R, T, K).cpu()
     assert rel(dw, old) < (2e-6 if prec == 3 else 2e-5), rel(dw, old)
+
+
+# ------------------------------------------------------------------------------------------------ optimizers that do not bump version counters
+@pytest.mark.parametrize("fused", [True, False])
+def test_fused_optimizer_steps_reach_the_packed_weights(fused):
+    """torch.optim.Adam(fused=True) updates parameters in place WITHOUT moving their version counters; the packed GEMM weights of the
+    HIP training path must follow anyway (training._PackedCache: refreshed at the first use of every pass).  The same seven steps on the
+    PyTorch composite are the witness: same losses step by step (the first step's losses are equal to 1e-6; Adam's sign-like first
+    updates then amplify the 1e-5 gradient differences somewhat)."""
+    from naturalspeech2_pytorch_amd import NaturalSpeech2
+    traj = {}
+    for backend in ("hip", "composite"):
+        torch.manual_seed(0)
+        m = Model(dim=128, depth=2).to(DEV).train()
+        m.train_backend = backend
+        d = NaturalSpeech2(m, codec=None, target_sample_hz=24000).to(DEV)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=fused or None)
+        g = torch.Generator().manual_seed(1)
+        audio, times, noise = torch.randn(2, 256, 128, generator=g).to(DEV), torch.rand(2, generator=g).to(DEV), torch.randn(2, 256, 128, generator=g).to(DEV)
+        ls = []
+        for _ in range(7):
+            opt.zero_grad(set_to_none=True)
+            loss = d(audio, times=times, noise=noise)
+            loss.backward()
+            opt.step()
+            ls.append(float(loss))
+        traj[backend] = ls
+    h, c = traj["hip"], traj["composite"]
+    assert abs(h[0] - c[0]) < 1e-5 * abs(c[0])
+    assert h[-1] < 0.97 * h[0] and c[-1] < 0.97 * c[0]                      # both actually train
+    worst = max(abs(a - b) / abs(b) for a, b in zip(h, c))
+    record(f"training_trajectory_hip_vs_composite/adam_fused_{int(fused)}/worst_rel_loss_difference_over_7_steps", worst)
+    assert worst < 2e-3, (h, c)                                             # stale packs gave 4e-2 at step 1 already
