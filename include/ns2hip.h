@@ -318,6 +318,21 @@ int ns2_saturation_peek_train_async(unsigned int* host1, void* stream);
  * no allocation, no synchronisation -- the per-step refresh of an optimizer's weights */
 int ns2_weight_update(ns2_weight* w, const float* w_src, const float* extra1x1, void* stream);
 
+/* Every pack of a training pass in ONE launch.  A part = a rectangle of a packed weight (rows [row0, row0 + rows), columns per tap
+ * [col0, col0 + cols) of a plain ns2_weight_pack weight: no GEGLU permutation, no extra 1x1 block) and where its fp32 values live:
+ * element (r, c, tap) at src[r * sr + c * sc + tap * st], strides in elements and possibly negative -- the parameter's own storage
+ * serves the forward pack (sr = C T, sc = T, st = 1), the dgrad pack W^T (sr = T, sc = C T) with flipped taps (st = -1 from src + T - 1)
+ * and q | kv concatenations (two parts) without any copy.  ns2_weights_repack_build writes the device table (caller-owned memory of
+ * ns2_weights_repack_table_bytes(n) bytes; synchronises once), ns2_weights_repack replays it: stream-ordered, no allocation. */
+typedef struct {
+  ns2_weight* w; const float* src;
+  int64_t sr, sc, st;
+  int row0, rows, col0, cols;
+} ns2_repack_part;
+int64_t ns2_weights_repack_table_bytes(int n);
+int ns2_weights_repack_build(const ns2_repack_part* parts, int n, void* table_device, int64_t table_bytes, int64_t* total_blocks, void* stream);
+int ns2_weights_repack(const void* table_device, int n, int64_t total_blocks, void* stream);
+
 /* fp32 gradient x [M, C] (row stride ldx) -> any of
  *   row planes [M, ld_row] (zero beyond C)                                  -- the A operand of the dgrad GEMM;
  *   transposed planes T[c][m] with ld_t token columns (ld_t a multiple of 32, zero beyond M) and t_rows rows (zero beyond C; a

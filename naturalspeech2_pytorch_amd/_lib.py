@@ -40,6 +40,11 @@ class AttnBwdArgs(ctypes.Structure):
                 ("B", I), ("H", I), ("Nq", I), ("Nk", I), ("scale", F)]
 
 
+class RepackPart(ctypes.Structure):
+    """ns2_repack_part (include/ns2hip.h), field for field"""
+    _fields_ = [("w", P), ("src", P), ("sr", L), ("sc", L), ("st", L), ("row0", I), ("rows", I), ("col0", I), ("cols", I)]
+
+
 # name -> (restype, argtypes); mirrors include/ns2hip.h line by line
 SIGNATURES = {
     "ns2_last_error": (c_char_p, []),
@@ -108,6 +113,9 @@ SIGNATURES = {
     "ns2_grad_prep": (I, [P, L, I, I, I, I, P, P, I, P, P, L, I, I, P, I, P]),
     "ns2_planes_transpose": (I, [P, P, I, I, I, I, I, I, P, P, L, I, I, I, P]),
     "ns2_reduce_slices": (I, [P, L, I, L, P, I, P]),
+    "ns2_weights_repack_table_bytes": (L, [I]),
+    "ns2_weights_repack_build": (I, [P, I, P, L, POINTER(c_int64), P]),
+    "ns2_weights_repack": (I, [P, I, L, P]),
     "ns2_wgrad_workspace_bytes": (L, [I, I, L]),
     "ns2_wgrad": (I, [P, P, P, P, L, I, I, I, I, P, P, L, I, P]),
     "ns2_wgrad_rows_preferred": (I, [I, I, L]),

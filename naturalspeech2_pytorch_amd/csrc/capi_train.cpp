@@ -37,6 +37,44 @@ extern "C" int ns2_weight_update(ns2_weight* w, const float* w_src, const float*
   return NS2_OK;
 }
 
+// ---- all packs of a training pass in one launch (elementwise.hip repack_kernel).  The table lives in CALLER-owned device memory (the
+// library keeps no state): ns2_weights_repack_build fills it from a host array of parts (once; synchronising copy), ns2_weights_repack
+// replays it (stream-ordered, no allocation, no synchronisation).  A part is valid while its weight handle and its source storage live.
+extern "C" int64_t ns2_weights_repack_table_bytes(int n) { return n > 0 ? (int64_t)n * (int64_t)sizeof(RepackDesc) : 0; }
+extern "C" int ns2_weights_repack_build(const ns2_repack_part* parts, int n, void* table_device, int64_t table_bytes, int64_t* total_blocks, void* stream) {
+  ARGCHK(parts && n > 0 && table_device && total_blocks, "ns2_weights_repack_build: null argument");
+  ARGCHK(table_bytes >= ns2_weights_repack_table_bytes(n), "ns2_weights_repack_build: table too small (ns2_weights_repack_table_bytes)");
+  std::vector<RepackDesc> tab((size_t)n);
+  long blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const ns2_repack_part& p = parts[i];
+    ARGCHK(p.w && p.src, "ns2_weights_repack_build: null weight / source");
+    const ns2_weight* w = p.w;
+    ARGCHK(!w->geglu && !w->has_extra, "ns2_weights_repack_build: plain packs only (no GEGLU row permutation, no extra 1x1 block)");
+    ARGCHK(p.rows > 0 && p.cols > 0 && p.row0 >= 0 && p.col0 >= 0 && p.row0 + p.rows <= w->w.N && p.col0 + p.cols <= w->cols,
+           "ns2_weights_repack_build: part outside its weight");
+    RepackDesc& d = tab[(size_t)i];
+    const bool il = w->w.lo != nullptr;
+    d.src = p.src; d.sr = (long)p.sr; d.sc = (long)p.sc; d.st = (long)p.st;
+    d.dst_hi = w->w.hi; d.drs = il ? 2L * w->w.ldk : (long)w->w.ldk;
+    d.row0 = p.row0; d.rows = p.rows; d.col0 = p.col0; d.cols = p.cols;
+    d.Cp = w->cols_p; d.T = w->taps; d.fmt = w->w.fmt; d.il = il ? 1 : 0;
+    d.chunks = (w->taps * ((p.cols + 3) / 4) + 255) / 256; d.pad_ = 0;          // a thread packs 4 columns
+    d.block0 = blocks;
+    blocks += (long)p.rows * d.chunks;
+  }
+  ARGCHK(blocks <= 0x7fffffffL, "ns2_weights_repack_build: too many blocks for one launch");
+  HIPRET(hipMemcpyAsync(table_device, tab.data(), (size_t)n * sizeof(RepackDesc), hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIPRET(hipStreamSynchronize((hipStream_t)stream));         // the host vector dies here
+  *total_blocks = blocks;
+  return NS2_OK;
+}
+extern "C" int ns2_weights_repack(const void* table_device, int n, int64_t total_blocks, void* stream) {
+  ARGCHK(table_device && n > 0 && total_blocks > 0, "ns2_weights_repack: bad arguments");
+  HIPRET(launch_repack(static_cast<const RepackDesc*>(table_device), n, (long)total_blocks, (hipStream_t)stream));
+  return NS2_OK;
+}
+
 // the training kernels' share of the range guard (ns2_saturation_count sums it in; this is its stream-ordered, non-synchronising
 // read for a training loop under the mixed arithmetic: one word into pinned host memory)
 extern "C" int ns2_saturation_peek_train_async(unsigned int* host1, void* stream) {

@@ -560,6 +560,63 @@ hipError_t launch_pack_weight(const float* src, int C, int T, int Cp, const int*
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- re-pack of MANY weights in one launch (training: once per pass)
+// A training pass multiplies ~270 packed weights (two packs per parameter: forward and dgrad) and an optimizer step changes all of
+// them.  Refreshing them one ns2_weight_update at a time cost 269 launches of ~6 us + 1-3 small PyTorch kernels each to bring the
+// source into the pack's orientation (W^T, taps flipped, q | kv concatenated): 3.5 ms of a 100 ms d512 step and 5 ms of the
+// HOST-bound 15 ms d128 step.  Here every part is a descriptor -- where its values live (the PARAMETER's own storage, any strides:
+// a transposition or a tap flip is a stride) and which rectangle of which packed weight they fill -- in a table in device memory
+// that is built once; a pass is ONE launch, block -> descriptor by binary search over the block prefix.
+__global__ __launch_bounds__(256) void repack_kernel(const RepackDesc* tab, int n) {
+  const long b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].block0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const RepackDesc d = tab[lo];
+  const long lb = b - d.block0;
+  const int r = (int)(lb / d.chunks), ch = (int)(lb - (long)r * d.chunks);
+  // a thread takes 4 adjacent columns of one tap (one 8 + 4 + 4 byte store of an FMT_H8 line instead of twelve 1-2 byte stores)
+  const int c4 = (d.cols + 3) >> 2;
+  const int q = ch * 256 + threadIdx.x;
+  if (q >= d.T * c4) return;
+  const int tap = q / c4, c = (q - tap * c4) * 4;
+  const float* sp = d.src + (long)r * d.sr + (long)c * d.sc + (long)tap * d.st;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (c + e < d.cols) ? sp[(long)e * d.sc] : 0.f;
+  const int rp = d.row0 + r, kc = tap * d.Cp + d.col0 + c;
+  bf16_t* row = d.dst_hi + (long)rp * d.drs;
+  // whole group inside the part and 4-aligned in the pack (Cp and col0 multiples of 4 in practice): vector store; else element by element
+  if ((kc & 3) == 0 && c + 3 < d.cols) { store_cols4(row, kc, v[0], v[1], v[2], v[3], d.fmt, d.il != 0); return; }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (c + e >= d.cols) break;
+    const int k1 = kc + e;
+    if (d.fmt == FMT_H8) {
+      uint32_t h16, h8, l8;
+      cvt2_h8(v[e], 0.f, h16, h8, l8);
+      bf16_t* line = row + ((k1 & ~31) << 1);
+      line[k1 & 31] = (bf16_t)(h16 & 0xffffu);
+      reinterpret_cast<unsigned char*>(line)[64 + (k1 & 31)] = (unsigned char)(h8 & 0xffu);
+      reinterpret_cast<unsigned char*>(line)[96 + (k1 & 31)] = (unsigned char)(l8 & 0xffu);
+    } else {
+      bf16_t h, l;
+      split_bf16(v[e], h, l);
+      if (d.fmt == FMT_F16) h = (bf16_t)(cvt2h(v[e], 0.f) & 0xffffu);
+      const long o = pcol(k1, d.il != 0);
+      row[o] = h;
+      if (d.il) row[o + 32] = l;
+    }
+  }
+}
+hipError_t launch_repack(const RepackDesc* tab, int n, long total_blocks, hipStream_t s) {
+  if (!tab || n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(repack_kernel, dim3((unsigned)total_blocks), dim3(256), 0, s, tab, n);
+  return hipGetLastError();
+}
+
 // ================================================================ EnCodec SEANet helpers (HFENC:81-347)
 // The SEANet convolutions run on the GEMM family (channel-last rows, shifted-row taps).  What they need around the GEMM:
 //   * the activation in front of every convolution (ELU, HFENC:285-347 nn.ELU()) and the conversion to operand planes;

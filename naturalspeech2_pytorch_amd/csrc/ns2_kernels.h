@@ -167,6 +167,15 @@ hipError_t launch_ddim(const DdimArgs& a, hipStream_t s);
 hipError_t launch_cfg_mix(const float* cond, const float* null, float* out, long n, float scale, hipStream_t s);
 
 // weight packing: fp32 [rows, C, T] (T taps, 1 for linear) -> split planes [rows_p, T*Cp]; row_map[r] = source row or -1
+// one rectangular part of a packed weight and where its fp32 values live (elementwise.hip repack_kernel; built by ns2_weights_repack_build)
+struct RepackDesc {
+  const float* src; long sr, sc, st;        // element (r, c, tap) of the part at src[r * sr + c * sc + tap * st] (element strides, may be negative)
+  bf16_t* dst_hi; long drs;                 // packed weight: first plane, physical row stride
+  int row0, rows, col0, cols;               // packed rows [row0, row0 + rows), packed columns (per tap) [col0, col0 + cols)
+  int Cp, T, fmt, il;                       // packed columns per tap, taps, PlaneFmt, interleaved lines
+  long block0; int chunks, pad_;            // first block of the part, 256-element chunks per packed row
+};
+hipError_t launch_repack(const RepackDesc* tab, int n, long total_blocks, hipStream_t s);
 hipError_t launch_pack_weight(const float* src, int C, int T, int Cp, const int* row_map, int rows_p, bf16_t* dst_hi,
                               bf16_t* dst_lo, int ldk, int k_off, hipStream_t s, int fmt = 0);
 

@@ -76,18 +76,75 @@ class _PackedCache:
         self.map = {}
         self.precision = precision
         self.pass_id = 0
+        self._table = None          # (signature, device table, parts kept alive, n, total_blocks): every trainable pack, one launch per pass
+
+    # ---- one launch per pass (ns2_weights_repack): possible once every entry has told where its values live (`parts`)
+    @staticmethod
+    def _part(lib_part, pw, p, mode, row0, col0):
+        """`mode`: "n" = the pack's rows / columns / taps are the parameter's; "t" = transposed ([C, R(, T)] from [R, C(, T)]);
+        "tf" = transposed with the taps flipped (the dgrad weight of a causal conv)"""
+        R, C = p.shape[0], p.shape[1]
+        T = p.shape[2] if p.ndim == 3 else 1
+        assert p.is_contiguous() and p.dtype == torch.float32
+        base = p.data_ptr()
+        if mode == "n":
+            sr, sc, st, rows, cols = C * T, T, 1, R, C
+        elif mode == "t":
+            sr, sc, st, rows, cols = T, C * T, 1, C, R
+        else:
+            sr, sc, st, rows, cols = T, C * T, -1, C, R
+            base += 4 * (T - 1)
+        return lib_part(pw.handle, base, sr, sc, st, row0, rows, col0, cols)
+
+    def _signature(self):
+        return tuple((k, tuple(p.data_ptr() for p in (r() for r in v[4]) if p is not None)) for k, v in self.map.items())
+
+    def _repack_all(self):
+        """every trainable entry with a `parts` description in one launch; False when some entry cannot be described"""
+        if not self.map or any(v[6] is None or any(r() is None for r in v[4]) for v in self.map.values()):
+            return False
+        lib = _lib.load()
+        sig = self._signature()
+        if self._table is None or self._table[0] != sig:
+            parts = []
+            for v in self.map.values():
+                params = [r() for r in v[4]]
+                if not any(p.requires_grad for p in params):
+                    continue
+                for (idx, mode, row0, col0) in v[6]:
+                    parts.append(self._part(_lib.RepackPart, v[0], params[idx], mode, row0, col0))
+            if not parts:
+                return False
+            arr = (_lib.RepackPart * len(parts))(*parts)
+            nbytes = lib.ns2_weights_repack_table_bytes(len(parts))
+            dev = next(r() for v in self.map.values() for r in v[4]).device
+            table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            total = ctypes.c_int64(0)
+            check(lib.ns2_weights_repack_build(arr, len(parts), table.data_ptr(), nbytes, ctypes.byref(total), _s()), "ns2_weights_repack_build")
+            self._table = (sig, table, len(parts), total.value)
+        _, table, n, total = self._table
+        check(lib.ns2_weights_repack(table.data_ptr(), n, total, _s()), "ns2_weights_repack")
+        return True
 
     def begin_pass(self):
         self.pass_id += 1
+        if self.pass_id > 1 and self._repack_all():
+            for k, v in self.map.items():                                    # fresh for this pass (versions as they are now)
+                params = [r() for r in v[4]]
+                self.map[k] = (v[0], tuple((p.data_ptr(), p._version) for p in params), v[2], v[3], v[4], self.pass_id, v[6])
 
     def _purge(self):
         dead = [k for k, v in self.map.items() if any(r() is None for r in v[4])]
         for k in dead:
             del self.map[k]
+        if dead:
+            self._table = None
 
-    def get(self, key, params, make_src, **pack_kw):
+    def get(self, key, params, make_src, parts=None, **pack_kw):
         """`key` carries id()s of `params`: an entry is only a hit while those very objects are alive (weak references), so a
-        recycled id can never return another model's weights"""
+        recycled id can never return another model's weights.  `parts`: [(index into params, mode, row0, col0)] -- where the pack's
+        values live in the parameters' own storage (`_part`), which lets begin_pass refresh every pack of the model in one launch;
+        `make_src` builds the same matrix as a tensor for the first pack (and for entries without `parts`)."""
         sig = tuple((p.data_ptr(), p._version) for p in params)
         hit = self.map.get(key)
         if hit is not None and any(r() is not p for r, p in zip(hit[4], params)):
@@ -95,6 +152,7 @@ class _PackedCache:
         refs = tuple(weakref.ref(p) for p in params)
         if hit is None:
             self._purge()                    # a miss is rare (first step of a model): drop the packs of models that no longer exist
+            self._table = None
         if hit is not None and hit[1] == sig and (hit[5] == self.pass_id or not any(p.requires_grad for p in params)):
             return hit[0]
         src = make_src()
@@ -102,10 +160,10 @@ class _PackedCache:
         w, extra = (t.detach().float().contiguous() if t is not None else None for t in src)
         if hit is not None and hit[2] == (tuple(w.shape), None if extra is None else tuple(extra.shape)):
             check(_lib.load().ns2_weight_update(hit[0].handle, w.data_ptr(), _p(extra), _s()), "ns2_weight_update")
-            self.map[key] = (hit[0], sig, hit[2], (w, extra), refs, self.pass_id)  # keep the sources alive until the stream has consumed them
+            self.map[key] = (hit[0], sig, hit[2], (w, extra), refs, self.pass_id, parts)  # keep the sources alive until the stream has consumed them
             return hit[0]
         pw = ops.PackedWeight(w, extra1x1=extra, precision=self.precision, **pack_kw)
-        self.map[key] = (pw, sig, (tuple(w.shape), None if extra is None else tuple(extra.shape)), (w, extra), refs, self.pass_id)
+        self.map[key] = (pw, sig, (tuple(w.shape), None if extra is None else tuple(extra.shape)), (w, extra), refs, self.pass_id, parts)
         return pw
 
 
@@ -125,8 +183,8 @@ class HipBackend:
         self.packs = _PackedCache(precision)
 
     # ---- weights
-    def pack(self, key, params, make_src):
-        return self.packs.get(key, params, make_src)
+    def pack(self, key, params, make_src, parts=None):
+        return self.packs.get(key, params, make_src, parts=parts)
 
     # ---- forward pieces
     def split(self, x, C=None):
@@ -440,15 +498,15 @@ def _taps(w):
 
 
 def _fwd_pack(bk, w):
-    return bk.pack(("f", id(w)), (w,), lambda: w)
+    return bk.pack(("f", id(w)), (w,), lambda: w, parts=[(0, "n", 0, 0)])
 
 
 def _bwd_pack(bk, w):
     """the dgrad weight: dX = dY W  ->  rows = input channels, columns = output channels, taps flipped (the gradient of a causal
     conv reads dY[n + (k - 1 - t) dil], i.e. a conv with pad_left = 0 whose tap t' is the forward's tap k - 1 - t')"""
     if w.ndim == 3:
-        return bk.pack(("b", id(w)), (w,), lambda: w.detach().permute(1, 0, 2).flip(-1))
-    return bk.pack(("b", id(w)), (w,), lambda: w.detach().t())
+        return bk.pack(("b", id(w)), (w,), lambda: w.detach().permute(1, 0, 2).flip(-1), parts=[(0, "tf", 0, 0)])
+    return bk.pack(("b", id(w)), (w,), lambda: w.detach().t(), parts=[(0, "t", 0, 0)])
 
 
 def _shifts(taps, dil):
@@ -568,7 +626,8 @@ class AttnFn(torch.autograd.Function):
         B, a = M // seq_len, heads * 64
         xn = bk.rmsnorm(h, seq_len, cond=film) if film is not None else bk.split(h)
         if ctxt is None:                                                    # self attention: one GEMM for q | k | v
-            wqkv = bk.pack(("qkv", id(wq), id(wkv)), (wq, wkv), lambda: torch.cat((wq.detach(), wkv.detach()), 0))
+            wqkv = bk.pack(("qkv", id(wq), id(wkv)), (wq, wkv), lambda: torch.cat((wq.detach(), wkv.detach()), 0),
+                           parts=[(0, "n", 0, 0), (1, "n", a, 0)])
             qkv = bk.gemm_split(wqkv, xn, attn=True)
             q, k, v, qc, kc, vc, Nk, cp = qkv, qkv, qkv, 0, a, 2 * a, seq_len, None
         else:
@@ -607,7 +666,8 @@ class AttnFn(torch.autograd.Function):
             dwq = dwkv = None
             if need_w:
                 dwq, dwkv = dwqkv[:a, :, 0], dwqkv[a:, :, 0]
-            wqkv = bk.pack(("qkv_b", id(wq), id(wkv)), (wq, wkv), lambda: torch.cat((wq.detach(), wkv.detach()), 0).t())
+            wqkv = bk.pack(("qkv_b", id(wq), id(wkv)), (wq, wkv), lambda: torch.cat((wq.detach(), wkv.detach()), 0).t(),
+                           parts=[(0, "t", 0, 0), (1, "t", 0, a)])
             dxn = bk.gemm_f32(wqkv, g_row)
             dctx = None
         else:
@@ -657,15 +717,25 @@ class FeedForwardFn(torch.autograd.Function):
         B = M // seq_len
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
         ng = ctx.needs_input_grad                                           # (h, film, w1, b1, wc, bc, w2, b2, -)
-        dy_row, dw2, db2 = _grads(bk, dy, d, cp, f, need_w=ng[6], need_b=ng[7])
+        planes_dc = wc is not None and bk.wgrad_rows_ok(f, 3, f, seq_len, M)
+        dy_row, dw2, db2 = _grads(bk, dy, d, cp, f, need_w=ng[6], need_b=ng[7] or (planes_dc and ng[5]))
         dw2 = dw2[:, :, 0] if ng[6] else None
-        dc = bk.gemm_f32(_bwd_pack(bk, w2), dy_row)                         # [M, f]
         dwc = dbc = None
-        if wc is not None:
-            dc_row, dwc, dbc = _grads(bk, dc, f, hp, f, 3, 1, seq_len, need_w=ng[4], need_b=ng[5])
+        if planes_dc:
+            # dc = dy W2 feeds two GEMMs only (the conv's dgrad and wgrad): it leaves the dgrad GEMM as operand planes and never exists in
+            # fp32; the conv's bias gradient, colsum(dy W2), is colsum(dy) W2 -- a [d] x [d, f] product of what the FF-out bias gradient sums anyway
+            dc_row = bk.gemm_split(_bwd_pack(bk, w2), dy_row)
+            dwc = bk.wgrad_rows(dc_row, hp, f, 3, f, 1, seq_len) if ng[4] else None
+            dbc = db2 @ w2.detach() if ng[5] else None
+            db2 = db2 if ng[7] else None
             dhh = bk.gemm_f32(_bwd_pack(bk, wc), dc_row, taps=3, dil=1, seq_len=seq_len, pad_left=0)
         else:
-            dhh = dc
+            dc = bk.gemm_f32(_bwd_pack(bk, w2), dy_row)                     # [M, f]
+            if wc is not None:
+                dc_row, dwc, dbc = _grads(bk, dc, f, hp, f, 3, 1, seq_len, need_w=ng[4], need_b=ng[5])
+                dhh = bk.gemm_f32(_bwd_pack(bk, wc), dc_row, taps=3, dil=1, seq_len=seq_len, pad_left=0)
+            else:
+                dhh = dc
         dpre = bk.geglu_bwd(dhh, pre, f)                                    # [M, 2 f]
         p_row, dw1, db1 = _grads(bk, dpre, 2 * f, xn, d, need_w=ng[2], need_b=ng[3])
         dw1 = dw1[:, :, 0] if ng[2] else None

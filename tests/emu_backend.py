@@ -45,7 +45,7 @@ class EmuBackend:
     def __init__(self):
         self.calls = []
 
-    def pack(self, key, params, make_src):
+    def pack(self, key, params, make_src, parts=None):
         src = make_src()
         return EPW(src if not isinstance(src, tuple) else src[0])
 
