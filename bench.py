@@ -316,7 +316,7 @@ def main():
                     step(tab[i - warmup] if use_table else None)
             if world > 1:                                # the sharded sampler's single collective
                 src = audio if dist.get_backend() != "gloo" else audio.cpu()     # gloo (functional test only) gathers on the host
-                gathered = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+                gathered = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)   # rank r's shard at rows [r B, (r + 1) B): the form gloo and nccl both take
                 dist.all_gather_into_tensor(gathered, src)       # single-buffer form: the collective row measures the wire, not copies
             barrier()
             elapsed = time.perf_counter() - t0

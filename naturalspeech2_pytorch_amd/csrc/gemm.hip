@@ -312,6 +312,66 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
       const float bc1 = (g.bias && col_base + 32 + l31 < g.N) ? g.bias[col_base + 32 + l31] : 0.f;
       const int lcpr = 31 - __builtin_clz(nvc >> 2);              // log2(16-byte chunks per row): 2, 3 or 4
       const int lr0 = lane >> lcpr, ch = lane & ((1 << lcpr) - 1), rpi = 64 >> lcpr;
+      // Round 5 -- the RMSNorm behind a residual update, in the same epilogue (launch_gemm guarantees N == 128 == BN and M % 128 == 0,
+      // so this block owns 128 whole rows and all four waves are here): the lane keeps its 16 float4 of x, the row's sum of squares
+      // is 16 lanes of this wave + the partner wave's half (wn ^ 1) through 64 floats of LDS per wave, added in a fixed order.
+      if (g.nrm_hi) {
+        float4 keep[2][8];
+        float* s_part = reinterpret_cast<float*>(smem + wave * (STAGE_BYTES / 2) + 32 * RS);      // 64 floats in the slack behind the staged rows
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+              *reinterpret_cast<float*>(wbuf + lr * RS + (ni * 32 + l31) * 4) = acc[mi][ni][r] + (ni ? bc1 : bc0);
+            }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {                          // 64 columns: 16 lanes per row, 4 rows per iteration
+            const int lr = it * 4 + (lane >> 4);
+            float4 v = *reinterpret_cast<const float4*>(wbuf + lr * RS + (lane & 15) * 16);
+            const long row = row_base + mi * 32 + lr;
+            if (g.resid) {
+              const float4 rr = *reinterpret_cast<const float4*>(g.resid + row * g.ldr + col_base + (lane & 15) * 4);
+              v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            *reinterpret_cast<float4*>(g.out_f + row * g.ldo_f + col_base + (lane & 15) * 4) = v;
+            keep[mi][it] = v;
+            float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+            if ((lane & 15) == 0) s_part[mi * 32 + lr] = ss;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        const float* p0 = reinterpret_cast<const float*>(smem + (wm * 2 + 0) * (STAGE_BYTES / 2) + 32 * RS);
+        const float* p1 = reinterpret_cast<const float*>(smem + (wm * 2 + 1) * (STAGE_BYTES / 2) + 32 * RS);
+        const float scale = sqrtf((float)g.N);
+        const bool nil = g.nrm_lo != nullptr;
+        const int c = col_base + (lane & 15) * 4;
+        float gm[4] = {1.f, 1.f, 1.f, 1.f};
+        if (g.nrm_gamma) { const float4 t = *reinterpret_cast<const float4*>(g.nrm_gamma + c); gm[0] = t.x; gm[1] = t.y; gm[2] = t.z; gm[3] = t.w; }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int lr = it * 4 + (lane >> 4);
+            const long row = row_base + mi * 32 + lr;
+            const float tot = p0[mi * 32 + lr] + p1[mi * 32 + lr];
+            const float inv = scale / fmaxf(sqrtf(tot), 1e-12f);   // F.normalize eps (NS2:727-746)
+            float o[4] = {keep[mi][it].x * inv, keep[mi][it].y * inv, keep[mi][it].z * inv, keep[mi][it].w * inv};
+            if (g.nrm_gamma) { o[0] *= gm[0]; o[1] *= gm[1]; o[2] *= gm[2]; o[3] *= gm[3]; }
+            if (g.nrm_cond) {
+              const float* gc = g.nrm_cond + (g.nrm_seq_len > 0 ? row / g.nrm_seq_len : 0) * (long)g.nrm_cond_ld;
+              const float4 t = *reinterpret_cast<const float4*>(gc + c), u = *reinterpret_cast<const float4*>(gc + g.N + c);
+              o[0] = o[0] * t.x + u.x; o[1] = o[1] * t.y + u.y; o[2] = o[2] * t.z + u.z; o[3] = o[3] * t.w + u.w;
+            }
+            store_cols4(g.nrm_hi + row * pld(g.nrm_ld, nil), c, o[0], o[1], o[2], o[3], g.nrm_fmt, nil);
+          }
+        return;
+      }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll

@@ -1078,9 +1078,32 @@ void splitk_plan(int M, int N, int nkt, int kt_per_tap, bool epi_f32, long scrat
 
 // Dispatch: the 256x256 LDS-DMA kernel for wide outputs, the 128x128 kernel when N <= 128 (half of a 256-wide tile
 // would be padding, e.g. the dim=128 model's d x d projections).  W rows are padded to 256 by the packers.
+// Does this product take the one-launch 128 x 128 kernel whose workgroups own whole rows (N == 128), so that its fp32 epilogue can run
+// the RMSNorm that follows (GemmArgs::nrm_*)?  Not when K is split (the finishing launch runs the epilogue) or the big kernel is forced.
+bool gemm_fuses_norm(const GemmArgs& g, int precision) {
+  if (g.epi != EPI_F32 || g.N != 128 || g.M <= 0 || (g.M % 128) || g.act != 0 || g.nz > 1 || g.ksplit != 0) return false;
+  if ((g.ldo_f & 3) || (reinterpret_cast<uintptr_t>(g.out_f) & 15) || (g.resid && ((g.ldr & 3) || (reinterpret_cast<uintptr_t>(g.resid) & 15)))) return false;
+  const int f = forced_kernel();
+  if (f == 2) return false;
+  if (f == 0 && g.sk_ws && !g.dil_z) {
+    int S, c;
+    splitk_plan(g.M, g.N, g.nkt, g.kt_per_tap, true, g.sk_ws_floats, &S, &c);
+    if (S >= 2) return false;
+  }
+  (void)precision;
+  return true;
+}
+
 hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
   GemmArgs g = g_in;
   if (precision < 1 || precision > 4) return hipErrorInvalidValue;
+  if (g.nrm_hi) {
+    const bool nil = g.nrm_lo != nullptr;
+    if (!gemm_fuses_norm(g, precision) || !planes_ok(g.nrm_hi, g.nrm_lo) || (g.nrm_ld & (nil ? 31 : 3)) || g.nrm_ld < g.N ||
+        (g.nrm_fmt == FMT_H8 && !nil) || (g.nrm_fmt == FMT_F16 && nil) || (g.nrm_cond && ((g.nrm_cond_ld & 3) || (reinterpret_cast<uintptr_t>(g.nrm_cond) & 15))) ||
+        (g.nrm_gamma && (reinterpret_cast<uintptr_t>(g.nrm_gamma) & 15)))
+      return hipErrorInvalidValue;
+  }
   const int op_fmt = precision == 2 ? FMT_F16 : (precision == 4 ? FMT_H8 : FMT_BF16);
   if (g.out_fmt < 0) g.out_fmt = op_fmt;
   if (g.vt_fmt < 0) g.vt_fmt = (precision == 2 || precision == 4) ? FMT_F16 : FMT_BF16;

@@ -259,6 +259,22 @@ int gemm_f32(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, 
   HIPCHK(launch_gemm(g, prec, s));
   return NS2_OK;
 }
+// The residual stream's update followed by the RMSNorm that reads it (NS2:794-807): ONE launch where the GEMM's workgroups own whole
+// rows (dim = 128: the 128 x 128 kernel, gemm.hip), else the GEMM and rmsnorm_kernel.  `fused` tells the caller what happened (profile
+// categories).  cond_ld == 0 with cond != null: every utterance reads the same (gamma, beta) row (the time table).
+int gemm_f32_norm(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, const float* bias, const float* resid, int ldr,
+                  float* out, int ldo, int prec, int seq_len, const float* gamma, const float* cond, int cond_ld, bf16_t* n_hi, bf16_t* n_lo,
+                  int n_ld, int n_fmt, hipStream_t s, bool* fused) {
+  GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
+  g.epi = EPI_F32; g.bias = bias; g.resid = resid; g.ldr = ldr; g.out_f = out; g.ldo_f = ldo;
+  *fused = gemm_fuses_norm(g, prec);
+  if (*fused) {
+    g.nrm_hi = n_hi; g.nrm_lo = n_lo; g.nrm_ld = n_ld; g.nrm_fmt = n_fmt;
+    g.nrm_gamma = gamma; g.nrm_cond = cond; g.nrm_cond_ld = cond_ld; g.nrm_seq_len = seq_len;
+  }
+  HIPCHK(launch_gemm(g, prec, s));
+  return NS2_OK;
+}
 int gemm_split(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
                const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left, int act, int out_fmt) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
@@ -913,38 +929,48 @@ static int forward_impl(ns2_model* m, const float* x, const float* times, const 
   }
   // sum of the 8 skip convs == one GEMM over the concatenated columns (NS2:639-640, 685-686, 725), then final_conv
   PROF(PC_GEMM_SPLIT, gemm_split(m->w_skip, prev.hi, prev.lo, L * dp, M, 0, 1, 0, m->b_skip, w.ssum.hi, w.ssum.lo, dp, prec, s));
-  PROF(PC_GEMM_F32, gemm_f32(m->w_final, w.ssum.hi, w.ssum.lo, dp, M, 0, 1, 0, m->b_final, nullptr, 0, w.xres, dim, prec, s));
+  // Every update of the residual stream is followed by exactly one RMSNorm that reads it (NS2:794-807, 781-784): `update_then_norm` runs
+  // the pair as one launch where the GEMM's workgroups own whole rows (dim = 128; gemm_f32_norm), else as the GEMM + rmsnorm_kernel.
+  const float* cbase = call + (size_t)S * L * 2 * dim;
+  auto update_then_norm = [&](const PackedW& pw, const Planes& a, int lda, const float* bias, bool add_resid, int gprec, const float* gamma,
+                              const float* ncond, const Planes& nout) -> int {
+    bool fused = false;
+    PROF(PC_GEMM_F32, gemm_f32_norm(pw, a.hi, a.lo, lda, M, bias, add_resid ? w.xres : nullptr, dim, w.xres, dim, gprec, N, gamma, ncond, cld,
+                                    nout.hi, nout.lo, dp, nout.fmt, s, &fused));
+    if (!fused) PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, gamma, ncond, cld, nout, dp, nullptr, 0, s));
+    return NS2_OK;
+  };
+  auto layer_cond = [&](int l, int which) { return cbase + (size_t)l * m->nnorm * 2 * dim + (size_t)which * 2 * dim; };
+  // final_conv of the Wavenet -> the residual stream, normed for layer 0's self attention
+  NSCHK(update_then_norm(m->w_final, w.ssum, dp, m->b_final, false, prec, nullptr, layer_cond(0, 0), w.xn));
   NSCHK(tap_f32(m, "wavenet.out", w.xres, (int64_t)M * dim, s));
 
   // ---- transformer (NS2:786-809)
-  const float* cbase = call + (size_t)S * L * 2 * dim;
   for (int l = 0; l < m->cfg.depth; ++l) {
     const ns2_model::Layer& ly = m->layers[l];
-    const float* cn = cbase + (size_t)l * m->nnorm * 2 * dim;
-    // self attention
-    PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn, cld, w.xn, dp, nullptr, 0, s));
+    const bool last = l + 1 == m->cfg.depth;
+    // self attention (its norm ran behind the previous update)
     PROF(PC_GEMM_QKV, gemm_qkv(ly.qkv, w.xn.hi, w.xn.lo, dp, M, N, 2 * a, w.qk.hi, w.qk.lo, 2 * a, w.vt.hi, w.vt.lo, w.Nkp, prec, s));
     PROF(PC_ATTENTION, attention_call(w.qk.hi, w.qk.lo, 2 * a, 0, w.qk.hi, w.qk.lo, 2 * a, a, w.vt, w.Nkp, w.o, a, B, H, N, N, prec, s));
-    PROF(PC_GEMM_F32, gemm_f32(ly.out, w.o.hi, w.o.lo, a, M, 0, 1, 0, nullptr, w.xres, dim, w.xres, dim, prec, s));
+    // out-projection + residual, then the norm of what follows: the cross attention (conditioned) or the feed-forward
+    NSCHK(update_then_norm(ly.out, w.o, a, nullptr, true, prec, nullptr, layer_cond(l, cond ? 1 : m->nnorm - 1), cond ? w.xn : xn_ff));
     snprintf(name, sizeof name, "layer%d.attn", l);
     NSCHK(tap_f32(m, name, w.xres, (int64_t)M * dim, s));
     if (cond) {   // cross attention to the resampled prompt tokens (NS2:799-803)
-      PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + 2 * dim, cld, w.xn, dp, nullptr, 0, s));
       PROF(PC_GEMM_SPLIT, gemm_split(ly.cq, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, w.xq.hi, w.xq.lo, a, prec, s, -1, 0, w.xq.fmt));
       PROF(PC_ATTENTION, attention_call(w.xq.hi, w.xq.lo, a, 0, cs.ck[l].hi, cs.ck[l].lo, a, 0, cs.cvt[l], cs.Lmp, w.o, a, B, H, N, Lm, xprec, s));
-      PROF(PC_GEMM_F32, gemm_f32(ly.cout, w.o.hi, w.o.lo, a, M, 0, 1, 0, nullptr, w.xres, dim, w.xres, dim, prec, s));
+      NSCHK(update_then_norm(ly.cout, w.o, a, nullptr, true, prec, nullptr, layer_cond(l, m->nnorm - 1), xn_ff));
     }
     // feedforward: Linear -> GEGLU -> causal conv k3 -> Linear (NS2:1009-1025); precision 6: the whole branch on dense IEEE-half planes
-    PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, nullptr, cn + (size_t)(m->nnorm - 1) * 2 * dim, cld, xn_ff, dp, nullptr, 0, s));
     PROF(PC_GEMM_GEGLU, gemm_geglu(ly.ffin, xn_ff.hi, xn_ff.lo, dp, M, ly.b_ffin, w.ffh_conv.hi, w.ffh_conv.lo, fp, ff_prec, s, w.ffh_conv.fmt));
     PROF(PC_GEMM_FFCONV, gemm_split(ly.conv, w.ffh_conv.hi, w.ffh_conv.lo, fp, M, 3, 1, N, ly.b_conv, ffc_ff.hi, ffc_ff.lo, fp,
                                     conv_prec, s, -1, 0, ffc_ff.fmt));
-    PROF(PC_GEMM_F32, gemm_f32(ly.ffout, ffc_ff.hi, ffc_ff.lo, fp, M, 0, 1, 0, ly.b_ffout, w.xres, dim, w.xres, dim, ff_prec, s));
+    // FF-out + residual, then the next layer's self-attention norm -- or to_pred's RMSNorm (learned gamma, NS2:781-784) after the last
+    NSCHK(update_then_norm(ly.ffout, ffc_ff, fp, ly.b_ffout, true, ff_prec, last ? m->g_pred : nullptr, last ? nullptr : layer_cond(l + 1, 0), w.xn));
     snprintf(name, sizeof name, "layer%d", l);
     NSCHK(tap_f32(m, name, w.xres, (int64_t)M * dim, s));
   }
-  // to_pred: RMSNorm -> Linear (NS2:781-784)
-  PROF(PC_NORM, norm_call(w.xres, dim, M, dim, N, m->g_pred, nullptr, 0, w.xn, dp, nullptr, 0, s));
+  // to_pred: Linear on the normed stream (NS2:781-784)
   PROF(PC_GEMM_F32, gemm_f32(m->w_pred, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, nullptr, 0, out, dim, prec, s));
   return NS2_OK;
 }

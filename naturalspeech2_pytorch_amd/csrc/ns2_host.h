@@ -20,6 +20,9 @@ struct PackedW {                 // bf16 split-plane weight, rows padded to 128,
 int gemm_f32(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
              const float* bias, const float* resid, int ldr, float* out, int ldo, int prec, hipStream_t s, int pad_left = -1,
              int act = 0);
+int gemm_f32_norm(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, const float* bias, const float* resid, int ldr,
+                  float* out, int ldo, int prec, int seq_len, const float* gamma, const float* cond, int cond_ld, bf16_t* n_hi, bf16_t* n_lo,
+                  int n_ld, int n_fmt, hipStream_t s, bool* fused);
 int gemm_split(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
                const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left = -1, int act = 0,
                int out_fmt = -1);

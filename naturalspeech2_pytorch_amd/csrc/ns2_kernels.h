@@ -80,6 +80,12 @@ struct GemmArgs {
   // one slice covers (slice z: input columns [z * ksplit * 32, ...) of each tap); 0 = the plain launch.
   float* sk_ws; long sk_ws_floats;
   int ksplit;
+  // EPI_F32 on the 128 x 128 kernel with N == 128 (the dim = 128 model: a workgroup owns WHOLE rows): the RMSNorm that follows the
+  // residual stream's update (NS2:727-746, 794-807) inside the same epilogue -- out_f = acc + bias + resid as always, then
+  // nrm planes = F.normalize(out_f row) * sqrt(N) [* nrm_gamma] [* cond_g + cond_b] in format nrm_fmt, the next GEMM's operand.
+  // nrm_hi == null: not requested.  gemm_fuses_norm() says whether launch_gemm will honour it for a given shape.
+  bf16_t* nrm_hi; bf16_t* nrm_lo; int nrm_ld, nrm_fmt;
+  const float* nrm_gamma; const float* nrm_cond; int nrm_cond_ld, nrm_seq_len;
   // launch_gemm_tr only (weight gradients from token-major planes, gemm2.hip TR): tokens the operands have, channels per tap block of
   // the N dimension (a multiple of 32), taps (0 / 1: no shift; tap t of a causal conv reads token m - (tr_taps - 1 - t) * dil)
   int tr_tokens, tr_kp, tr_taps;
@@ -88,6 +94,7 @@ struct GemmArgs {
 // precision: 3 = bf16 x3 ("exact"), 1 = bf16 ("fast"), 2 = one IEEE-half product ("half"), 4 = half product + both
 // first-order correction terms on the fp8 MFMA ("mixed", FMT_H8 operands).  Dispatches gemm.hip / gemm2.hip by shape.
 hipError_t launch_gemm(const GemmArgs& g, int precision, hipStream_t s);
+bool gemm_fuses_norm(const GemmArgs& g, int precision);                 // gemm2.hip: the shape takes the 128 x 128 kernel's whole-row epilogue (no split-K)
 hipError_t launch_gemm_tr(const GemmArgs& g, int precision, hipStream_t s);   // gemm2.hip: both operands read transposed (precision 3 / 4)
 void splitk_plan(int M, int N, int nkt, int kt_per_tap, bool epi_f32, long scratch_floats, int* S, int* c);   // gemm2.hip; S = 1: no split
 void force_gemm_kernel(int k);                                          // 0 auto, 1 = 128x128, 2 = 256x256, 3 = auto without split-K (test hook); a forced kernel never splits K
