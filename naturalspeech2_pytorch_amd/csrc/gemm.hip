@@ -517,6 +517,52 @@ __global__ __launch_bounds__(256) void splitk_finish_f32_kernel(const float* par
   *reinterpret_cast<float4*>(out + (long)row * ldo + c) = v;
 }
 
+// The same finishing pass with the RMSNorm that follows the residual update (GemmArgs::nrm_*; round 5): N = 128, 256 or 512, so a row
+// is 32 / 64 / 128 threads of a 256-thread block (N4 = N / 4 threads, 256 / N4 rows per block): the row's sum of squares is a wave
+// reduction plus, for N = 512, one exchange between the two waves of the row through LDS, added in a fixed order.  Small batches (1 .. 8
+// utterances: every N = dim product is split over K) lose their rmsnorm launches this way -- 13 of the ~58 launches of a dim-128 step.
+template <int N4>
+__global__ __launch_bounds__(256) void splitk_finish_f32_norm_kernel(const float* part, int S, long slot, int ldp, int M, const float* bias,
+                                                                     const float* resid, int ldr, float* out, int ldo, GemmArgs g) {
+  constexpr int RPB = 256 / N4;                                  // rows per block
+  __shared__ float s_sum[4];
+  const int tid = threadIdx.x;
+  const int rloc = tid / N4, c = (tid - rloc * N4) * 4;
+  const long row_raw = (long)blockIdx.x * RPB + rloc;
+  const bool ok = row_raw < M;
+  const long row = ok ? row_raw : M - 1;                         // every lane computes (the reductions need them); only valid rows store
+  const float* p = part + row * ldp + c;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sl = 0; sl < S; ++sl) {
+    const float4 t = *reinterpret_cast<const float4*>(p + sl * slot);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  if (bias) { v.x += bias[c]; v.y += bias[c + 1]; v.z += bias[c + 2]; v.w += bias[c + 3]; }
+  if (resid) {
+    const float4 r = *reinterpret_cast<const float4*>(resid + row * ldr + c);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  if (ok) *reinterpret_cast<float4*>(out + row * ldo + c) = v;
+  float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+  for (int d = 1; d < (N4 < 64 ? N4 : 64); d <<= 1) ss += __shfl_xor(ss, d, 64);
+  if constexpr (N4 > 64) {                                       // N = 512: waves 2 r, 2 r + 1 hold the two halves of row r
+    if ((tid & 63) == 0) s_sum[tid >> 6] = ss;
+    __syncthreads();
+    ss = s_sum[2 * rloc] + s_sum[2 * rloc + 1];
+  }
+  const float inv = sqrtf((float)(4 * N4)) / fmaxf(sqrtf(ss), 1e-12f);
+  float o[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+  if (g.nrm_gamma) { const float4 t = *reinterpret_cast<const float4*>(g.nrm_gamma + c); o[0] *= t.x; o[1] *= t.y; o[2] *= t.z; o[3] *= t.w; }
+  if (g.nrm_cond) {
+    const float* gc = g.nrm_cond + (g.nrm_seq_len > 0 ? row / g.nrm_seq_len : 0) * (long)g.nrm_cond_ld;
+    const float4 t = *reinterpret_cast<const float4*>(gc + c), u = *reinterpret_cast<const float4*>(gc + 4 * N4 + c);
+    o[0] = o[0] * t.x + u.x; o[1] = o[1] * t.y + u.y; o[2] = o[2] * t.z + u.z; o[3] = o[3] * t.w + u.w;
+  }
+  const bool nil = g.nrm_lo != nullptr;
+  if (ok) store_cols4(g.nrm_hi + row * pld(g.nrm_ld, nil), c, o[0], o[1], o[2], o[3], g.nrm_fmt, nil);
+}
+
 hipError_t launch_gemm1(const GemmArgs& g, int precision, hipStream_t s);
 // g: validated by launch_gemm, formats resolved; S slices of c K tiles per tap
 hipError_t launch_gemm_splitk(const GemmArgs& g, int precision, int S, int c, hipStream_t s) {
@@ -526,7 +572,7 @@ hipError_t launch_gemm_splitk(const GemmArgs& g, int precision, int S, int c, hi
   GemmArgs p = g;
   p.epi = EPI_F32; p.bias = nullptr; p.bias2 = nullptr; p.resid = nullptr; p.act = 0; p.film = nullptr;
   p.out_f = g.sk_ws; p.ldo_f = ldp; p.out_f_zs = slot;
-  p.out_hi = nullptr; p.out_lo = nullptr; p.vt_hi = nullptr; p.vt_lo = nullptr;
+  p.out_hi = nullptr; p.out_lo = nullptr; p.vt_hi = nullptr; p.vt_lo = nullptr; p.nrm_hi = nullptr; p.nrm_lo = nullptr;
   p.nz = S; p.a_zs = 0; p.w_zs = 0; p.dil_z = 0; p.ksplit = c;
   // the slots are ldp = round_up(N, 64) wide and the packed weight's padding rows are zeros: let the slices write whole 64-column
   // wave tiles (the vectorised fp32 epilogue; a ragged last tile took the per-value one: 41 us instead of ~25 for the FF conv's slices)
@@ -538,6 +584,14 @@ hipError_t launch_gemm_splitk(const GemmArgs& g, int precision, int S, int c, hi
     case EPI_F32:
       if ((g.N & 3) == 0 && (g.ldo_f & 3) == 0 && (reinterpret_cast<uintptr_t>(g.out_f) & 15) == 0 &&
           (!g.resid || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.resid) & 15) == 0))) {
+        if (g.nrm_hi) {                                          // (gemm_fuses_norm: N in {128, 256, 512}, no activation)
+          const int rpb = 256 / (g.N >> 2);
+          const dim3 grid((unsigned)((g.M + rpb - 1) / rpb));
+          if (g.N == 128) hipLaunchKernelGGL(splitk_finish_f32_norm_kernel<32>, grid, dim3(256), 0, s, g.sk_ws, S, slot, ldp, g.M, g.bias, g.resid, g.ldr, g.out_f, g.ldo_f, g);
+          else if (g.N == 256) hipLaunchKernelGGL(splitk_finish_f32_norm_kernel<64>, grid, dim3(256), 0, s, g.sk_ws, S, slot, ldp, g.M, g.bias, g.resid, g.ldr, g.out_f, g.ldo_f, g);
+          else hipLaunchKernelGGL(splitk_finish_f32_norm_kernel<128>, grid, dim3(256), 0, s, g.sk_ws, S, slot, ldp, g.M, g.bias, g.resid, g.ldr, g.out_f, g.ldo_f, g);
+          break;
+        }
         const long n = (long)g.M * (g.N >> 2);
         hipLaunchKernelGGL(splitk_finish_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g.sk_ws, S, slot, ldp, g.M, g.N,
                            g.bias, g.resid, g.ldr, g.act, g.out_f, g.ldo_f);

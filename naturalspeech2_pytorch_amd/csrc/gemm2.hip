@@ -1080,18 +1080,19 @@ void splitk_plan(int M, int N, int nkt, int kt_per_tap, bool epi_f32, long scrat
 // would be padding, e.g. the dim=128 model's d x d projections).  W rows are padded to 256 by the packers.
 // Does this product take the one-launch 128 x 128 kernel whose workgroups own whole rows (N == 128), so that its fp32 epilogue can run
 // the RMSNorm that follows (GemmArgs::nrm_*)?  Not when K is split (the finishing launch runs the epilogue) or the big kernel is forced.
+// Two cases: (a) K is split (small batches): the flat finishing launch owns whole rows whatever the tile -- N = 128, 256 or 512;
+// (b) one launch of the 128 x 128 kernel with N == 128 == BN and M % 128 == 0 (the dim = 128 model at full batch).
 bool gemm_fuses_norm(const GemmArgs& g, int precision) {
-  if (g.epi != EPI_F32 || g.N != 128 || g.M <= 0 || (g.M % 128) || g.act != 0 || g.nz > 1 || g.ksplit != 0) return false;
+  if (g.epi != EPI_F32 || g.M <= 0 || g.act != 0 || g.nz > 1 || g.ksplit != 0 || g.dil_z) return false;
   if ((g.ldo_f & 3) || (reinterpret_cast<uintptr_t>(g.out_f) & 15) || (g.resid && ((g.ldr & 3) || (reinterpret_cast<uintptr_t>(g.resid) & 15)))) return false;
   const int f = forced_kernel();
-  if (f == 2) return false;
-  if (f == 0 && g.sk_ws && !g.dil_z) {
+  if (f == 0 && g.sk_ws) {
     int S, c;
     splitk_plan(g.M, g.N, g.nkt, g.kt_per_tap, true, g.sk_ws_floats, &S, &c);
-    if (S >= 2) return false;
+    if (S >= 2) return g.N == 128 || g.N == 256 || g.N == 512;
   }
   (void)precision;
-  return true;
+  return f != 2 && g.N == 128 && (g.M % 128) == 0;
 }
 
 hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {

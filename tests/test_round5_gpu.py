@@ -330,3 +330,32 @@ def test_fused_optimizer_steps_reach_the_packed_weights(fused):
     worst = max(abs(a - b) / abs(b) for a, b in zip(h, c))
     record(f"training_trajectory_hip_vs_composite/adam_fused_{int(fused)}/worst_rel_loss_difference_over_7_steps", worst)
     assert worst < 2e-3, (h, c)                                             # stale packs gave 4e-2 at step 1 already
+
+
+# ------------------------------------------------------------------------------------------------ residual update + RMSNorm in one launch (dim = 128)
+@pytest.mark.parametrize("prec,tol", [("exact", 1e-4), ("hybrid", 2.5e-4), ("mixed", 2.5e-4), ("half", 1e-3), ("hybrid_ff", 4e-4)])
+@pytest.mark.parametrize("conditioned", [False, True])
+def test_whole_row_epilogue_runs_the_norm_at_dim_128(prec, tol, conditioned):
+    """At dim = 128 the GEMMs that update the residual stream own whole rows (N == BN == 128) and run the following RMSNorm in their
+    epilogue when M % 128 == 0 (gemm.hip EPI_F32 nrm_*; model_exec.cpp update_then_norm): adaptive norms in front of self attention,
+    cross attention and feed-forward, and to_pred's learned-gamma norm.  Against the fp32 oracle, and a batch whose M is NOT a multiple
+    of 128 (separate rmsnorm_kernel) must give the same utterances within the two paths' rounding."""
+    from oracle import ns2_oracle as O
+    kw = dict(dim=128, depth=2, dim_prompt=128, condition_on_prompt=True) if conditioned else dict(dim=128, depth=2)
+    m, sd = _model(kw, seed=31, precision=prec)
+    x = make_input("x", (3, 256, 128), seed=32)                       # M = 768: fused;  the first utterance alone, 250 frames: not
+    t = make_input("times", (3,), seed=32, uniform=True)
+    extra = {}
+    if conditioned:
+        extra = dict(prompt=make_input("prompt", (3, 40, 128), seed=33), cond=make_input("cond", (3, 128, 256), seed=33))
+    with torch.no_grad():
+        y = m(x.to(DEV), t.to(DEV), **{k: v.to(DEV) for k, v in extra.items()}).cpu()
+        ref = O.model_forward(sd, x, t, **extra)
+        y1 = m(x[:1, :250].to(DEV), t[:1].to(DEV), **{k: (v[:1, :, :250] if k == "cond" else v[:1]).to(DEV) for k, v in extra.items()}).cpu()
+        ref1 = O.model_forward(sd, x[:1, :250], t[:1], **{k: (v[:1, :, :250] if k == "cond" else v[:1]) for k, v in extra.items()})
+        # one utterance of 256 frames: every N = 128 product is split over K and the FINISHING launch runs the norm (gemm.hip
+        # splitk_finish_f32_norm_kernel); it must reproduce the utterance of the full batch (rows are independent)
+        y2 = m(x[:1].to(DEV), t[:1].to(DEV), **{k: v[:1].to(DEV) for k, v in extra.items()}).cpu()
+    e, e1, e2 = rel(y, ref), rel(y1, ref1), rel(y2, ref[:1])
+    record(f"fused_norm_d128/{'cond' if conditioned else 'uncond'}/{prec}", max(e, e2))
+    assert e < tol and e1 < tol and e2 < tol, (e, e1, e2)
