@@ -81,9 +81,9 @@ def train_step_side(dev):
     import torch
     from naturalspeech2_pytorch_amd import Model, NaturalSpeech2
     out = {}
-    for tag, kw, b, n, iters in (("config1_d128_L6_b4", dict(dim=128, depth=6), 4, 1024, 6), ("headline_d512_L12_b32", dict(dim=512, depth=12), 32, 1024, 5)):
+    for tag, kw, b, n, iters in (("config1_d128_L6_b4", dict(dim=128, depth=6), 4, 1024, 8), ("headline_d512_L12_b32", dict(dim=512, depth=12), 32, 1024, 6)):
         res = {}
-        for name, backend, tprec, k in (("mixed", "hip", "mixed", iters), ("exact", "hip", "exact", iters), ("composite", "composite", "exact", 2)):
+        for name, backend, tprec, k in (("mixed", "hip", "mixed", iters), ("exact", "hip", "exact", iters), ("composite", "composite", "exact", 2)):   # k timed steps (two windows)
             torch.manual_seed(0)
             m = Model(**kw).to(dev).train()
             m.train_backend, m.train_precision = backend, tprec
@@ -101,12 +101,19 @@ def train_step_side(dev):
 
             for _ in range(2):
                 step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(k):
-                loss = step()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / k
+            # two timed windows, the faster one is reported: the step issues ~2000 launches from Python, and a neighbour's CPU load on
+            # the box (the pod's GPU slots share the host) once turned a 100 ms step into 150 ms for one window (profiles/README.md)
+            wins = []
+            for kw_ in ((k + 1) // 2, k // 2):
+                if kw_ == 0:
+                    continue
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(kw_):
+                    loss = step()
+                torch.cuda.synchronize()
+                wins.append((time.perf_counter() - t0) / kw_)
+            dt = min(wins)
             for _ in range(iters - k):                   # (untimed) so that every backend reports the loss of the SAME iteration
                 loss = step()
             res[name] = (dt, float(loss.detach()))
@@ -126,7 +133,7 @@ def train_step_side(dev):
                         pytorch_composite_ms_per_step=round(1e3 * res["composite"][0], 2),
                         speedup_vs_pytorch_composite=round(res["composite"][0] / res[best][0], 2),
                         loss_mixed=res["mixed"][1], loss_exact=res["exact"][1], loss_composite=res["composite"][1],
-                        loss_iteration=f"all after 2 warm-up + {iters} Adam steps from the same init",
+                        loss_iteration=f"all after 2 warm-up + {iters} Adam steps from the same init", timing="the faster of two timed windows of steps",
                         parity="every parameter's .grad vs the reference's own autograd in both arithmetics: tests/test_backward_gpu.py, "
                                "tests/test_round5_gpu.py, profiles/r05_parity.json keys backward_vs_reference_autograd/*")
     return out
