@@ -97,7 +97,8 @@ class _PackedCache:
         return lib_part(pw.handle, base, sr, sc, st, row0, rows, col0, cols)
 
     def _signature(self):
-        return tuple((k, tuple(p.data_ptr() for p in (r() for r in v[4]) if p is not None)) for k, v in self.map.items())
+        # (storage and trainability of every parameter: a re-allocated, frozen or unfrozen parameter rebuilds the table)
+        return tuple((k, tuple((p.data_ptr(), p.requires_grad) for p in (r() for r in v[4]) if p is not None)) for k, v in self.map.items())
 
     def _repack_all(self):
         """every trainable entry with a `parts` description in one launch; False when some entry cannot be described"""
@@ -106,11 +107,12 @@ class _PackedCache:
         lib = _lib.load()
         sig = self._signature()
         if self._table is None or self._table[0] != sig:
-            parts = []
-            for v in self.map.values():
+            parts, keys = [], set()
+            for k, v in self.map.items():
                 params = [r() for r in v[4]]
                 if not any(p.requires_grad for p in params):
                     continue
+                keys.add(k)
                 for (idx, mode, row0, col0) in v[6]:
                     parts.append(self._part(_lib.RepackPart, v[0], params[idx], mode, row0, col0))
             if not parts:
@@ -121,17 +123,17 @@ class _PackedCache:
             table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             total = ctypes.c_int64(0)
             check(lib.ns2_weights_repack_build(arr, len(parts), table.data_ptr(), nbytes, ctypes.byref(total), _s()), "ns2_weights_repack_build")
-            self._table = (sig, table, len(parts), total.value)
-        _, table, n, total = self._table
+            self._table = (sig, table, len(parts), total.value, keys)
+        _, table, n, total, _ = self._table
         check(lib.ns2_weights_repack(table.data_ptr(), n, total, _s()), "ns2_weights_repack")
         return True
 
     def begin_pass(self):
         self.pass_id += 1
         if self.pass_id > 1 and self._repack_all():
-            for k, v in self.map.items():                                    # fresh for this pass (versions as they are now)
-                params = [r() for r in v[4]]
-                self.map[k] = (v[0], tuple((p.data_ptr(), p._version) for p in params), v[2], v[3], v[4], self.pass_id, v[6])
+            for k in self._table[4]:                                         # what the launch re-packed is fresh for this pass
+                v = self.map[k]                                              # (a frozen weight is not in the table: its version rule stands)
+                self.map[k] = (v[0], tuple((p.data_ptr(), p._version) for p in (r() for r in v[4])), v[2], v[3], v[4], self.pass_id, v[6])
 
     def _purge(self):
         dead = [k for k, v in self.map.items() if any(r() is None for r in v[4])]

@@ -300,6 +300,37 @@ def test_wgrad_from_row_planes(prec, R, K, T, M, dil, seq):
 
 
 # ------------------------------------------------------------------------------------------------ optimizers that do not bump version counters
+def test_packs_follow_freezing_and_unfreezing():
+    """the one-launch re-pack covers the TRAINABLE packs of a pass; a block frozen for three steps and then unfrozen must train exactly as
+    it does on the PyTorch composite (the table is rebuilt when trainability changes; a frozen pack is never marked fresh by the launch)"""
+    from naturalspeech2_pytorch_amd import NaturalSpeech2
+    traj = {}
+    for backend in ("hip", "composite"):
+        torch.manual_seed(0)
+        m = Model(dim=128, depth=2).to(DEV).train()
+        m.train_backend = backend
+        d = NaturalSpeech2(m, codec=None, target_sample_hz=24000).to(DEV)
+        frozen = [p for n, p in m.named_parameters() if n.startswith("wavenet")]
+        for p in frozen:
+            p.requires_grad_(False)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)
+        g = torch.Generator().manual_seed(1)
+        audio, times, noise = torch.randn(2, 256, 128, generator=g).to(DEV), torch.rand(2, generator=g).to(DEV), torch.randn(2, 256, 128, generator=g).to(DEV)
+        ls = []
+        for i in range(8):
+            if i == 3:
+                for p in frozen:
+                    p.requires_grad_(True)
+            opt.zero_grad(set_to_none=True)
+            loss = d(audio, times=times, noise=noise)
+            loss.backward()
+            opt.step()
+            ls.append(float(loss.detach()))
+        traj[backend] = ls
+    worst = max(abs(a - b) / abs(b) for a, b in zip(traj["hip"], traj["composite"]))
+    assert worst < 2e-3, traj
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_fused_optimizer_steps_reach_the_packed_weights(fused):
     """torch.optim.Adam(fused=True) updates parameters in place WITHOUT moving their version counters; the packed GEMM weights of the
@@ -322,7 +353,7 @@ def test_fused_optimizer_steps_reach_the_packed_weights(fused):
             loss = d(audio, times=times, noise=noise)
             loss.backward()
             opt.step()
-            ls.append(float(loss))
+            ls.append(float(loss.detach()))
         traj[backend] = ls
     h, c = traj["hip"], traj["composite"]
     assert abs(h[0] - c[0]) < 1e-5 * abs(c[0])
