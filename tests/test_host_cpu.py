@@ -687,3 +687,22 @@ def test_seanet_narrow_resblock_weight_arrangement(monkeypatch):
         h = torch.stack([nr["b1"] + sum(ex[idx(n - 2 + t)] @ nr["w1p"][t] for t in range(3)) for n in range(T)])
         got = nr["b2s"] + torch.nn.functional.elu(h) @ nr["w2p"] + x @ nr["wsp"]
     assert torch.allclose(got, ref, atol=1e-5), (got - ref).abs().max()
+
+
+def test_wgrad_route_and_repack_table_host_arithmetic():
+    """host-only entry points of the round-5 training ABI: which weight gradients take the row-plane (transposed-read) kernel -- the
+    headline model's all do, the dim = 128 model's and short batches keep the transposed route where launch_gemm picks the 128 x 128
+    kernel -- and the size of the one-launch re-pack table"""
+    lib = _lib.load()
+    M = 32 * 1024
+    for R, ncols in ((512, 512), (512, 3 * 512), (1536, 512), (2730, 512), (512, 1376), (1365, 3 * 1376)):
+        assert lib.ns2_wgrad_rows_preferred(R, ncols, M) == 1, (R, ncols)
+    assert lib.ns2_wgrad_rows_preferred(128, 512, 4096) == 0            # R = 128: half-empty 256-row tiles
+    assert lib.ns2_wgrad_rows_preferred(512, 128, M) == 0               # one 128-column strip
+    assert lib.ns2_wgrad_rows_preferred(512, 512, 256) == 0             # a handful of tokens: <= 64 blocks
+    assert lib.ns2_wgrad_rows_preferred(512, 512, 0) == 0
+    assert lib.ns2_weights_repack_table_bytes(0) == 0
+    b1, b270 = lib.ns2_weights_repack_table_bytes(1), lib.ns2_weights_repack_table_bytes(270)
+    assert b1 > 0 and b270 == 270 * b1
+    # workspace of the row-plane route = the transposed route's (same slots): R x ncols floats per slice
+    assert lib.ns2_wgrad_workspace_bytes(512, 512, M) % (512 * 512 * 4) == 0

@@ -271,3 +271,49 @@ def test_mixed_training_arithmetic_needs_and_gets_its_loss_scale(cond):
     worst = max(_rel(g1[k], g0[k]) for k in g0)
     assert _rel(dx1, dx0) < 3e-4 and worst < 3e-4, (_rel(dx1, dx0), worst)
     assert max(_rel(g2[k], g0[k]) for k in g0) > 1e-2                                    # unscaled: garbage
+
+
+def test_repack_parts_describe_the_sources_the_packs_were_made_from():
+    """`_PackedCache._part` tells ns2_weights_repack where a rectangle of a packed weight lives in the PARAMETER's own storage (strides in
+    elements, possibly negative).  Walking the parameter through those strides on the CPU must rebuild exactly the matrix `make_src`
+    hands to the first pack -- for the forward pack, the dgrad pack of a Linear (W^T), of a causal conv (W^T with flipped taps) and
+    the q | kv concatenations (two parts, by rows / by columns)."""
+    from naturalspeech2_pytorch_amd.training import _PackedCache
+
+    class PW:
+        handle = 0
+
+    def rebuild(shape, params, parts):
+        out = torch.full(shape, float("nan"))
+        for (idx, mode, row0, col0) in parts:
+            p = params[idx]
+            desc = _PackedCache._part(lambda h, base, sr, sc, st, r0, rows, c0, cols: (base, sr, sc, st, r0, rows, c0, cols), PW(), p, mode, row0, col0)
+            base, sr, sc, st, r0, rows, c0, cols = desc
+            flat = p.detach().reshape(-1)
+            off0 = (base - p.data_ptr()) // 4
+            T = shape[2] if len(shape) == 3 else 1
+            for r in range(rows):
+                for c in range(cols):
+                    for t in range(T):
+                        v = flat[off0 + r * sr + c * sc + t * st]
+                        if len(shape) == 3:
+                            out[r0 + r, c0 + c, t] = v
+                        else:
+                            out[r0 + r, c0 + c] = v
+        return out
+
+    g = torch.Generator().manual_seed(0)
+    w_lin = torch.nn.Parameter(torch.randn(6, 10, generator=g))
+    w_conv = torch.nn.Parameter(torch.randn(5, 7, 3, generator=g))
+    wq, wkv = torch.nn.Parameter(torch.randn(8, 6, generator=g)), torch.nn.Parameter(torch.randn(16, 6, generator=g))
+    cases = [
+        ((w_lin,), [(0, "n", 0, 0)], w_lin.detach()),
+        ((w_conv,), [(0, "n", 0, 0)], w_conv.detach()),
+        ((w_lin,), [(0, "t", 0, 0)], w_lin.detach().t()),
+        ((w_conv,), [(0, "tf", 0, 0)], w_conv.detach().permute(1, 0, 2).flip(-1)),
+        ((wq, wkv), [(0, "n", 0, 0), (1, "n", 8, 0)], torch.cat((wq.detach(), wkv.detach()), 0)),
+        ((wq, wkv), [(0, "t", 0, 0), (1, "t", 0, 8)], torch.cat((wq.detach(), wkv.detach()), 0).t()),
+    ]
+    for params, parts, want in cases:
+        got = rebuild(tuple(want.shape), params, parts)
+        assert torch.equal(got, want.contiguous()), (parts, got, want)
