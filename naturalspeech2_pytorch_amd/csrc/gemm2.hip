@@ -425,9 +425,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
   const bf16_t* psrc[4][2];      // [A0, A1, B0, B1][piece]: source row pointer at K offset 0
   int pnseq[2][2];               // A pieces: position inside the utterance (-2^30 = row >= M)
   int pldst[4][2];               // LDS byte offset inside a stage (wave-uniform)
-  // TR: a piece = 8 tokens (lane row lrow) of ONE 32-channel group: row group rg = 4 * channel group + token block; psrc = the
-  // channel group's column in this lane's token row of the slice's first K tile (the zero page when the group lies beyond the operand), pnseq = the piece's first token inside a K
-  // tile (A and B), ptshift = the tap shift of a B piece's channel group in tokens
+  // TR: a piece = 8 tokens of ONE 32-channel group: row group rg = 4 * channel group + token block.  psrc = this lane's 16 bytes of
+  // that group in ITS token row of the slice's first K tile (tap shift applied; the zero page when the group lies beyond the operand),
+  // ptok = the lane's token inside a K tile, ptshift = the tap shift of a B piece's channel group in tokens
   int ptok[4][2], ptshift[2][2];
   bool pvalid[4][2];             // (wave-uniform) the piece's channel group exists in the operand
   // TR LDS image of a piece (1 KiB = 8 tokens x the 128-B line of one channel group): eight 128-B BLOCKS, each exactly what one
