@@ -706,3 +706,77 @@ def test_wgrad_route_and_repack_table_host_arithmetic():
     assert b1 > 0 and b270 == 270 * b1
     # workspace of the row-plane route = the transposed route's (same slots): R x ncols floats per slice
     assert lib.ns2_wgrad_workspace_bytes(512, 512, M) % (512 * 512 * 4) == 0
+
+
+def test_lds_transpose_read_layouts_deliver_the_fragments_the_mfma_expects():
+    """A pure-Python model of the two kernels that read their operands TRANSPOSED out of LDS (round 5), against the probed semantics of
+    gfx950's transpose reads (profiles/r05_lds_transpose_read_probe.txt):
+        ds_read_b64_tr_b16: lane i of a 16-lane group receives, as element j, the 16-bit word (i % 4) at the address lane 4 j + i // 4 supplied
+        ds_read_b64_tr_b8:  ... as byte j, the byte (i % 8) at the address lane 2 j + i // 8 supplied.
+    (1) gemm2.hip TR (weight gradients): the DMA lane -> (token, chunk) assignment, the eight-block piece image and the read offsets must hand
+    lane (tg, i16, hi) the tokens 16 kc + 8 hi + 4 q .. + 3 (16-bit) / 8 q .. + 7 (bytes) of channel 16 tg + i16.
+    (2) backward.hip attn_bwd2: chunk c of tile row r is stored at c ^ f(r); the 16 rows of a ds_read_b128 group and the 4 rows of a
+    transpose block must land on distinct bank groups, and the transpose read must return walked rows .. + 3 of the lane's d column."""
+    # ---------------- (1) the TR piece image, FMT_H8 (mixed) and bf16 hi / lo (exact)
+    for nsplit in (2, 3):
+        lds = {}                                            # byte offset inside the 4 pieces of a channel group -> (token, byte of the source line)
+        for piece in range(4):                              # tokens 8 piece .. + 7
+            for lane in range(64):
+                b, w = lane >> 3, lane & 7
+                bytes_blk = nsplit == 2 and b >= 4
+                tokp = w if bytes_blk else 4 * ((b >> 1) & 1) + (w >> 1)
+                lchunk = b if bytes_blk else ((4 * (b >> 2) if nsplit == 3 else 0) + 2 * (b & 1) + (w & 1))
+                for k in range(16):
+                    lds[piece * 1024 + lane * 16 + k] = (8 * piece + tokp, lchunk * 16 + k)
+        assert len(lds) == 4096 and len(set(lds.values())) == 4096          # every byte of the 32 token lines exactly once
+        for lane in range(64):
+            i16, tg, hi = lane & 15, (lane >> 4) & 1, lane >> 5
+            grp = [l for l in range(64) if l >> 4 == lane >> 4]
+            for p in range(2 if nsplit == 3 else 1):
+                for kc in range(2):
+                    for q in range(2):
+                        addr = {l: (l >> 5) * 1024 + (4 * p + 2 * q + ((l >> 4) & 1)) * 128 + (l & 15) * 8 + kc * 2048 for l in grp}
+                        for j in range(4):
+                            src = addr[grp[4 * j + i16 // 4]] + 2 * (i16 % 4)
+                            tok, byte = lds[src]
+                            assert tok == 16 * kc + 8 * hi + 4 * q + j and byte == p * 64 + 2 * (16 * tg + i16), (nsplit, lane, p, kc, q, j)
+            if nsplit == 2:
+                for ws in range(2):
+                    part = (1 - hi) if ws else hi            # A: lanes 0-31 h8, 32-63 l8;  W: the other way round
+                    for q in range(4):
+                        addr = {l: (4 + 2 * ((1 - (l >> 5)) if ws else (l >> 5)) + ((l >> 4) & 1)) * 128 + (l & 15) * 8 + q * 1024 for l in grp}
+                        for j in range(8):
+                            tok, byte = lds[addr[grp[2 * j + i16 // 8]] + i16 % 8]
+                            assert tok == 8 * q + j and byte == 64 + 32 * part + 16 * tg + i16, (lane, ws, q, j)
+    # ---------------- (2) the attention backward tile image
+    f = lambda r: ((r & 3) << 2) | ((r >> 2) & 3)           # noqa: E731
+    tile = {}                                               # byte offset -> (row, byte of the row's 256 source bytes)
+    for j in range(16):                                     # DMA instruction j: rows 4 j .. + 3
+        for lane in range(64):
+            row, pos = 4 * j + (lane >> 4), lane & 15
+            lc = pos ^ f(row)
+            for k in range(16):
+                tile[j * 1024 + lane * 16 + k] = (row, lc * 16 + k)
+    assert len(set(tile.values())) == 64 * 256
+    for r0 in range(0, 64, 16):                             # a ds_read_b128 group: 16 rows, the same logical chunk -> 16 distinct positions
+        for c in range(16):
+            assert len({(c ^ f(r)) for r in range(r0, r0 + 16)}) == 16
+    for r0 in range(0, 64, 4):                              # a transpose block: 4 rows x 4 adjacent chunks -> the four 64-byte quarters
+        for c0 in range(0, 16, 4):
+            assert len({(c0 ^ f(r)) >> 2 for r in range(r0, r0 + 4)}) == 4
+    for lane in range(64):
+        i16, tg, hi = lane & 15, (lane >> 4) & 1, lane >> 5
+        grp = [l for l in range(64) if l >> 4 == lane >> 4]
+        for js in range(2):
+            for g1 in range(2):
+                for dt in range(2):
+                    for p in range(2):
+                        for q in range(2):
+                            def addr(l):
+                                row = 32 * js + 16 * g1 + 8 * (l >> 5) + 4 * q + ((l & 15) >> 2)
+                                lc = dt * 8 + p * 4 + 2 * ((l >> 4) & 1) + (((l & 15) >> 1) & 1)
+                                return row * 256 + ((lc ^ f(row)) << 4) + (l & 1) * 8
+                            for j in range(4):
+                                row, byte = tile[addr(grp[4 * j + i16 // 4]) + 2 * (i16 % 4)]
+                                d = 16 * tg + i16                      # the lane's d column inside the 32-column half dt
+                                assert row == 32 * js + 16 * g1 + 8 * hi + 4 * q + j and byte == dt * 128 + p * 64 + 2 * d, (lane, js, g1, dt, p, q, j)
