@@ -410,6 +410,10 @@ typedef struct {
   float* dk; int lddk, dk_col0;
   float* dv; int lddv, dv_col0;
   int B, H, Nq, Nk; float scale;
+  /* round 5: gp_q / gp_kv != 0 -- that half of the gradients leaves the kernel as OPERAND PLANES instead of fp32 (the q | k | v projection's
+   * dgrad and wgrad GEMMs are their only consumers): planes [rows, gp_ld] of precision gp_precision (3: bf16 hi / lo lines, 4: FMT_H8),
+   * dq at columns dq_col0 + 64 h of row b Nq + q, dk / dv at dk_col0 / dv_col0 + 64 h of row b Nk + k (column offsets multiples of 32) */
+  uint16_t* gp_hi; uint16_t* gp_lo; int gp_ld, gp_precision, gp_q, gp_kv;
 } ns2_attn_bwd_args;
 int ns2_attention_bwd(const ns2_attn_bwd_args* args, void* stream);
 

@@ -37,7 +37,8 @@ class AttnBwdArgs(ctypes.Structure):
                 ("dq", P), ("lddq", I), ("dq_col0", I),
                 ("dk", P), ("lddk", I), ("dk_col0", I),
                 ("dv", P), ("lddv", I), ("dv_col0", I),
-                ("B", I), ("H", I), ("Nq", I), ("Nk", I), ("scale", F)]
+                ("B", I), ("H", I), ("Nq", I), ("Nk", I), ("scale", F),
+                ("gp_hi", P), ("gp_lo", P), ("gp_ld", I), ("gp_precision", I), ("gp_q", I), ("gp_kv", I)]
 
 
 class RepackPart(ctypes.Structure):

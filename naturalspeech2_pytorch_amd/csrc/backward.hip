@@ -791,6 +791,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(const AttnBwdArgs a) 
 
   // ---- store: lane holds d = 32 dt + 8 gq + 4 hi + e of its own row
   if (!own_ok) return;
+  if (ROLE == 0 ? a.gp_q : a.gp_kv) {
+    // operand planes: the lane's 4-column groups of its own row (lanes l31 and l31 + 32 interleave the groups of a 32-column line)
+    bf16_t* prow = a.gp_hi + ((long)b * Nown + orow) * 2L * a.gp_ld;
+    const int c1 = (ROLE == 0 ? a.dq_col0 : a.dk_col0) + h * 64, c2 = a.dv_col0 + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int dcol = 32 * dt + 8 * gq + 4 * hi;
+        store_cols4(prow, c1 + dcol, acc1[dt][4 * gq] * a.scale, acc1[dt][4 * gq + 1] * a.scale, acc1[dt][4 * gq + 2] * a.scale,
+                    acc1[dt][4 * gq + 3] * a.scale, a.gp_fmt, true);
+        if constexpr (ROLE == 1)
+          store_cols4(prow, c2 + dcol, acc2[dt][4 * gq], acc2[dt][4 * gq + 1], acc2[dt][4 * gq + 2], acc2[dt][4 * gq + 3], a.gp_fmt, true);
+      }
+    return;
+  }
   float* o1 = ROLE == 0 ? a.dq + ((long)b * a.Nq + orow) * a.lddq + a.dq_col0 + h * 64
                         : a.dk + ((long)b * a.Nk + orow) * a.lddk + a.dk_col0 + h * 64;
 #pragma unroll
@@ -824,10 +840,14 @@ hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
   auto il = [](const bf16_t* hi_, const bf16_t* lo_) { return hi_ && lo_ == hi_ + 32; };
   if (!il(a.q_hi, a.q_lo) || !il(a.k_hi, a.k_lo) || !il(a.v_hi, a.v_lo) || !il(a.do_hi, a.do_lo)) return hipErrorInvalidValue;
   if (((a.ldq | a.ldk | a.ldv | a.lddo) & 31) || ((a.q_col0 | a.k_col0 | a.v_col0) & 31)) return hipErrorInvalidValue;
-  const bool want_q = a.dq != nullptr, want_kv = a.dk != nullptr || a.dv != nullptr;
+  const bool want_q = a.dq != nullptr || a.gp_q, want_kv = a.dk != nullptr || a.dv != nullptr || a.gp_kv;
   if (!want_q && !want_kv) return hipErrorInvalidValue;
-  if (want_kv && (!a.dk || !a.dv || ((a.lddk | a.lddv | a.dk_col0 | a.dv_col0) & 3))) return hipErrorInvalidValue;
-  if (want_q && ((a.lddq & 3) || (a.dq_col0 & 3))) return hipErrorInvalidValue;
+  if (a.gp_q || a.gp_kv) {        // planes: interleaved lines, 32-column aligned head blocks, one of the two line formats
+    if (!a.gp_hi || a.gp_lo != a.gp_hi + 32 || (a.gp_ld & 31) || (a.gp_fmt != FMT_BF16 && a.gp_fmt != FMT_H8)) return hipErrorInvalidValue;
+    if ((a.gp_q && (a.dq_col0 & 31)) || (a.gp_kv && ((a.dk_col0 | a.dv_col0) & 31))) return hipErrorInvalidValue;
+  }
+  if (want_kv && !a.gp_kv && (!a.dk || !a.dv || ((a.lddk | a.lddv | a.dk_col0 | a.dv_col0) & 3))) return hipErrorInvalidValue;
+  if (want_q && !a.gp_q && ((a.lddq & 3) || (a.dq_col0 & 3))) return hipErrorInvalidValue;
   if (want_q) { hipError_t e = launch_attn_bwd2_role<0>(a, s); if (e != hipSuccess) return e; }
   if (want_kv) { hipError_t e = launch_attn_bwd2_role<1>(a, s); if (e != hipSuccess) return e; }
   return hipSuccess;

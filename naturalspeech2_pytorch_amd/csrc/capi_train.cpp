@@ -278,6 +278,9 @@ extern "C" int ns2_attention_bwd(const ns2_attn_bwd_args* p, void* stream) {
   a.dk = p->dk; a.lddk = p->lddk; a.dk_col0 = p->dk_col0;
   a.dv = p->dv; a.lddv = p->lddv; a.dv_col0 = p->dv_col0;
   a.B = p->B; a.H = p->H; a.Nq = p->Nq; a.Nk = p->Nk; a.scale = p->scale;
+  a.gp_hi = p->gp_hi; a.gp_lo = p->gp_lo; a.gp_ld = p->gp_ld; a.gp_q = p->gp_q; a.gp_kv = p->gp_kv;
+  ARGCHK(p->gp_precision == 0 || p->gp_precision == 3 || p->gp_precision == 4, "ns2_attention_bwd: gp_precision 3 (bf16 hi / lo planes) or 4 (FMT_H8 lines)");
+  a.gp_fmt = p->gp_precision == 4 ? FMT_H8 : FMT_BF16;
   HIPRET(launch_attention_bwd(a, (hipStream_t)stream));
   return NS2_OK;
 }

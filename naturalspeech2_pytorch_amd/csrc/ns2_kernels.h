@@ -296,6 +296,10 @@ struct AttnBwdArgs {
   float* dk; int lddk, dk_col0;
   float* dv; int lddv, dv_col0;
   int B, H, Nq, Nk; float scale;
+  // round 5: the gradients as OPERAND PLANES instead of fp32 (what consumes dq | dk | dv of a self attention is the q | k | v projection's
+  // dgrad and wgrad GEMMs, nothing else): gp planes [rows, gp_ld] in format gp_fmt (FMT_BF16 hi / lo lines or FMT_H8), dq at columns
+  // dq_col0 + 64 h of row b Nq + q, dk / dv at dk_col0 / dv_col0 of row b Nk + k; gp_q / gp_kv say which halves go there
+  bf16_t* gp_hi; bf16_t* gp_lo; int gp_ld, gp_fmt, gp_q, gp_kv;
 };
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
 

@@ -386,8 +386,14 @@ class HipBackend:
               "ns2_attention_delta")
         return delta
 
-    def attention_bwd(self, q, q_col0, k, k_col0, v, v_col0, do_row, lse, delta, B, H, Nq, Nk, dq=None, dkv=None):
-        """dq: (fp32 tensor [B*Nq, ld], col0) or None; dkv: (tensor [B*Nk, ld], k col0, v col0) or None"""
+    def new_planes(self, M, C):
+        """uninitialised operand planes [M, round_up(C, 32)] in the backend's GEMM format (a kernel is about to fill every column)"""
+        return ops._out_planes(M, round_up(C, 32), torch.device("cuda", torch.cuda.current_device()), self.prec)
+
+    def attention_bwd(self, q, q_col0, k, k_col0, v, v_col0, do_row, lse, delta, B, H, Nq, Nk, dq=None, dkv=None, planes=None):
+        """dq: (fp32 tensor [B*Nq, ld], col0) or None; dkv: (tensor [B*Nk, ld], k col0, v col0) or None;
+        planes: (operand planes [B*N, ld], dq col0, dk col0, dv col0) -- self attention: the three gradients leave the kernels as the
+        operand of the q | k | v projection's dgrad / wgrad GEMMs instead of fp32 + a conversion pass"""
         a = _lib.AttnBwdArgs()
         a.q_hi, a.q_lo, a.ldq, a.q_col0 = q.hi, q.lo, q.ld, q_col0
         a.k_hi, a.k_lo, a.ldk, a.k_col0 = k.hi, k.lo, k.ld, k_col0
@@ -399,6 +405,10 @@ class HipBackend:
         if dkv is not None:
             a.dk, a.lddk, a.dk_col0 = dkv[0].data_ptr(), dkv[0].stride(0), dkv[1]
             a.dv, a.lddv, a.dv_col0 = dkv[0].data_ptr(), dkv[0].stride(0), dkv[2]
+        if planes is not None:
+            gp, a.dq_col0, a.dk_col0, a.dv_col0 = planes
+            assert gp.precision == self.prec
+            a.gp_hi, a.gp_lo, a.gp_ld, a.gp_precision, a.gp_q, a.gp_kv = gp.hi, gp.lo, gp.ld, self.prec, 1, 1
         a.B, a.H, a.Nq, a.Nk, a.scale = B, H, Nq, Nk, 0.125
         check(self.lib.ns2_attention_bwd(ctypes.byref(a), _s()), "ns2_attention_bwd")
 
@@ -661,10 +671,16 @@ class AttnFn(torch.autograd.Function):
         # (the backward kernels form K^T, Q^T and dO^T inside the CU: LDS transpose reads of the row-major tiles)
         do_row, _, _ = bk.grad_prep(do, a, want_row=True, attn=True)
         if not cross:
-            dqkv = torch.empty(M, 3 * a, dtype=torch.float32, device=h.device)
-            bk.attention_bwd(q, qc, k, kc, v, vc, do_row, lse, delta, B, heads, seq_len, Nk, dq=(dqkv, 0), dkv=(dqkv, a, 2 * a))
             need_w = ng[3] or ng[4]
-            g_row, dwqkv, _ = _grads(bk, dqkv, 3 * a, xn, d, need_w=need_w)
+            if not need_w or bk.wgrad_rows_ok(3 * a, 1, d, 0, M):
+                # dq | dk | dv feed two GEMMs only (the projection's dgrad and wgrad): they leave the attention backward as operand planes
+                g_row = bk.new_planes(M, 3 * a)
+                bk.attention_bwd(q, qc, k, kc, v, vc, do_row, lse, delta, B, heads, seq_len, Nk, planes=(g_row, 0, a, 2 * a))
+                dwqkv = bk.wgrad_rows(g_row, xn, 3 * a, 1, d) if need_w else None
+            else:
+                dqkv = torch.empty(M, 3 * a, dtype=torch.float32, device=h.device)
+                bk.attention_bwd(q, qc, k, kc, v, vc, do_row, lse, delta, B, heads, seq_len, Nk, dq=(dqkv, 0), dkv=(dqkv, a, 2 * a))
+                g_row, dwqkv, _ = _grads(bk, dqkv, 3 * a, xn, d, need_w=need_w)
             dwq = dwkv = None
             if need_w:
                 dwq, dwkv = dwqkv[:a, :, 0], dwqkv[a:, :, 0]

@@ -245,8 +245,13 @@ class EmuBackend:
         a = H * 64
         return (do[:, :a] * o.t[:, :a]).reshape(B, Nq, H, 64).sum(-1).transpose(1, 2).contiguous()
 
-    def attention_bwd(self, q, q_col0, k, k_col0, v, v_col0, do_row, lse, delta, B, H, Nq, Nk, dq=None, dkv=None):
+    def new_planes(self, M, C):
+        return EP(torch.full((M, rup(C, 32)), float("nan")))
+
+    def attention_bwd(self, q, q_col0, k, k_col0, v, v_col0, do_row, lse, delta, B, H, Nq, Nk, dq=None, dkv=None, planes=None):
         a = H * 64
+        if planes is not None:                              # the three gradients as operand planes (same values: the emulation keeps fp32)
+            dq, dkv = (planes[0].t, planes[1]), (planes[0].t, planes[2], planes[3])
         hd = lambda t, c0, n: t[:, c0:c0 + a].reshape(B, n, H, 64).transpose(1, 2)      # noqa: E731
         qq, kk, vv = hd(q.t, q_col0, Nq), hd(k.t, k_col0, Nk), hd(v.t, v_col0, Nk)
         dO = hd(do_row.t, 0, Nq)

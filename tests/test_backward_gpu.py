@@ -212,6 +212,11 @@ def test_attention_forward_lse_and_backward(B, H, Nq, Nk, cross):
     dkv2 = torch.full((B * Nk, 2 * a), float("nan"), device=DEV)
     HB.attention_bwd(qp, qc, kp, kc, vp, vc, do_row, lse, delta, B, H, Nq, Nk, dkv=(dkv2, 0, a))
     assert torch.equal(dkv2, dkv)                       # two launches, the same bits (no atomics, fixed order)
+    if not cross:                                       # round 5: dq | dk | dv as operand planes straight from the kernels = the conversion of the fp32 ones
+        gp = HB.new_planes(B * Nq, 3 * a)
+        HB.attention_bwd(qp, qc, kp, kc, vp, vc, do_row, lse, delta, B, H, Nq, Nk, planes=(gp, 0, a, 2 * a))
+        want = HB.split(torch.cat((dq[:, 32:], dkv), -1))
+        assert torch.equal(join(gp), join(want))
 
 
 def test_weight_update_in_place():
