@@ -47,8 +47,11 @@ PEAK_16BIT_TFLOPS = 2500.0         # dense bf16 / f16 MFMA peak, MI355X_MICROARC
 PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (RVQ)
 UTT_GFLOP = {(512, 12, False): 316.37, (512, 12, True): 331.98, (128, 6, False): 26.74}   # per 1024-frame utterance, SURVEY §8d
 MFMA_UNITS = {"exact": 3, "mixed": 2, "half": 1, "fast": 1, "hybrid": 1, "hybrid_ff": 1}   # MFMA-pipe time per algorithmic FLOP of the dominant kernel, in 16-bit-product units
-KERNEL_NAME = {"exact": "gemm2_kernel<3, 1, false, 0>", "mixed": "gemm2_kernel<2, 1, true, 0>", "half": "gemm2_kernel<1, 1, true, 0>",
-               "fast": "gemm2_kernel<1, 1, false, 0>", "hybrid": "gemm2_kernel<1, 1, true, 0>", "hybrid_ff": "gemm2_kernel<1, 1, true, 0>"}     # <NSPLIT, EPI_SPLIT = 1, F16, P1>
+KERNEL_NAME = {"exact": "gemm2_kernel<3, 1, false, 0>", "mixed": "gemm2_kernel<2, 1, true, 0>",
+               "half": "ffc3::ffconv3_kernel<PF_F16> + gemm2_kernel<1, 1, true, 0>",
+               "fast": "gemm2_kernel<1, 1, false, 0>", "hybrid": "ffc3::ffconv3_kernel<PF_H8>", "hybrid_ff": "ffc3::ffconv3_kernel<PF_F16>"}
+# gemm2_kernel<NSPLIT, EPI_SPLIT = 1, F16, P1> (csrc/gemm2.hip); ffconv3_kernel = the dedicated FF causal conv kernel of the plans whose conv
+# is one IEEE-half product (csrc/ffconv_kernel.h, round 6; NS2_GEMM=4 switches it off: the conv then runs on gemm2_kernel<1, 1, true, 0>)
 DTYPE = {"exact": "bf16x3 split operands on the bf16 MFMA, fp32 accumulate",
          "mixed": "fp16 operands on the f16 MFMA + both first-order correction terms as e5m2 on the block-scaled fp8 MFMA, fp32 accumulate",
          "hybrid": "fp16 operands on the f16 MFMA + both first-order correction terms as e5m2 on the block-scaled fp8 MFMA "
@@ -371,7 +374,7 @@ def main():
                 busy = tj.get("mfma_pipe_busy_frac")
         what = f"FF causal conv k3 x{depth}" + ("" if precision in ("hybrid", "hybrid_ff") else ", wavenet init conv, skip-sum GEMM") + \
                (f", cross-attention q projection x{depth}" if conditioned and precision not in ("hybrid", "hybrid_ff") else "")
-        return dict(bound="mfma", kernel=f"ns2::{KERNEL_NAME[precision]} = EPI_SPLIT ({what})",
+        return dict(bound="mfma", kernel=f"ns2::{KERNEL_NAME[precision]} ({what})",
                     achieved=round(ach, 2), peak=PEAK_16BIT_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_16BIT_TFLOPS, 4),
                     traffic=traffic, traffic_source=tsrc, mfma_pipe_busy_frac_profiled=busy, avg_launch_ms=round(avg_ms, 4), launches=kern_n_v,
                     algorithmic_gflop_per_launch=round(fl / nl / 1e9, 2),

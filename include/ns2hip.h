@@ -51,7 +51,8 @@ extern "C" {
 const char* ns2_last_error(void);
 int ns2_version(void);
 /* test hook: force the GEMM kernel variant (0 = dispatch by shape, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA,
- * 3 = dispatch by shape but never split K) */
+ * 3 = dispatch by shape but never split K, 4 = dispatch by shape but never the dedicated FF-conv kernel, 5 = dispatch by shape but
+ * the dedicated FF-conv kernel whenever a call is eligible, whatever its size) */
 int ns2_debug_force_gemm(int kernel);
 /* Split-K of small products.  ns2_model_forward* lend a region of their workspace to every GEMM of the pass: a product with too
  * few output tiles to fill the chip runs as K slices into fixed slots plus a second launch that adds the slots in order and
@@ -97,6 +98,15 @@ int ns2_linear_f32(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_
 int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,
                      int dilation, int seq_len, const float* bias, uint16_t* out_hi, uint16_t* out_lo, int ldo,
                      int pad_left, int act, int precision, void* stream);
+/* The feed-forward causal conv (CausalConv1d(f, f, 3), NS2:1016 / 583-595) as one IEEE-half product has a kernel of its own
+ * (csrc/ffconv_kernel.h).  It reads the weight as pre-tiled LDS images: ns2_weight_tile_conv3 builds them for a weight packed with
+ * taps = 3 at precision 2 (one-time set-up, allocates once; ns2_weight_update keeps them current; the packs of ns2_weights_repack
+ * must not have them).  A later ns2_linear_split / ns2_linear_split_as call with that weight takes the kernel when: conv_taps = 3,
+ * dilation = 1, pad_left = -1, act = 0, M % 256 == 0, seq_len % 256 == 0, lda == ns2_conv3_input_ld(cols) (dense half rows padded to
+ * a multiple of 128 columns; the padding is never multiplied), output dense half or FMT_H8 lines.  Results are bit-identical to the
+ * general kernel's (same products, same summation order).  ns2_model_finalize does all of this for precisions 2 / 5 / 6. */
+int ns2_weight_tile_conv3(ns2_weight* w, void* stream);
+int ns2_conv3_input_ld(int cols);
 /* same, with the output planes in the format of ANOTHER precision (out_precision 3: bf16 hi / lo lines from a precision-4 product --
  * the q | k | v projection of the mixed training arithmetic, whose attention stays bf16 x3) */
 int ns2_linear_split_as(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,

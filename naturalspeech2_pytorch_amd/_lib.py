@@ -109,6 +109,8 @@ SIGNATURES = {
     "ns2_model_destroy": (None, [P]),
     # ---- training: the backward pass
     "ns2_weight_update": (I, [P, P, P, P]),
+    "ns2_weight_tile_conv3": (I, [P, P]),
+    "ns2_conv3_input_ld": (I, [I]),
     "ns2_saturation_peek_train_async": (I, [P, P]),
     "ns2_grad_prep_slices": (L, [I, L]),
     "ns2_grad_prep": (I, [P, L, I, I, I, I, P, P, I, P, P, L, I, I, P, I, P]),

@@ -43,9 +43,9 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 112; }   // 112: ns2_seanet_resblock_narrow; 111: training entry points take a precision (3 = bf16 x3, 4 = mixed on FMT_H8 lines), ns2_linear_split_as; 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 113; }   // 113: ns2_weight_tile_conv3 + ns2_conv3_input_ld (the dedicated FF causal conv kernel, ffconv_kernel.h), ns2_debug_force_gemm(4); 112: ns2_seanet_resblock_narrow; 111: training entry points take a precision (3 = bf16 x3, 4 = mixed on FMT_H8 lines), ns2_linear_split_as; 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
-  ARGCHK(kernel >= 0 && kernel <= 3, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel, 3 = auto without split-K");
+  ARGCHK(kernel >= 0 && kernel <= 5, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel, 3 = auto without split-K, 4 = auto without the dedicated FF-conv kernel, 5 = auto, the FF-conv kernel whenever eligible");
   force_gemm_kernel(kernel);
   return NS2_OK;
 }
@@ -76,6 +76,15 @@ extern "C" int ns2_weight_pack(const float* w, int rows, int cols, int taps, int
   *out = h;
   return NS2_OK;
 }
+// Give a k = 3 conv weight packed for precision 2 (dense IEEE half) the tiled images of the dedicated FF causal conv kernel
+// (ffconv_kernel.h).  ns2_linear_split / ns2_linear_split_as then take that kernel whenever the call is eligible: dilation 1, causal
+// padding, no activation, M and seq_len multiples of 256, activations with rows of ns2_conv3_input_ld(cols) elements, FMT_H8 or dense
+// half output.  One-time set-up like ns2_weight_pack (allocates on the first call); ns2_weight_update refreshes the images with the pack.
+extern "C" int ns2_weight_tile_conv3(ns2_weight* w, void* stream) {
+  ARGCHK(w && w->taps == 3 && !w->geglu && !w->has_extra && w->w.fmt == FMT_F16 && !w->w.lo, "ns2_weight_tile_conv3: a k = 3 conv weight packed for precision 2");
+  return build_conv3_tiles(&w->owned, &w->w, (hipStream_t)stream);
+}
+extern "C" int ns2_conv3_input_ld(int cols) { return cols > 0 ? ffconv3_lda((cols + 31) / 32 * 32) : 0; }
 extern "C" void ns2_weight_free(ns2_weight* w) {
   if (!w) return;
   for (void* p : w->owned) (void)hipFree(p);

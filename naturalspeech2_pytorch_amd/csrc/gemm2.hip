@@ -17,10 +17,12 @@
 //     chunk c ^ ((r>>1)&7);
 //   * causal-conv zero fill (rows before the utterance start) and M-edge rows are lanes whose source pointer is
 //     redirected to a 16-B zero page -- the DMA needs no predication.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
 #include "gemm_epi_fast.h"
+#include "ffconv_kernel.h"
 
 namespace ns2 {
 
@@ -1120,6 +1122,7 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
       !planes_ok(g.vt_hi, g.vt_lo))
     return hipErrorInvalidValue;
   const int f = forced_kernel();
+  if (f == 5 && ffconv3_eligible(g, precision)) return launch_ffconv3(g, s);      // test hook: the dedicated FF-conv kernel whatever the size
   // Small products (a batch of 1 ... 4 utterances) split K when the caller lent scratch (splitk_plan above).
   // (f == 3: automatic kernel choice, never split -- A/B hook.)
   if (f == 0 && g.sk_ws && g.epi != EPI_WAVENET && g.nz <= 1 && !g.dil_z && g.ksplit == 0) {
@@ -1130,8 +1133,10 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
   // a product that would put at most 64 blocks of 256 x 256 on the 256 CUs runs on the 128 x 128 kernel (4 x the blocks, a
   // quarter of the serial work each): 1 x 1024-frame steps measured 4 % faster with it, 4 x 1024 slower (exp_small_m_kernel.py)
   const long blocks256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.nz > 0 ? g.nz : 1);
-  const bool big = (f == 2) || (f != 1 && g.N > 128 && !((f == 0 || f == 3) && blocks256 <= 64));
+  const bool big = (f == 2) || (f != 1 && g.N > 128 && !((f == 0 || f >= 3) && blocks256 <= 64));
   if (!big) return launch_gemm1(g, precision, s);
+  // the FF causal conv of the one-half-product plans on full row tiles: its own kernel (ffconv_kernel.h)
+  if ((f == 0 || f == 3) && ffconv3_eligible(g, precision)) return launch_ffconv3(g, s);
   switch (precision) {
     case 3: return launch2_epi<3, false>(g, s);
     case 4: return launch2_epi<2, true>(g, s);
@@ -1139,6 +1144,12 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
     default: return launch2_epi<1, false>(g, s);
   }
 }
+
+size_t ffconv3_tiled_bytes_of(int N, int Cp) { return ffconv3_tiled_bytes(N, Cp); }
+hipError_t ffconv3_build_tiles(const bf16_t* w_hi, int ldw, int Cp, int rows_p, int N, bf16_t* out, hipStream_t s) {
+  return launch_ffconv3_tile(w_hi, ldw, Cp, rows_p, N, out, s);
+}
+int ffconv3_lda(int Cp) { return ffconv3_tiles_per_tap(Cp) * 64; }
 
 NS2_DEFINE_SATURATION_READER(gemm2)
 

@@ -60,6 +60,8 @@ struct ns2_model {
   bool finalized = false;
   // derived
   int dim, a, f, fp, dp, dt, Tc, L, S, Lm, dpp, nnorm, Jtot;
+  int fpc;                       // row length of the FF conv's INPUT planes: fp, or (plans whose conv is one half product on dense planes) the
+                                 // 128-multiple the dedicated conv kernel wants (ffconv_kernel.h: 128-byte aligned rows, an even number of K tiles)
   // packed
   const float* freqs; float* wt_time; const float* b_time;
   float* wt_cond; float* b_cond;
@@ -183,6 +185,16 @@ static int pack_linear(const PackCtx& pc, PackedW* w, const float* src, int R, i
   return pack_into(w, src, C, T, Cp, identity_map(R, w->rows_p), 0, 0, s);
 }
 
+// k = 3 conv weights packed as dense IEEE half: (re)build the tiled LDS images the dedicated FF-conv kernel reads (ffconv_kernel.h) from the
+// row-major pack -- a permutation of the packed values, so both kernels multiply the same operands
+int build_conv3_tiles(std::vector<void*>* owned, PackedW* w, hipStream_t s) {
+  if (w->fmt != FMT_F16 || w->lo || w->nkt != 3 * w->kt_per_tap) { set_error("build_conv3_tiles: not a dense IEEE-half k = 3 conv weight"); return NS2_ERR_ARG; }
+  const int Cp = w->kt_per_tap * 32;
+  if (!w->t3) NSCHK(dev_alloc(owned, (void**)&w->t3, ffconv3_tiled_bytes_of(w->N, Cp)));
+  HIPCHK(ffconv3_build_tiles(w->hi, w->ldk, Cp, w->rows_p, w->N, w->t3, s));
+  return NS2_OK;
+}
+
 static int pack_geglu(const PackCtx& pc, PackedW* w, const float* src, int f, int C, hipStream_t s) {
   const int Cp = rup(C, 32), fpad = rup(f, 32);
   NSCHK(alloc_packed(pc, w, 2 * fpad, Cp, Cp / 32));
@@ -241,7 +253,7 @@ static GemmArgs base_args(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_
   memset(&g, 0, sizeof(g));
   g.sk_ws = tl_sk_ws; g.sk_ws_floats = tl_sk_ws ? SPLITK_SCRATCH_FLOATS : 0;
   g.a_hi = a_hi; g.a_lo = a_lo; g.lda = lda;
-  g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk;
+  g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk; g.w_t3 = w.t3;
   g.M = M; g.N = w.N; g.nkt = w.nkt; g.kt_per_tap = w.nkt; g.conv_taps = 0; g.dil = 1; g.mid_kt = -1;
   g.nz = 1; g.pad_left = -1; g.act = 0; g.out_fmt = -1; g.vt_fmt = -1;
   return g;
@@ -285,10 +297,10 @@ int gemm_split(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda
   return NS2_OK;
 }
 int gemm_geglu(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, const float* pbias, bf16_t* o_hi,
-               bf16_t* o_lo, int ldo, int prec, hipStream_t s, int out_fmt) {
+               bf16_t* o_lo, int ldo, int prec, hipStream_t s, int out_fmt, int out_ncols) {
   GemmArgs g = base_args(w, a_hi, a_lo, lda, M);
   g.out_fmt = out_fmt;
-  g.epi = EPI_GEGLU; g.bias = pbias; g.out_hi = o_hi; g.out_lo = o_lo; g.ldo_s = ldo; g.out_ncols = ldo;
+  g.epi = EPI_GEGLU; g.bias = pbias; g.out_hi = o_hi; g.out_lo = o_lo; g.ldo_s = ldo; g.out_ncols = out_ncols > 0 ? out_ncols : ldo;
   HIPCHK(launch_gemm(g, prec, s));
   return NS2_OK;
 }
@@ -341,6 +353,7 @@ extern "C" int ns2_model_create(const ns2_model_config* cfg, ns2_model** out) {
   m->dim = cfg->dim; m->a = cfg->heads * cfg->dim_head;
   m->f = (int)((double)cfg->dim * cfg->ff_mult * 2 / 3);           // int(dim * mult * 2 / 3)  NS2:1010
   m->fp = rup(m->f, 32); m->dp = cfg->dim;
+  m->fpc = (cfg->precision == 2 || hybrid_plan(cfg->precision)) ? ffconv3_lda(m->fp) : m->fp;
   m->dt = cfg->dim * cfg->dim_cond_mult;
   m->Tc = m->dt * (cfg->condition_on_prompt ? 2 : 1);              // NS2:884
   m->L = cfg->wavenet_layers; m->S = cfg->wavenet_stacks;
@@ -478,6 +491,7 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
       NSCHK(pack_geglu(pc_ff, &ly.ffin, w1->p, f, dim, s));
       NSCHK(pack_geglu_bias(&m->owned, &ly.b_ffin, b1->p, f, ly.ffin.rows_p));
       NSCHK(pack_linear(pc_conv, &ly.conv, cw->p, f, f, 3, s)); ly.b_conv = cb->p;
+      if (pc_conv.fmt == FMT_F16) NSCHK(build_conv3_tiles(&m->owned, &ly.conv, s));
       NSCHK(pack_linear(pc_ff, &ly.ffout, w2->p, dim, f, 1, s)); ly.b_ffout = b2->p; }
   }
   { GETP(g, "transformer.to_pred.0.gamma"); GETP(w, "transformer.to_pred.1.weight");
@@ -631,7 +645,7 @@ static int64_t carve_work(const ns2_model* m, Work* w, void* base, int64_t cap, 
   w->Nkp = rup(N, kpad);
   w->vt = take_planes(c, (int64_t)B * a * w->Nkp, ail, afmt);
   w->o = take_planes(c, Mq * a, il, f16);
-  w->ffh = take_planes(c, Mq * fp, il, f16);
+  w->ffh = take_planes(c, Mq * std::max(fp, m->fpc), il, f16);      // (the conv's dense-half input view has rows of fpc elements)
   w->ffh_conv = w->ffh;
   if (hybrid_plan(m->cfg.precision)) { w->ffh_conv.lo = nullptr; w->ffh_conv.fmt = FMT_F16; }
   w->ffc = take_planes(c, M * fp, il, f16);
@@ -885,7 +899,7 @@ static int forward_impl(ns2_model* m, const float* x, const float* times, const 
   CondState cs;
   if (cond) carve_cond(m, &cs, const_cast<void*>(cond_state), 0, B, N, n_cond);
   const int dim = m->dim, a = m->a, dp = m->dp, fp = m->fp, L = m->L, S = m->S, H = m->cfg.heads, prec = op_precision(m->cfg.precision);
-  const int M = B * N, Jtot = m->Jtot, Lm = m->Lm;
+  const int M = B * N, Jtot = m->Jtot, Lm = m->Lm, fpc = m->fpc;
   const int conv_prec = hybrid_plan(m->cfg.precision) ? 2 : prec;
   const int ff_prec = ff_half_plan(m->cfg.precision) ? 2 : prec;
   Planes xn_ff = w.xn, ffc_ff = w.ffc;                 // precision 6: dense IEEE-half views of the same memory
@@ -962,8 +976,8 @@ static int forward_impl(ns2_model* m, const float* x, const float* times, const 
       NSCHK(update_then_norm(ly.cout, w.o, a, nullptr, true, prec, nullptr, layer_cond(l, m->nnorm - 1), xn_ff));
     }
     // feedforward: Linear -> GEGLU -> causal conv k3 -> Linear (NS2:1009-1025); precision 6: the whole branch on dense IEEE-half planes
-    PROF(PC_GEMM_GEGLU, gemm_geglu(ly.ffin, xn_ff.hi, xn_ff.lo, dp, M, ly.b_ffin, w.ffh_conv.hi, w.ffh_conv.lo, fp, ff_prec, s, w.ffh_conv.fmt));
-    PROF(PC_GEMM_FFCONV, gemm_split(ly.conv, w.ffh_conv.hi, w.ffh_conv.lo, fp, M, 3, 1, N, ly.b_conv, ffc_ff.hi, ffc_ff.lo, fp,
+    PROF(PC_GEMM_GEGLU, gemm_geglu(ly.ffin, xn_ff.hi, xn_ff.lo, dp, M, ly.b_ffin, w.ffh_conv.hi, w.ffh_conv.lo, fpc, ff_prec, s, w.ffh_conv.fmt, fp));
+    PROF(PC_GEMM_FFCONV, gemm_split(ly.conv, w.ffh_conv.hi, w.ffh_conv.lo, fpc, M, 3, 1, N, ly.b_conv, ffc_ff.hi, ffc_ff.lo, fp,
                                     conv_prec, s, -1, 0, ffc_ff.fmt));
     // FF-out + residual, then the next layer's self-attention norm -- or to_pred's RMSNorm (learned gamma, NS2:781-784) after the last
     NSCHK(update_then_norm(ly.ffout, ffc_ff, fp, ly.b_ffout, true, ff_prec, last ? m->g_pred : nullptr, last ? nullptr : layer_cond(l + 1, 0), w.xn));

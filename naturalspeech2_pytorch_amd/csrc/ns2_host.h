@@ -15,6 +15,7 @@ struct PackedW {                 // bf16 split-plane weight, rows padded to 128,
   bf16_t* hi = nullptr; bf16_t* lo = nullptr;
   int rows_p = 0, ldk = 0, N = 0, nkt = 0, kt_per_tap = 0;
   int fmt = 0;                   // PlaneFmt: bf16 planes (precisions 1 / 3), dense IEEE half (2), FMT_H8 lines (4)
+  bf16_t* t3 = nullptr;          // k = 3 conv weights in dense IEEE half: the tiled LDS images of the dedicated FF-conv kernel (ffconv_kernel.h), or null
 };
 
 int gemm_f32(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int conv_taps, int dil, int seq_len,
@@ -27,7 +28,7 @@ int gemm_split(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda
                const float* bias, bf16_t* o_hi, bf16_t* o_lo, int ldo, int prec, hipStream_t s, int pad_left = -1, int act = 0,
                int out_fmt = -1);
 int gemm_geglu(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, const float* pbias, bf16_t* o_hi,
-               bf16_t* o_lo, int ldo, int prec, hipStream_t s, int out_fmt = -1);
+               bf16_t* o_lo, int ldo, int prec, hipStream_t s, int out_fmt = -1, int out_ncols = 0);   // out_ncols: columns written (zeros beyond f); 0 = ldo
 int gemm_qkv(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, int M, int seq_len, int split_col,
              bf16_t* o_hi, bf16_t* o_lo, int ldo, bf16_t* vt_hi, bf16_t* vt_lo, int vt_ld, int prec, hipStream_t s, int att_fmt = -1);
 int gemm_wavenet(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int lda, long a_zs, int M, int seq_len, int dil,
@@ -37,6 +38,7 @@ int gemm_wavenet(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int l
 int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, int precision, PackedW* out,
                        std::vector<void*>* owned, hipStream_t s);
 std::vector<int> geglu_row_map(int f, int rows_p);
+int build_conv3_tiles(std::vector<void*>* owned, PackedW* w, hipStream_t s);   // model_exec.cpp: (re)build w->t3 from the row-major pack
 
 }  // namespace ns2
 

@@ -48,6 +48,7 @@ struct GemmArgs {
   const bf16_t* a_hi; const bf16_t* a_lo; int lda;
   // W operand: packed weights, bf16 split planes [ceil(N/128)*128, ldw], K contiguous
   const bf16_t* w_hi; const bf16_t* w_lo; int ldw;
+  const bf16_t* w_t3;       // optional: the same conv weight (k = 3, dense IEEE half) as tiled LDS images (ffconv_kernel.h); null = none
   int M, N;          // N = valid output columns
   int nkt;           // number of 32-wide K tiles (total, all taps/phases)
   int kt_per_tap;    // K tiles per tap (plain linear: == nkt)
@@ -97,7 +98,11 @@ hipError_t launch_gemm(const GemmArgs& g, int precision, hipStream_t s);
 bool gemm_fuses_norm(const GemmArgs& g, int precision);                 // gemm2.hip: the shape takes the 128 x 128 kernel's whole-row epilogue (no split-K)
 hipError_t launch_gemm_tr(const GemmArgs& g, int precision, hipStream_t s);   // gemm2.hip: both operands read transposed (precision 3 / 4)
 void splitk_plan(int M, int N, int nkt, int kt_per_tap, bool epi_f32, long scratch_floats, int* S, int* c);   // gemm2.hip; S = 1: no split
-void force_gemm_kernel(int k);                                          // 0 auto, 1 = 128x128, 2 = 256x256, 3 = auto without split-K (test hook); a forced kernel never splits K
+void force_gemm_kernel(int k);                                          // 0 auto, 1 = 128x128, 2 = 256x256, 3 = auto without split-K, 4 = auto without the dedicated FF-conv kernel, 5 = auto with it whatever the size (test hook); a forced kernel never splits K
+// the dedicated FF causal conv kernel (ffconv_kernel.h, compiled in gemm2.hip): tiled weight images
+size_t ffconv3_tiled_bytes_of(int N, int Cp);
+hipError_t ffconv3_build_tiles(const bf16_t* w_hi, int ldw, int Cp, int rows_p, int N, bf16_t* out, hipStream_t s);
+int ffconv3_lda(int Cp);                                                // activations' row length (elements) the kernel wants for Cp packed columns per tap
 constexpr long SPLITK_SCRATCH_FLOATS = 512L * 128 * 128;                // what any split needs at most: slices x output tiles <= 512 tiles of 128 x 128 (32 MiB)
 
 // flash attention forward, head dim 64, non-causal (ATT:77-155 hot path)

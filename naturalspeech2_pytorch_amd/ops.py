@@ -145,6 +145,11 @@ class PackedWeight:
                                           ctypes.byref(h), _stream()), "ns2_weight_pack")
         self.handle = h
 
+    def tile_conv3(self) -> "PackedWeight":
+        """give a k = 3 conv weight packed at precision 2 the tiled images of the dedicated FF causal conv kernel (include/ns2hip.h)"""
+        check(_lib.load().ns2_weight_tile_conv3(self.handle, _stream()), "ns2_weight_tile_conv3")
+        return self
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):
@@ -163,13 +168,24 @@ def linear_f32(w: PackedWeight, a: Planes, M: Optional[int] = None, bias=None, r
     return out
 
 
+def conv3_input_ld(cols: int) -> int:
+    """row length (elements) of the dense-half activations the dedicated FF causal conv kernel reads for `cols` input channels"""
+    return _lib.load().ns2_conv3_input_ld(cols)
+
+
 def linear_split(w: PackedWeight, a: Planes, bias=None, conv_taps=0, dilation=1, seq_len=0, precision=3, ldo=None, pad_left=-1,
-                 act=0) -> Planes:
+                 act=0, out_precision=None) -> Planes:
+    """out_precision: write the output planes in the operand format of another precision (ns2_linear_split_as), e.g. FMT_H8 lines (4)
+    from a precision-2 product -- what the hybrid plan's FF causal conv does"""
     M = a.rows
     ldo = ldo or round_up(w.rows, 32)
-    out = _out_planes(M, ldo, a.device, precision)
-    check(_lib.load().ns2_linear_split(w.handle, a.hi, a.lo, a.ld, M, conv_taps, dilation, seq_len, _p(bias),
-                                       out.hi, out.lo, ldo, pad_left, act, precision, _stream()), "ns2_linear_split")
+    out = _out_planes(M, ldo, a.device, out_precision or precision)
+    if out_precision is None:
+        check(_lib.load().ns2_linear_split(w.handle, a.hi, a.lo, a.ld, M, conv_taps, dilation, seq_len, _p(bias),
+                                           out.hi, out.lo, ldo, pad_left, act, precision, _stream()), "ns2_linear_split")
+    else:
+        check(_lib.load().ns2_linear_split_as(w.handle, a.hi, a.lo, a.ld, M, conv_taps, dilation, seq_len, _p(bias),
+                                              out.hi, out.lo, ldo, pad_left, act, precision, out_precision, _stream()), "ns2_linear_split_as")
     return out
 
 

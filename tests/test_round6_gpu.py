@@ -1,0 +1,114 @@
+"""Round-6 GPU tests.
+
+  * the dedicated FF causal conv kernel (csrc/ffconv_kernel.h; FeedForward's CausalConv1d(f, f, 3), NS2:1016 / 583-595) against
+    (a) the general kernels on the same operands -- bit for bit: same products, same summation order -- and (b) an fp64 restatement of
+    the conv on the half-rounded operands, over shapes that reach every code path: full / half-valid / partly valid column tiles,
+    first tiles of utterances, K tails of 0 / 32 / 64 padded columns, one and many row tiles, both output formats;
+  * the executor on it: a hybrid / half / hybrid_ff model step equals the step with the kernel switched off, bit for bit.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+from naturalspeech2_pytorch_amd import Model, _lib, ops  # noqa: E402
+from tests.golden.gen import make_input, make_weights  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def _force(k):
+    _lib.check(_lib.load().ns2_debug_force_gemm(k), "ns2_debug_force_gemm")
+
+
+def _conv_ref64(xh, wh, bias, B, N):
+    """fp64 causal conv (NS2:583-595: left padding dil * (k - 1) = 2) on operands already rounded to half: xh [B*N, C], wh [R, C, 3]"""
+    x = xh.double().reshape(B, N, -1).transpose(1, 2)
+    y = torch.nn.functional.conv1d(torch.nn.functional.pad(x, (2, 0)), wh.double(), bias.double())
+    return y.transpose(1, 2).reshape(B * N, -1)
+
+
+CASES = [
+    # B, N, C_in, C_out          what the shape reaches
+    (8, 1024, 1365, 1365),     # the headline widths: 5 full column tiles + a half-valid one, K tail of 32 padded columns
+    (4, 256, 341, 341),        # dim 128: one full + one half-valid column tile, every row tile starts an utterance
+    (3, 512, 170, 170),        # K tail: the last K tile is padding only (Cp = 192 in rows of 256)
+    (2, 768, 682, 300),        # Cp = 704 in rows of 768; 300 output columns: a full tile + 44 columns
+    (1, 256, 96, 96),          # one block, one K-tile pair, a half-valid only column tile
+    (5, 256, 200, 200),        # a single partly valid column tile (200 > 128: every wave active, the last quarter beyond N)
+    (2, 512, 128, 640),        # lda == Cp (no padding), 2.5 column tiles
+]
+
+
+@pytest.mark.parametrize("B,N,C,R", CASES)
+@pytest.mark.parametrize("out_precision", [4, 2])
+def test_ffconv3_equals_the_general_kernel_and_the_fp64_conv(B, N, C, R, out_precision):
+    g = torch.Generator().manual_seed(1000 + C + R)
+    x = torch.randn(B * N, C, generator=g)
+    w = torch.randn(R, C, 3, generator=g) * (1.0 / (3 * C) ** 0.5)
+    bias = torch.randn(R, generator=g)
+    ld = ops.conv3_input_ld(C)
+    assert ld % 128 == 0 and 0 <= ld - ops.round_up(C, 32) < 128
+    a = ops.split(x.to(DEV), ldo=ld, precision=2)
+    # poison the padding columns of the activations: the kernel fetches them but must never multiply them
+    a.buf.view(B * N, ld)[:, ops.round_up(C, 32):] = float("nan")
+    pw = ops.PackedWeight(w.to(DEV), precision=2).tile_conv3()
+    bd = bias.to(DEV)
+
+    def run():
+        return ops.linear_split(pw, a, bias=bd, conv_taps=3, dilation=1, seq_len=N, precision=2, out_precision=out_precision)
+
+    try:
+        _force(5)                    # the dedicated kernel whatever the size
+        new = run()
+        new2 = run()
+        _force(2)                    # gemm2_kernel (256 x 256 tiles), the kernel it replaces; the 128 x 128 kernel sums in another order
+        old = run()
+    finally:
+        _force(0)
+    assert torch.equal(new.buf, new2.buf), "two launches of the dedicated kernel differ"
+    assert torch.equal(new.buf, old.buf), "dedicated FF-conv kernel and general kernel differ"
+    got = ops.join(new, R).cpu().double()
+    ref = _conv_ref64(x.half().float(), w.half().float(), bias, B, N)
+    err = ((got - ref).norm() / ref.norm()).item()
+    assert err < (6e-4 if out_precision == 2 else 1e-5), err      # the output format's own rounding: half 2^-11, FMT_H8 half + l8 ~ 2^-19
+
+
+def test_ffconv3_takes_the_big_shapes_by_itself():
+    """without any hook: a product of more than 64 output tiles runs on the dedicated kernel (same bits as with it switched off)"""
+    B, N, C = 32, 1024, 341
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B * N, C, generator=g)
+    w = torch.randn(C, C, 3, generator=g) * 0.03
+    a = ops.split(x.to(DEV), ldo=ops.conv3_input_ld(C), precision=2)
+    pw = ops.PackedWeight(w.to(DEV), precision=2).tile_conv3()
+    new = ops.linear_split(pw, a, conv_taps=3, dilation=1, seq_len=N, precision=2, out_precision=4)
+    try:
+        _force(4)
+        old = ops.linear_split(pw, a, conv_taps=3, dilation=1, seq_len=N, precision=2, out_precision=4)
+    finally:
+        _force(0)
+    assert torch.equal(new.buf, old.buf)
+
+
+@pytest.mark.parametrize("precision", ["hybrid", "half", "hybrid_ff"])
+@pytest.mark.parametrize("kw,B,N", [(dict(dim=128, depth=2), 32, 1024), (dict(dim=512, depth=1), 8, 1024)])
+def test_model_step_is_bit_identical_with_and_without_the_ffconv3_kernel(precision, kw, B, N):
+    m = Model(**kw, precision=precision)
+    sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=3)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = make_input("x", (B, N, kw["dim"]), seed=4).to(DEV)
+    t = make_input("times", (B,), seed=4, uniform=True).to(DEV)
+    with torch.no_grad():
+        try:
+            _force(0)
+            y_new = m(x, t).clone()
+            _force(4)
+            y_old = m(x, t).clone()
+        finally:
+            _force(0)
+    assert torch.isfinite(y_new).all()
+    assert torch.equal(y_new, y_old)

@@ -1,0 +1,597 @@
+// Round 6 probe: a DEDICATED kernel for the feed-forward causal conv (k = 3, dilation 1; NS2:1016, 583-595) of the hybrid plan --
+// dense IEEE-half activations [M, lda] x pre-tiled IEEE-half weights -> FMT_H8 lines (or fp32 for verification) -- built to find
+// out what the steady-state loop of the product kernel (csrc/gemm2.hip run_k8_conv3: 680 instructions per 96 MFMAs) can become
+// when addressing is hoisted out of it.  Stand-alone: compiles against csrc's headers, needs no torch.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../naturalspeech2_pytorch_amd/csrc -I../../include ffconv_probe.hip -o ffconv_probe
+//   ./ffconv_probe [--iters 20] [--rounds 5] [--variants 0,1,2] [--verify 1]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gemm_epi_fast.h"
+
+using namespace ns2;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
+
+namespace ffc {
+
+constexpr int RB = 128;                       // LDS row bytes = 64 halves = one K tile of one row
+constexpr int A_ROWS = 264;                   // A'(it): input rows m0 - 8 ... m0 + 255 (33 pieces of 8 rows)
+constexpr int A_BUF = A_ROWS * RB;            // 33792
+constexpr int W_BUF = 256 * RB;               // 32768
+constexpr int SA = 0, SW = 2 * A_BUF;         // LDS offsets (the dynamic LDS segment starts at 0: no static LDS in this kernel)
+constexpr int S_DUMP = SW + 2 * W_BUF;        // 1 KiB nobody reads: destination of the redirected piece of first-tile blocks
+constexpr int LDS_BYTES = 8 * EPI_LDS_WAVE_BYTES;
+
+struct Args {
+  const unsigned char* A;        // dense half [M, lda]
+  const unsigned char* Wt;       // tiled weights: [ntn][3 * tpt][32 KiB LDS image] (pack_w below)
+  const float* bias;
+  void* out;                     // FMT_H8 lines [M, ldo] (ldo logical, multiple of 32) or fp32 [M, ldo]
+  int M, N, lda, ldo, seq_len;
+  int tpt;                       // K tiles of 64 per tap (even)
+  int kc_last;                   // 16-deep chunks of the last K tile that hold data (2 or 4)
+  int order;                     // block id -> tile: 0 column tile fastest; 1 the half-valid last column tile's blocks first on half of each XCD's CUs; 2 two column tiles x 16 row tiles per XCD pass
+  int hot;                       // timing experiment: every block reads the operands of tile (0, 0) (everything hits in L2); results are garbage
+  unsigned long long* stats;     // optional: [0] += shader cycles, [1] += 100 MHz ticks of the K loops of wave 0 of every block, [2] += blocks
+};
+
+// ---- LDS-DMA as inline assembly: the compiler neither counts these loads (its waitcnt pass would drain them with vmcnt(0) in front of
+// every LDS read) nor needs to know M0.  `s_mov_b32 m0` + one wait state + the load (guide 5.7; cdna4 ISA: M0 write -> LDS-DMA).
+// The immediate offset is applied to BOTH the global and the LDS address.
+#define FFC_DMA(POLSTR, M0C) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" POLSTR ::"v"(voff), "s"(sbase), M0C, "n"(IMM) : "memory")
+template <int IMM, int POL = 0>
+NS2_DEVINL void dma_k(unsigned voff, const unsigned char* sbase, int m0c) {          // M0 = compile-time constant
+  if constexpr (POL == 1) FFC_DMA(" nt", "n"(m0c));
+  else if constexpr (POL == 2) FFC_DMA(" sc1", "n"(m0c));
+  else if constexpr (POL == 3) FFC_DMA(" sc0 sc1", "n"(m0c));
+  else if constexpr (POL == 4) FFC_DMA(" sc0", "n"(m0c));
+  else FFC_DMA("", "n"(m0c));
+}
+template <int IMM, int POL = 0>
+NS2_DEVINL void dma_s(unsigned voff, const unsigned char* sbase, unsigned m0s) {     // M0 from an SGPR
+  if constexpr (POL == 1) FFC_DMA(" nt", "s"(m0s));
+  else if constexpr (POL == 2) FFC_DMA(" sc1", "s"(m0s));
+  else if constexpr (POL == 3) FFC_DMA(" sc0 sc1", "s"(m0s));
+  else if constexpr (POL == 4) FFC_DMA(" sc0", "s"(m0s));
+  else FFC_DMA("", "s"(m0s));
+}
+template <int N> NS2_DEVINL void vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+NS2_DEVINL void bar_raw() { asm volatile("s_barrier" ::: "memory"); }
+
+// variant switches (template ints so that one binary holds every arm of an A/B)
+struct Cfg {
+  int prio;        // s_setprio around the MFMA clusters
+  int abl;         // 0 full; 1 no MFMA; 2 no DMA in the loop; 3 no fragment reads in the loop
+  int epi;         // 0 FMT_H8 lines (the product's epilogue); 1 fp32 (verification); 2 none
+};
+
+// STRUCT: 4 = four quadrant phases per step (8 MFMAs per slot), 2 = two phases per step (16 MFMAs per slot, reads complete before the barrier)
+// ABL: 0 full; 1 no MFMA; 2 no DMA in the loop; 3 no fragment reads; 4 MFMA + barriers only; 5 MFMA only (no barriers either)
+template <int PRIO, int ABL, int EPI, int STRUCT = 4, int POLA = 0, int POLW = 0>
+struct Kern {
+  static NS2_DEVINL void bar() { if constexpr (ABL != 5) bar_raw(); }
+  struct Ctx {
+    f32x16 acc[4][2];
+    bf16x8 A[2][4], W0[4], W1[4];
+    unsigned vA[3][4];         // fragment read addresses of A' per (tap, k chunk); + buffer / row-tile immediates
+    unsigned vW[4];
+    unsigned voA[4], voAx;     // DMA source offsets of this wave's A' pieces j = wave + 8 e (bytes from sA); voAx: piece 32 (wave 7)
+    unsigned voW0, voW1;       // DMA source offsets inside a W tile image: half 0 / half 1
+    const unsigned char* sA;   // A' source base of the NEXT `it` to request: A + (m0 - 8) * lda * 2 + it * 128
+    const unsigned char* sW;   // W tile image of the NEXT step to request
+    unsigned m0A[2][4];        // M0 of this wave's A' pieces per buffer (piece 0 of wave 0 of a first-tile block: the dump area)
+    unsigned m0W[2][2];        // M0 of this wave's pieces of W half b in buffer WBUF
+    int wave;
+    bool full_last;
+  };
+
+  static NS2_DEVINL bf16x8 lds16(unsigned addr, int imm) {           // imm: a constant after unrolling -> the ds_read's offset field
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    return *reinterpret_cast<const bf16x8*>(smem + addr + imm);
+  }
+
+  // fragments of A' half `a` (row tiles 2a, 2a+1) for tap TAP out of buffer ABUF
+  template <int TAP, int ABUF, int a> static NS2_DEVINL void load_a(Ctx& c) {
+    if constexpr (ABL == 3 || ABL >= 4) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      c.A[i][0] = lds16(c.vA[TAP][0], SA + ABUF * A_BUF + (2 * a + i) * 4096);
+      c.A[i][1] = lds16(c.vA[TAP][1], SA + ABUF * A_BUF + (2 * a + i) * 4096);
+      c.A[i][2] = lds16(c.vA[TAP][2], SA + ABUF * A_BUF + (2 * a + i) * 4096);
+      c.A[i][3] = lds16(c.vA[TAP][3], SA + ABUF * A_BUF + (2 * a + i) * 4096);
+    }
+  }
+  template <int WBUF, int b> static NS2_DEVINL void load_w(Ctx& c, bf16x8 (&W)[4]) {
+    if constexpr (ABL == 3 || ABL >= 4) return;
+    W[0] = lds16(c.vW[0], WBUF * W_BUF + b * 16384);
+    W[1] = lds16(c.vW[1], WBUF * W_BUF + b * 16384);
+    W[2] = lds16(c.vW[2], WBUF * W_BUF + b * 16384);
+    W[3] = lds16(c.vW[3], WBUF * W_BUF + b * 16384);
+  }
+  template <int a, int b, int KCN> static NS2_DEVINL void mma_q(Ctx& c, const bf16x8 (&W)[4]) {
+    if constexpr (ABL == 1) {
+      // keep the fragments alive without the MFMAs
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(c.A[0][j]), "v"(c.A[1][j]), "v"(W[j]));
+      return;
+    }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      c.acc[2 * a][b] = mma16<true>(c.A[0][kc], W[kc], c.acc[2 * a][b]);
+      c.acc[2 * a + 1][b] = mma16<true>(c.A[1][kc], W[kc], c.acc[2 * a + 1][b]);
+    }
+    if (KCN == 4 || c.full_last) {                  // KCN == 2: the last K tile, whose upper 32 columns may be padding (wave-uniform)
+#pragma unroll
+      for (int kc = 2; kc < 4; ++kc) {
+        c.acc[2 * a][b] = mma16<true>(c.A[0][kc], W[kc], c.acc[2 * a][b]);
+        c.acc[2 * a + 1][b] = mma16<true>(c.A[1][kc], W[kc], c.acc[2 * a + 1][b]);
+      }
+    }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+  }
+
+  // this wave's pieces of half B<b> of the W tile at c.sW into W buffer WBUF.  NW = 2 (every column quarter is needed) or 1 (last
+  // column tile, at most half valid: only the image's first 8 KiB of each half = column quarters 0 and 1)
+  template <int WBUF, int b, int NW> static NS2_DEVINL void issue_w(Ctx& c) {
+    if constexpr (ABL == 2 || ABL >= 4) return;
+    dma_s<0, POLW>(b ? c.voW1 : c.voW0, c.sW, c.m0W[WBUF][b]);
+    if constexpr (NW == 2) dma_s<1024, POLW>(b ? c.voW1 : c.voW0, c.sW, c.m0W[WBUF][b]);
+  }
+  // A' piece e (0..3) of this wave, and the 33rd piece (wave 7 only), of A'(it at c.sA) into A' buffer ABUF
+  template <int ABUF, int e> static NS2_DEVINL void issue_a(Ctx& c) {
+    if constexpr (ABL == 2 || ABL >= 4) return;
+    dma_s<0, POLA>(c.voA[e], c.sA, c.m0A[ABUF][e]);
+  }
+  template <int ABUF> static NS2_DEVINL void issue_ax(Ctx& c) {
+    if constexpr (ABL == 2 || ABL >= 4) return;
+    if (c.wave == 7) dma_k<0, POLA>(c.voAx, c.sA, SA + ABUF * A_BUF + 32 * 1024);
+  }
+
+  // One step = one (K tile `it`, tap): 32 MFMAs per wave in four accumulator-quadrant phases (the schedule of gemm2.hip's phased
+  // loops; hazards derived in DESIGN.md / the comments there): every phase = [fragment reads + requests] barrier [8 MFMAs] barrier,
+  // the wave groups 0-3 / 4-7 one barrier apart.  Requests: phases 0 / 1 of taps 0 and 1: one piece of A'(it + 1) each; phase 2: half B0,
+  // phase 3: half B1 of W(step + 2).  P = it & 1; the W buffer of step s = 3 it + tap is (P + TAP) & 1.
+  //   ACTIVE: this wave computes (false: the helper waves of a last column tile)    AI: request A'(it + 1)    WI: request W(step + 2)
+  template <int P, int TAP, int NW, bool ACTIVE, bool AI, bool WI, int KCN, bool WIP = true> static NS2_DEVINL void step(Ctx& c) {
+    constexpr int WB = (P + TAP) & 1;
+    // pieces of A' this wave requests in this step / requested in the previous one (wave 7's 33rd piece not counted: the smaller count is the safe one)
+    constexpr int aS = AI ? (TAP < 2 ? 2 : 0) : 0;
+    constexpr int aPrev = (TAP == 0) ? 0 : (AI ? 2 : 0);                 // previous step = tap - 1 of the same `it` (tap 0: tap 2 of it - 1 requested none)
+    constexpr int a0 = AI ? (TAP < 2 ? 1 : 0) : 0;
+    // ---- phase 0: quadrant (0, 0)
+    if constexpr (ACTIVE) { load_a<TAP, P, 0>(c); load_w<WB, 0>(c, c.W0); }
+    if constexpr (AI && TAP == 0) issue_a<P ^ 1, 0>(c);
+    if constexpr (AI && TAP == 1) issue_a<P ^ 1, 2>(c);
+    // half B1 of THIS step (requested in phase 3 two steps ago) is read in phase 1: everything older than the requests since then has landed
+    vmwait<(WIP ? 2 * NW : 0) + aPrev + a0>();  // WIP: the previous step requested W (false in the very last step only)
+    bar();
+    if constexpr (ACTIVE) mma_q<0, 0, KCN>(c, c.W0);
+    bar();
+    // ---- phase 1: quadrant (0, 1)
+    if constexpr (ACTIVE) load_w<WB, 1>(c, c.W1);
+    if constexpr (AI && TAP == 0) issue_a<P ^ 1, 1>(c);
+    if constexpr (AI && TAP == 1) { issue_a<P ^ 1, 3>(c); issue_ax<P ^ 1>(c); }
+    bar();
+    if constexpr (ACTIVE) mma_q<0, 1, KCN>(c, c.W1);
+    bar();
+    // ---- phase 2: quadrant (1, 1); request B0 of W(step + 2) into this step's W buffer (its B0 half was last read in phase 0)
+    if constexpr (ACTIVE) load_a<TAP, P, 1>(c);
+    if constexpr (WI) issue_w<WB, 0, NW>(c);
+    bar();
+    if constexpr (ACTIVE) mma_q<1, 1, KCN>(c, c.W1);
+    bar();
+    // ---- phase 3: quadrant (1, 0); request B1 of W(step + 2); B0 of step + 1 (and, before tap 0, all of A'(it + 1)) must have landed
+    if constexpr (WI) { issue_w<WB, 1, NW>(c); c.sW += W_BUF; }
+    vmwait<(WI ? 3 * NW : NW) + aS>();          // younger than B0(step + 1): B1(step + 1), this step's A' pieces, B0 / B1(step + 2)
+    bar();
+    if constexpr (ACTIVE) mma_q<1, 0, KCN>(c, c.W0);
+    bar();
+    if constexpr (AI && TAP == 2) c.sA += 128;
+  }
+
+
+  // STRUCT 2: two slots per step.  X: A' half 0 + both W halves -> quadrants (0,0) (0,1); Y: A' half 1 -> (1,1) (1,0).  Every load
+  // segment ends with lgkmcnt(0) BEFORE its barrier, so a buffer may be re-requested one slot after its last read: W(step + 2) in slot Y
+  // (the W tile was read in slot X), A'(it + 1) in the X slots of taps 0 / 1 (its buffer was last read in slot Y of the previous `it`).
+  template <int P, int TAP, int NW, bool ACTIVE, bool AI, bool WI, int KCN> static NS2_DEVINL void step2(Ctx& c) {
+    constexpr int WB = (P + TAP) & 1;
+    constexpr int aX = AI ? (TAP < 2 ? 2 : 0) : 0;
+    // ---- slot X
+    if constexpr (ACTIVE) { load_w<WB, 0>(c, c.W0); load_a<TAP, P, 0>(c); load_w<WB, 1>(c, c.W1); }
+    if constexpr (AI && TAP == 0) { issue_a<P ^ 1, 0>(c); issue_a<P ^ 1, 1>(c); }
+    if constexpr (AI && TAP == 1) { issue_a<P ^ 1, 2>(c); issue_a<P ^ 1, 3>(c); issue_ax<P ^ 1>(c); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bar();
+    if constexpr (ACTIVE) { mma_q<0, 0, KCN>(c, c.W0); mma_q<0, 1, KCN>(c, c.W1); }
+    bar();
+    // ---- slot Y
+    if constexpr (ACTIVE) load_a<TAP, P, 1>(c);
+    if constexpr (WI) { issue_w<WB, 0, NW>(c); issue_w<WB, 1, NW>(c); c.sW += W_BUF; }
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((WI ? 2 * NW : 0) + aX) : "memory");   // W(step + 1) (and, at tap 2, A'(it + 1)) has landed
+    bar();
+    if constexpr (ACTIVE) { mma_q<1, 1, KCN>(c, c.W1); mma_q<1, 0, KCN>(c, c.W0); }
+    bar();
+    if constexpr (AI && TAP == 2) c.sA += 128;
+  }
+  template <int P, int TAP, int NW, bool ACTIVE, bool AI, bool WI, int KCN, bool WIP = true> static NS2_DEVINL void stepx(Ctx& c) {
+    if constexpr (STRUCT == 2) step2<P, TAP, NW, ACTIVE, AI, WI, KCN>(c);
+    else step<P, TAP, NW, ACTIVE, AI, WI, KCN, WIP>(c);
+  }
+
+  template <int NW, bool ACTIVE> static NS2_DEVINL void kloop(Ctx& c, const int tpt) {
+    // steady state: pairs of K tiles (the buffer parities become immediates)
+    int it = 0;
+    for (; it + 2 < tpt; it += 2) {
+      stepx<0, 0, NW, ACTIVE, true, true, 4>(c); stepx<0, 1, NW, ACTIVE, true, true, 4>(c); stepx<0, 2, NW, ACTIVE, true, true, 4>(c);
+      stepx<1, 0, NW, ACTIVE, true, true, 4>(c); stepx<1, 1, NW, ACTIVE, true, true, 4>(c); stepx<1, 2, NW, ACTIVE, true, true, 4>(c);
+    }
+    // the last pair: no A' beyond it, no W beyond the last step; the last K tile may hold 32 columns only
+    stepx<0, 0, NW, ACTIVE, true, true, 4>(c); stepx<0, 1, NW, ACTIVE, true, true, 4>(c); stepx<0, 2, NW, ACTIVE, true, true, 4>(c);
+    stepx<1, 0, NW, ACTIVE, false, true, 2>(c); stepx<1, 1, NW, ACTIVE, false, false, 2>(c); stepx<1, 2, NW, ACTIVE, false, false, 2, false>(c);
+  }
+
+  // one path per kind of block / wave, each with its own accumulators and its own epilogue: alternative loop bodies that rewrite the
+  // SAME 128 accumulator registers meet in tuple copies at their merge point (measured here: 1500 spilled VGPRs)
+  template <int NW, bool ACTIVE> static NS2_DEVINL void body(const Args& g, const int tn, const int m0, const bool first) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1, l31 = lane & 31, hi = lane >> 5;
+    const long lda2 = 2L * g.lda;
+    Ctx c;
+    c.wave = wave;
+    c.full_last = g.kc_last == 4;
+    if constexpr (ACTIVE) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c.acc[mi][ni][r] = 0.f;
+      // fragment read addresses.  A' row of output row o and tap t: o + 6 + t; 16-B chunk q of LDS row r sits at q ^ ((r >> 1) & 7)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int r = wm * 128 + l31 + 6 + t;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) c.vA[t][kc] = r * RB + (((2 * kc + hi) ^ ((r >> 1) & 7)) << 4);
+      }
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) c.vW[kc] = SW + wn * 4096 + l31 * RB + (((2 * kc + hi) ^ ((l31 >> 1) & 7)) << 4);
+    }
+    // DMA source offsets.  A' piece j = wave + 8 e: LDS rows 8 j + lrow <- input rows m0 - 8 + 8 j + lrow, LDS position p of a row holds chunk p ^ swz(row)
+    const int lrow = lane >> 3, pch = lane & 7;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 8 * (wave + 8 * e) + lrow;
+      c.voA[e] = (unsigned)(row * lda2) + ((pch ^ ((row >> 1) & 7)) << 4);
+    }
+    { const int row = 256 + lrow; c.voAx = (unsigned)(row * lda2) + ((pch ^ ((row >> 1) & 7)) << 4); }
+#pragma unroll
+    for (int bf = 0; bf < 2; ++bf) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c.m0A[bf][e] = SA + bf * A_BUF + (wave + 8 * e) * 1024;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) c.m0W[bf][b] = SW + bf * W_BUF + b * 16384 + wave * (NW * 1024);
+    }
+    if (first && wave == 0) {                                     // wave-uniform: the piece in front of the utterance goes to the dump area,
+      c.voA[0] += (unsigned)(8 * lda2);                           // read from rows that exist
+      c.m0A[0][0] = S_DUMP; c.m0A[1][0] = S_DUMP;
+    }
+    c.sA = g.A + ((long)(g.hot ? 256 : m0) - 8) * lda2;
+    c.sW = g.Wt + (long)(g.hot ? 0 : tn) * (3 * g.tpt) * W_BUF;
+    c.voW0 = lane * 16 + wave * (NW * 1024);
+    c.voW1 = c.voW0 + 16384;
+    if (first && tid < 64) {
+      *reinterpret_cast<uint4*>(smem + SA + tid * 16) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(smem + SA + A_BUF + tid * 16) = make_uint4(0, 0, 0, 0);
+    }
+    // ---- prologue: A'(0), W(0), W(1) whole; everything landed before the first read
+    issue_a<0, 0>(c); issue_a<0, 1>(c); issue_a<0, 2>(c); issue_a<0, 3>(c); issue_ax<0>(c);
+    c.sA += 128;
+    issue_w<0, 0, NW>(c); issue_w<0, 1, NW>(c); c.sW += W_BUF; issue_w<1, 0, NW>(c); issue_w<1, 1, NW>(c); c.sW += W_BUF;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    bar();
+    if (wave >= 4) bar();                                         // the second group runs half a phase behind
+    if constexpr (ACTIVE && (ABL == 3 || ABL >= 4)) {              // ablations without fragment reads: any (finite) operand values
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c.A[0][j] = lds16(c.vA[0][j], 0); c.A[1][j] = lds16(c.vA[1][j], 0); c.W0[j] = lds16(c.vW[j], 0); c.W1[j] = lds16(c.vW[j], 16384); }
+    }
+    unsigned long long t0 = 0, r0 = 0;
+    if (g.stats) { t0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    kloop<NW, ACTIVE>(c, g.tpt);
+    if (g.stats && tid == 0) {
+      atomicAdd(g.stats + 0, (unsigned long long)(__builtin_readcyclecounter() - t0));
+      atomicAdd(g.stats + 1, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r0));
+      atomicAdd(g.stats + 2, 1ull);
+    }
+    if (wave < 4) bar();
+    if constexpr (!ACTIVE) return;
+    // ---- epilogue
+    const int row_base = m0 + wm * 128, col_base = tn * 256 + wn * 64;
+    if constexpr (EPI == 2) {
+      float s = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s += c.acc[mi][ni][r];
+      if (s == 12345.678f) reinterpret_cast<float*>(g.out)[tid] = s;
+      return;
+    }
+    if (col_base >= g.N) return;
+    if constexpr (EPI == 1) {
+      float* out = reinterpret_cast<float*>(g.out);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int col = col_base + ni * 32 + l31;
+          if (col >= g.N) continue;
+          const float bc = g.bias[col];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            out[(long)row * g.ldo + col] = c.acc[mi][ni][r] + bc;
+          }
+        }
+    } else {
+      GemmArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.M = g.M; ga.N = g.N; ga.bias = g.bias; ga.out_hi = reinterpret_cast<bf16_t*>(g.out); ga.out_lo = ga.out_hi + 32;
+      ga.ldo_s = g.ldo; ga.out_ncols = g.ldo; ga.out_fmt = FMT_H8; ga.epi = EPI_SPLIT;
+      unsigned char* const wbuf = smem + wave * EPI_LDS_WAVE_BYTES;
+      if (col_base + 64 <= g.N) epi_planes_fast<PF_H8, true>(c.acc, ga, 0, row_base, col_base, lane, wbuf);
+      else gemm_epilogue<EPI_SPLIT, 4, 2>(c.acc, ga, 0, row_base, col_base, 0, lane);
+    }
+  }
+
+  static NS2_DEVINL void run(const Args& g) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntn = (g.N + 255) >> 8, ntm = g.M >> 8;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tn_, tm_;
+    if (g.order == 1 && (ntm & 7) == 0 && g.N - (ntn - 1) * 256 <= 128 && ntn > 1) {
+      // per XCD (ntm / 8 row tiles x ntn column tiles, contiguous ids): first the blocks of the half-valid last column tile (they take ~0.6
+      // of a full block's time), so that the CUs of an XCD fall out of step and their epilogue store bursts stop coinciding
+      const int per = (ntm >> 3) * ntn, x = bid / per, i = bid - x * per, rt = ntm >> 3;
+      if (i < rt) { tm_ = x * rt + i; tn_ = ntn - 1; }
+      else { const int j = i - rt; tm_ = x * rt + j / (ntn - 1); tn_ = j % (ntn - 1); }
+    } else if (g.order == 2 && (ntm & 7) == 0 && (ntn & 1) == 0) {
+      const int per = (ntm >> 3) * ntn, x = bid / per, i = bid - x * per, rt = ntm >> 3;
+      const int cg = i / (2 * rt), k = i - cg * 2 * rt;          // column group of 2 tiles, inside it column fastest
+      tm_ = x * rt + (k >> 1); tn_ = cg * 2 + (k & 1);
+    } else { tn_ = bid % ntn; tm_ = bid / ntn; }
+    const int tn = __builtin_amdgcn_readfirstlane(tn_), tm = __builtin_amdgcn_readfirstlane(tm_);
+    const int m0 = tm * 256;
+    const bool first = __builtin_amdgcn_readfirstlane(m0 % g.seq_len) == 0;   // the 8 rows in front of the tile belong to the previous utterance: zeros
+    const bool last_half = tn * 256 + 128 >= g.N;                 // at most half of the column tile is valid
+    if (!last_half) body<2, true>(g, tn, m0, first);
+    else if (wave < 4) body<1, true>(g, tn, m0, first);
+    else body<1, false>(g, tn, m0, first);
+  }
+};
+
+template <int PRIO, int ABL, int EPI, int STRUCT = 4, int POLA = 0, int POLW = 0>
+__global__ __launch_bounds__(512, 2) void ffc_kernel(const Args g) { Kern<PRIO, ABL, EPI, STRUCT, POLA, POLW>::run(g); }
+
+// ---- host side: weights fp32 [N][C][3] -> the tiled LDS images (IEEE half, RNE)
+static inline uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+static inline float h2f_host(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+
+// image of tile (tn, step s = 3 it + tap): row n of the tile (output column tn * 256 + n) lives in half b = (n >> 5) & 1, quarter
+// wn = n >> 6, row r = n & 31 at byte b * 16384 + wn * 4096 + r * 128; chunk q (8 halves) of its 64-deep K tile at position q ^ ((r >> 1) & 7)
+static void pack_w(const std::vector<float>& w, int N, int C, int tpt, std::vector<uint16_t>& out) {
+  const int ntn = (N + 255) / 256, nst = 3 * tpt;
+  out.assign((size_t)ntn * nst * (W_BUF / 2), 0);
+  for (int tn = 0; tn < ntn; ++tn)
+    for (int it = 0; it < tpt; ++it)
+      for (int tap = 0; tap < 3; ++tap) {
+        uint16_t* img = out.data() + ((size_t)tn * nst + 3 * it + tap) * (W_BUF / 2);
+        for (int n = 0; n < 256; ++n) {
+          const int col = tn * 256 + n;
+          if (col >= N) continue;
+          const int b = (n >> 5) & 1, wn = n >> 6, r = n & 31;
+          for (int k = 0; k < 64; ++k) {
+            const int ch = it * 64 + k;
+            if (ch >= C) continue;
+            const int q = k >> 3, pos = q ^ ((r >> 1) & 7);
+            img[(b * 16384 + wn * 4096 + r * 128 + pos * 16) / 2 + (k & 7)] = f2h(w[((size_t)col * C + ch) * 3 + tap]);
+          }
+        }
+      }
+}
+
+}  // namespace ffc
+
+// ---- reference for a set of rows: double accumulation over the same half operands
+__global__ void ref_rows_kernel(const uint16_t* A, int lda, const float* w /* [N][C][3] rounded to half values */, const float* bias, int N, int C,
+                                int seq_len, const int* rows, int nrows, double* out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, ri = blockIdx.y;
+  if (n >= N || ri >= nrows) return;
+  const int m = rows[ri], pos = m % seq_len;
+  double s = bias[n];
+  for (int tap = 0; tap < 3; ++tap) {
+    const int sh = 2 - tap;
+    if (pos - sh < 0) continue;
+    const uint16_t* a = A + (long)(m - sh) * lda;
+    for (int ch = 0; ch < C; ++ch) s += (double)(float)__builtin_bit_cast(_Float16, a[ch]) * (double)w[((long)n * C + ch) * 3 + tap];
+  }
+  out[(long)ri * N + n] = s;
+}
+
+__global__ void fill_half_kernel(uint16_t* p, long rows, int ld, int valid, unsigned seed, float scale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ld) return;
+  const int col = (int)(i % ld);
+  unsigned x = (unsigned)(i * 2654435761u) ^ seed;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  unsigned y = x * 0x9e3779b9u + 0x7f4a7c15u; y ^= y >> 15; y *= 0x2c1b3c6du; y ^= y >> 12;
+  // Box-Muller: standard normal
+  const float u1 = ((x >> 8) + 1) * (1.0f / 16777217.0f), u2 = (y >> 8) * (1.0f / 16777216.0f);
+  const float v = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2) * scale;
+  p[i] = col < valid ? __builtin_bit_cast(uint16_t, (_Float16)v) : (uint16_t)0;
+}
+
+struct Variant { const char* name; void (*fn)(const ffc::Args); };
+
+int main(int argc, char** argv) {
+  int iters = 20, rounds = 5, verify = 1, order = 0, hot = 0;
+  std::string vsel = "";
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--iters")) iters = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--rounds")) rounds = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--verify")) verify = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--order")) order = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--hot")) hot = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--variants")) vsel = argv[++i];
+  }
+  const int B = 32, SEQ = 1024, F = 1365;
+  const int M = B * SEQ, N = F, C = F;
+  const int lda = 1408, tpt = lda / 64, Cv = (C + 31) / 32 * 32;
+  const int kc_last = (Cv - (tpt - 1) * 64) / 16;
+  const int ldo = 1376;
+  printf("ffconv probe: M %d N %d C %d lda %d tpt %d kc_last %d\n", M, N, C, lda, tpt, kc_last);
+  if (kc_last != 2 && kc_last != 4) { fprintf(stderr, "unsupported K tail\n"); return 2; }
+
+  // operands
+  uint16_t* dA; HIPCHK(hipMalloc(&dA, (size_t)M * lda * 2));
+  fill_half_kernel<<<(unsigned)(((long)M * lda + 255) / 256), 256>>>(dA, M, lda, C, 0x1234567u, 1.0f);
+  std::vector<float> w((size_t)N * C * 3), bias(N);
+  { unsigned s = 99991u; auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) * (1.0f / 16777216.0f)) * 2.f - 1.f; };
+    for (auto& v : w) { v = ffc::h2f_host(ffc::f2h(rnd() * 0.035f)); }
+    for (auto& v : bias) v = rnd(); }
+  std::vector<uint16_t> wt;
+  ffc::pack_w(w, N, C, tpt, wt);
+  unsigned char* dWt; HIPCHK(hipMalloc(&dWt, wt.size() * 2)); HIPCHK(hipMemcpy(dWt, wt.data(), wt.size() * 2, hipMemcpyHostToDevice));
+  float* dBias; HIPCHK(hipMalloc(&dBias, N * 4)); HIPCHK(hipMemcpy(dBias, bias.data(), N * 4, hipMemcpyHostToDevice));
+  float* dWf; HIPCHK(hipMalloc(&dWf, w.size() * 4)); HIPCHK(hipMemcpy(dWf, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+  float* dOutF; HIPCHK(hipMalloc(&dOutF, (size_t)M * ldo * 4));
+  unsigned char* dOutH; HIPCHK(hipMalloc(&dOutH, (size_t)M * ldo * 4));      // FMT_H8: 128 B per 32 logical columns = 4 B per column
+
+  ffc::Args g;
+  g.A = reinterpret_cast<const unsigned char*>(dA); g.Wt = dWt; g.bias = dBias; g.out = dOutH;
+  g.M = M; g.N = N; g.lda = lda; g.ldo = ldo; g.seq_len = SEQ; g.tpt = tpt; g.kc_last = kc_last; g.stats = nullptr; g.order = order; g.hot = 0;
+  unsigned long long* dStats; HIPCHK(hipMalloc(&dStats, 64)); HIPCHK(hipMemset(dStats, 0, 64));
+  const int ntn = (N + 255) / 256, grid = ntn * (M / 256);
+
+  std::vector<Variant> vars = {
+    {"S4 full prio1 h8", ffc::ffc_kernel<1, 0, 0, 4>},
+    {"S4 full prio1 no-epilogue", ffc::ffc_kernel<1, 0, 2, 4>},
+    {"S4 noMFMA (DMA+reads+barriers)", ffc::ffc_kernel<1, 1, 2, 4>},
+    {"S4 noDMA (reads+MFMA+barriers)", ffc::ffc_kernel<1, 2, 2, 4>},
+    {"S4 noREADS (DMA+MFMA+barriers)", ffc::ffc_kernel<1, 3, 2, 4>},
+    {"S4 MFMA+barriers", ffc::ffc_kernel<1, 4, 2, 4>},
+    {"S4 MFMA only", ffc::ffc_kernel<1, 5, 2, 4>},
+    {"S2 full prio1 h8", ffc::ffc_kernel<1, 0, 0, 2>},
+    {"S2 full prio0 h8", ffc::ffc_kernel<0, 0, 0, 2>},
+    {"S2 full prio1 no-epilogue", ffc::ffc_kernel<1, 0, 2, 2>},
+    {"S2 noMFMA (DMA+reads+barriers)", ffc::ffc_kernel<1, 1, 2, 2>},
+    {"S2 noDMA (reads+MFMA+barriers)", ffc::ffc_kernel<1, 2, 2, 2>},
+    {"S2 noREADS (DMA+MFMA+barriers)", ffc::ffc_kernel<1, 3, 2, 2>},
+    {"S2 MFMA+barriers", ffc::ffc_kernel<1, 4, 2, 2>},
+    {"S4 h8 A nt  W nt", ffc::ffc_kernel<1, 0, 0, 4, 1, 1>},
+    {"S4 h8 A sc1 W sc1", ffc::ffc_kernel<1, 0, 0, 4, 2, 2>},
+    {"S4 h8 A sc0sc1 W sc0sc1", ffc::ffc_kernel<1, 0, 0, 4, 3, 3>},
+    {"S4 h8 A sc0 W sc0", ffc::ffc_kernel<1, 0, 0, 4, 4, 4>},
+    {"S4 h8 A nt  W default", ffc::ffc_kernel<1, 0, 0, 4, 1, 0>},
+    {"S4 h8 A default W nt", ffc::ffc_kernel<1, 0, 0, 4, 0, 1>},
+  };
+  auto verify2_fn = ffc::ffc_kernel<1, 0, 1, 2>;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(verify2_fn), hipFuncAttributeMaxDynamicSharedMemorySize, ffc::LDS_BYTES));
+  auto verify_fn = ffc::ffc_kernel<1, 0, 1, 4>;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(verify_fn), hipFuncAttributeMaxDynamicSharedMemorySize, ffc::LDS_BYTES));
+  for (auto& v : vars) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, ffc::LDS_BYTES));
+
+  if (verify) {
+    ffc::Args gv = g; gv.out = dOutF;
+    HIPCHK(hipMemset(dOutF, 0xff, (size_t)M * ldo * 4));
+    hipLaunchKernelGGL(verify_fn, dim3(grid), dim3(512), ffc::LDS_BYTES, 0, gv);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<int> rows;
+    for (int tmi : {0, 1, 3, 4, 5, 63, 64, 127}) for (int r = 0; r < 256; ++r) rows.push_back(tmi * 256 + r);
+    int* dRows; HIPCHK(hipMalloc(&dRows, rows.size() * 4)); HIPCHK(hipMemcpy(dRows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+    double* dRef; HIPCHK(hipMalloc(&dRef, rows.size() * N * 8));
+    ref_rows_kernel<<<dim3((N + 127) / 128, (unsigned)rows.size()), 128>>>(dA, lda, dWf, dBias, N, C, SEQ, dRows, (int)rows.size(), dRef);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<double> ref(rows.size() * N);
+    HIPCHK(hipMemcpy(ref.data(), dRef, ref.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<float> got((size_t)N);
+    double worst = 0, num = 0, den = 0; long bad = 0;
+    for (size_t ri = 0; ri < rows.size(); ++ri) {
+      HIPCHK(hipMemcpy(got.data(), dOutF + (size_t)rows[ri] * ldo, N * 4, hipMemcpyDeviceToHost));
+      for (int n = 0; n < N; ++n) {
+        const double d = fabs((double)got[n] - ref[ri * N + n]);
+        num += d * d; den += ref[ri * N + n] * ref[ri * N + n];
+        if (!(d <= 2e-4 + 2e-5 * fabs(ref[ri * N + n]))) { if (bad < 10) printf("  MISMATCH row %d col %d: got %.7g ref %.7g\n", rows[ri], n, got[n], ref[ri * N + n]); ++bad; }
+        worst = std::max(worst, d);
+      }
+    }
+    printf("verify (fp32 epilogue, %zu rows x %d cols vs fp64 sums of the same half operands): rel L2 %.3e, worst abs %.3e, mismatches %ld -> %s\n",
+           rows.size(), N, sqrt(num / den), worst, bad, bad ? "FAIL" : "ok");
+    // full-output checksum of the fp32 result (for bitwise comparisons between builds)
+    std::vector<float> all((size_t)M * ldo);
+    HIPCHK(hipMemcpy(all.data(), dOutF, all.size() * 4, hipMemcpyDeviceToHost));
+    unsigned long long h = 1469598103934665603ull;
+    for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) { unsigned u; memcpy(&u, &all[(size_t)m * ldo + n], 4); h = (h ^ u) * 1099511628211ull; }
+    printf("fp32 output digest %016llx\n", h);
+    // run twice more: deterministic?
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(verify_fn, dim3(grid), dim3(512), ffc::LDS_BYTES, 0, gv);
+      HIPCHK(hipDeviceSynchronize());
+      std::vector<float> again((size_t)M * ldo);
+      HIPCHK(hipMemcpy(again.data(), dOutF, again.size() * 4, hipMemcpyDeviceToHost));
+      long diff = 0;
+      for (int m = 0; m < M; ++m) if (memcmp(&all[(size_t)m * ldo], &again[(size_t)m * ldo], N * 4)) ++diff;
+      printf("  rerun %d: rows that differ %ld\n", rep, diff);
+    }
+    hipLaunchKernelGGL(verify2_fn, dim3(grid), dim3(512), ffc::LDS_BYTES, 0, gv);
+    HIPCHK(hipDeviceSynchronize());
+    { std::vector<float> again((size_t)M * ldo);
+      HIPCHK(hipMemcpy(again.data(), dOutF, again.size() * 4, hipMemcpyDeviceToHost));
+      long diff = 0;
+      for (int m = 0; m < M; ++m) if (memcmp(&all[(size_t)m * ldo], &again[(size_t)m * ldo], N * 4)) ++diff;
+      printf("  S2 structure vs S4: rows that differ %ld\n", diff); if (diff) bad = 1; }
+    if (bad) return 1;
+  }
+
+  g.hot = hot;
+  printf("timing: order %d hot %d\n", order, hot);
+  const double flops = 2.0 * M * (double)N * 3 * C;
+  std::vector<int> sel;
+  if (vsel.empty()) for (size_t i = 0; i < vars.size(); ++i) sel.push_back((int)i);
+  else { size_t p = 0; while (p < vsel.size()) { sel.push_back(atoi(vsel.c_str() + p)); p = vsel.find(',', p); if (p == std::string::npos) break; ++p; } }
+  std::vector<std::vector<float>> times(vars.size());
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (int r = 0; r < rounds; ++r)
+    for (int vi : sel) {
+      for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(vars[vi].fn, dim3(grid), dim3(512), ffc::LDS_BYTES, 0, g);
+      HIPCHK(hipEventRecord(e0));
+      for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(vars[vi].fn, dim3(grid), dim3(512), ffc::LDS_BYTES, 0, g);
+      HIPCHK(hipEventRecord(e1)); HIPCHK(hipEventSynchronize(e1));
+      float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      times[vi].push_back(ms / iters);
+    }
+  for (int vi : sel) {
+    auto t = times[vi]; std::sort(t.begin(), t.end());
+    const double med = t[t.size() / 2];
+    HIPCHK(hipMemset(dStats, 0, 64));
+    ffc::Args gs = g; gs.stats = dStats;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(vars[vi].fn, dim3(grid), dim3(512), ffc::LDS_BYTES, 0, gs);
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long st[3]; HIPCHK(hipMemcpy(st, dStats, 24, hipMemcpyDeviceToHost));
+    const double ghz = st[1] ? (double)st[0] / ((double)st[1] * 10.0) : 0.0, cyc_blk = st[2] ? (double)st[0] / st[2] : 0.0;
+    printf("%-36s median %7.1f us  min %7.1f us  %7.1f TF | K loop: %8.0f cycles per block, %6.0f per step, clock %.2f GHz\n", vars[vi].name, med * 1e3, t[0] * 1e3,
+           flops / med / 1e9, cyc_blk, cyc_blk / (3.0 * tpt), ghz);
+  }
+  return 0;
+}
