@@ -51,8 +51,8 @@ extern "C" {
 const char* ns2_last_error(void);
 int ns2_version(void);
 /* test hook: force the GEMM kernel variant (0 = dispatch by shape, 1 = 128x128 register-staged, 2 = 256x256 LDS-DMA,
- * 3 = dispatch by shape but never split K, 4 = dispatch by shape but never the dedicated FF-conv kernel, 5 = dispatch by shape but
- * the dedicated FF-conv kernel whenever a call is eligible, whatever its size) */
+ * 3 = dispatch by shape but never split K, 4 = dispatch by shape but never the round-6 kernels (ffconv_kernel.h, gemm3_kernel.h), 5 = dispatch by shape but
+ * those kernels whenever a call is eligible, whatever its size) */
 int ns2_debug_force_gemm(int kernel);
 /* Split-K of small products.  ns2_model_forward* lend a region of their workspace to every GEMM of the pass: a product with too
  * few output tiles to fill the chip runs as K slices into fixed slots plus a second launch that adds the slots in order and
@@ -107,6 +107,11 @@ int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* 
  * general kernel's (same products, same summation order).  ns2_model_finalize does all of this for precisions 2 / 5 / 6. */
 int ns2_weight_tile_conv3(ns2_weight* w, void* stream);
 int ns2_conv3_input_ld(int cols);
+/* The mixed linear products (precision 4, FMT_H8 operands) on full 256-row tiles have a lean kernel too (csrc/gemm3_kernel.h): same
+ * arithmetic and summation order as the general kernel (bit-identical results), weights read as pre-tiled LDS images.
+ * ns2_weight_tile_linear builds them for a weight packed with taps = 1 at precision 4 (also with geglu = 1); ns2_linear_f32 / _split /
+ * _split_as / _qkv / _geglu then take the kernel when M % 256 == 0 and K >= 96.  Same life-cycle rules as ns2_weight_tile_conv3. */
+int ns2_weight_tile_linear(ns2_weight* w, void* stream);
 /* same, with the output planes in the format of ANOTHER precision (out_precision 3: bf16 hi / lo lines from a precision-4 product --
  * the q | k | v projection of the mixed training arithmetic, whose attention stays bf16 x3) */
 int ns2_linear_split_as(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,

@@ -34,7 +34,8 @@ extern "C" int ns2_weight_update(ns2_weight* w, const float* w_src, const float*
   if (extra1x1)
     HIPRET(launch_pack_weight(extra1x1, w->cols, 1, w->cols_p, w->d_map, w->w.rows_p, w->w.hi, w->w.lo, w->w.ldk, w->taps * w->cols_p, s,
                               w->w.fmt));
-  if (w->w.t3) return build_conv3_tiles(&w->owned, &w->w, s);      // the tiled copy of a k = 3 conv weight follows its pack (no allocation: it exists)
+  if (w->w.t3) return build_conv3_tiles(&w->owned, &w->w, s);      // the tiled copies follow the pack (no allocation: they exist)
+  if (w->w.tl) return build_lin_tiles(&w->owned, &w->w, s);
   return NS2_OK;
 }
 

@@ -21,12 +21,12 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "gemm_epi_fast.h"
+#include "gemm2_epilogue.h"
 #include "ffconv_kernel.h"
+#include "gemm3_kernel.h"
 
 namespace ns2 {
 
-constexpr int G2_BM = 256, G2_BN = 256;
 // (Round 3's schedule variants, timing-diagnostic builds and the buffer-descriptor DMA experiment -- G2_VAR, G2_DIAG, G2_BUFLDS --
 // live in tools/experiments/gemm2_r3_with_diag_variants.hip; the one-barrier-per-tile loops the phased loops were A/B'd against
 // (round 3: -DG2_PHASED=0, -DG2_PHASED_CONV3=0, -DG2_CONV3=false) in tools/experiments/gemm2_r4_one_barrier_loops.hip.)
@@ -916,68 +916,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmArgs g) {
     run_k8(ModeMain{}, 0, ntaps * tiles_per_tap(ModeMain{}));
   }
   BSTAMP(2);
-  // all waves are past the K loop's last barrier: the LDS ring is free, every wave takes a private 18 KiB region
-  if (wave_active) {
-    bool done = false;
-    unsigned char* const wbuf = smem + wave * EPI_LDS_WAVE_BYTES;
-    const int ocol_base = tn * 128 + wn * 32;
-#ifndef G2_SLOW_EPILOGUE
-    // Interior wave tiles (all 128 rows and 64 columns valid) take the streamlined epilogues of gemm_epi_fast.h; edge tiles
-    // and the formats a kernel of this arithmetic does not normally write keep the generic path.
-    if (row_base + 128 <= g.M) {
-      // plane format of the output: kernels on IEEE-half operands write F16 / H8, kernels on bf16 operands bf16 planes
-      auto planes = [&](auto&& fn) __attribute__((always_inline)) {
-        const bool al = ((reinterpret_cast<uintptr_t>(g.out_hi) & 15) == 0) && (g.ldo_s & 31) == 0;
-        if (!al) return false;
-        if constexpr (F16) {
-          if (g.out_fmt == FMT_F16 && !g.out_lo) { fn(std::integral_constant<int, PF_F16>{}); return true; }
-          if (g.out_fmt == FMT_H8) { fn(std::integral_constant<int, PF_H8>{}); return true; }
-          // bf16 hi / lo lines from the mixed product: q | k | v of the mixed TRAINING arithmetic, whose attention stays bf16 x3
-          if constexpr (NSPLIT == 2 && EPI == EPI_SPLIT) { if (g.out_fmt == FMT_BF16 && g.out_lo) { fn(std::integral_constant<int, PF_BF16IL>{}); return true; } }
-        } else {
-          if (g.out_fmt == FMT_BF16 && g.out_lo) { fn(std::integral_constant<int, PF_BF16IL>{}); return true; }
-          if constexpr (NSPLIT == 1) { if (g.out_fmt == FMT_BF16 && !g.out_lo) { fn(std::integral_constant<int, PF_BF16>{}); return true; } }
-        }
-        return false;
-      };
-      if constexpr (EPI == EPI_F32) {
-        if (col_base + 64 <= g.N && g.act == 0 && (g.ldo_f & 3) == 0 && (reinterpret_cast<uintptr_t>(g.out_f) & 15) == 0 &&
-            (!g.resid || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.resid) & 15) == 0))) {
-          epi_f32_fast(acc, g, z, row_base, col_base, lane, wbuf);
-          done = true;
-        }
-      } else if constexpr (EPI == EPI_GEGLU) {
-        if (ocol_base + 32 <= g.out_ncols)
-          done = planes([&](auto pf) __attribute__((always_inline)) { epi_geglu_fast<decltype(pf)::value>(acc, g, row_base, col_base, ocol_base, lane, wbuf); });
-      } else if constexpr (EPI == EPI_SPLIT) {
-        if (col_base + 64 <= g.N && g.act == 0)
-          done = planes([&](auto pf) __attribute__((always_inline)) { epi_planes_fast<decltype(pf)::value, true>(acc, g, z, row_base, col_base, lane, wbuf); });
-      } else if constexpr (EPI == EPI_WAVENET) {
-        if (col_base + 64 <= g.N)
-          done = planes([&](auto pf) __attribute__((always_inline)) { epi_planes_fast<decltype(pf)::value, false>(acc, g, z, row_base, col_base, lane, wbuf); });
-      } else if constexpr (EPI == EPI_QKV) {
-        if (col_base + 64 <= g.N && !g.bias) {
-          if (col_base + 64 <= g.split_col) {
-            done = planes([&](auto pf) __attribute__((always_inline)) { epi_planes_fast<decltype(pf)::value, false>(acc, g, 0, row_base, col_base, lane, wbuf); });
-          } else if (col_base >= g.split_col && !g.vt_lo && g.vt_fmt == (F16 ? FMT_F16 : FMT_BF16) && g.seq_len > 0 &&
-                     (g.seq_len & 127) == 0 && (g.vt_ld & 7) == 0 && (reinterpret_cast<uintptr_t>(g.vt_hi) & 15) == 0) {
-            epi_vt_fast<F16>(acc, g, row_base, col_base, lane, wbuf);
-            done = true;
-          }
-        }
-      }
-    }
-#endif
-    if (!done) {
-      if constexpr (EPI == EPI_F32) {
-        if (epi_lds_supported<EPI>(g, row_base)) {
-          gemm_epilogue_lds<EPI, 2, 0>(acc, g, z, row_base, col_base, ocol_base, lane, wbuf);
-          done = true;
-        }
-      }
-      if (!done) gemm_epilogue<EPI, 4, 2>(acc, g, z, row_base, col_base, ocol_base, lane);
-    }
-  }
+  g2_block_epilogue<NSPLIT, EPI, F16>(acc, g, z, tm, tn, wave, lane, smem);
 #ifdef G2_BLKTRACE
   BSTAMP(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1088,7 +1027,7 @@ bool gemm_fuses_norm(const GemmArgs& g, int precision) {
   if (g.epi != EPI_F32 || g.M <= 0 || g.act != 0 || g.nz > 1 || g.ksplit != 0 || g.dil_z) return false;
   if ((g.ldo_f & 3) || (reinterpret_cast<uintptr_t>(g.out_f) & 15) || (g.resid && ((g.ldr & 3) || (reinterpret_cast<uintptr_t>(g.resid) & 15)))) return false;
   const int f = forced_kernel();
-  if (f == 0 && g.sk_ws) {
+  if ((f == 0 || f == 4) && g.sk_ws) {
     int S, c;
     splitk_plan(g.M, g.N, g.nkt, g.kt_per_tap, true, g.sk_ws_floats, &S, &c);
     if (S >= 2) return g.N == 128 || g.N == 256 || g.N == 512;
@@ -1122,10 +1061,11 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
       !planes_ok(g.vt_hi, g.vt_lo))
     return hipErrorInvalidValue;
   const int f = forced_kernel();
-  if (f == 5 && ffconv3_eligible(g, precision)) return launch_ffconv3(g, s);      // test hook: the dedicated FF-conv kernel whatever the size
+  if (f == 5 && ffconv3_eligible(g, precision)) return launch_ffconv3(g, s);      // test hook: the dedicated kernels whatever the size
+  if (f == 5 && gemm3_eligible(g, precision)) return launch_gemm3(g, s);
   // Small products (a batch of 1 ... 4 utterances) split K when the caller lent scratch (splitk_plan above).
   // (f == 3: automatic kernel choice, never split -- A/B hook.)
-  if (f == 0 && g.sk_ws && g.epi != EPI_WAVENET && g.nz <= 1 && !g.dil_z && g.ksplit == 0) {
+  if ((f == 0 || f == 4) && g.sk_ws && g.epi != EPI_WAVENET && g.nz <= 1 && !g.dil_z && g.ksplit == 0) {
     int S, c;
     splitk_plan(g.M, g.N, g.nkt, g.kt_per_tap, g.epi == EPI_F32, g.sk_ws_floats, &S, &c);
     if (S >= 2) return launch_gemm_splitk(g, precision, S, c, s);
@@ -1137,6 +1077,8 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
   if (!big) return launch_gemm1(g, precision, s);
   // the FF causal conv of the one-half-product plans on full row tiles: its own kernel (ffconv_kernel.h)
   if ((f == 0 || f == 3) && ffconv3_eligible(g, precision)) return launch_ffconv3(g, s);
+  // the mixed linear products on full row tiles: the lean kernel (gemm3_kernel.h)
+  if ((f == 0 || f == 3) && gemm3_eligible(g, precision)) return launch_gemm3(g, s);
   switch (precision) {
     case 3: return launch2_epi<3, false>(g, s);
     case 4: return launch2_epi<2, true>(g, s);
@@ -1150,6 +1092,8 @@ hipError_t ffconv3_build_tiles(const bf16_t* w_hi, int ldw, int Cp, int rows_p, 
   return launch_ffconv3_tile(w_hi, ldw, Cp, rows_p, N, out, s);
 }
 int ffconv3_lda(int Cp) { return ffconv3_tiles_per_tap(Cp) * 64; }
+size_t gemm3_tiled_bytes_of(int rows_p, int nkt) { return gemm3_tiled_bytes(rows_p, nkt); }
+hipError_t gemm3_build_tiles(const bf16_t* w_hi, int ldk, int rows_p, bf16_t* out, hipStream_t s) { return launch_gemm3_tile(w_hi, ldk, rows_p, out, s); }
 
 NS2_DEFINE_SATURATION_READER(gemm2)
 

@@ -195,6 +195,15 @@ int build_conv3_tiles(std::vector<void*>* owned, PackedW* w, hipStream_t s) {
   return NS2_OK;
 }
 
+// FMT_H8 linear weights: (re)build the tiled LDS images the lean mixed linear kernel reads (gemm3_kernel.h) -- a permutation of the packed bytes.
+// Other formats, convolutions and K < 96: nothing to do (those products keep gemm2_kernel / gemm_kernel).
+int build_lin_tiles(std::vector<void*>* owned, PackedW* w, hipStream_t s) {
+  if (w->fmt != FMT_H8 || !w->lo || w->nkt != w->kt_per_tap || w->nkt < 3 || (w->rows_p & 255)) return NS2_OK;
+  if (!w->tl) NSCHK(dev_alloc(owned, (void**)&w->tl, gemm3_tiled_bytes_of(w->rows_p, w->nkt)));
+  HIPCHK(gemm3_build_tiles(w->hi, w->ldk, w->rows_p, w->tl, s));
+  return NS2_OK;
+}
+
 static int pack_geglu(const PackCtx& pc, PackedW* w, const float* src, int f, int C, hipStream_t s) {
   const int Cp = rup(C, 32), fpad = rup(f, 32);
   NSCHK(alloc_packed(pc, w, 2 * fpad, Cp, Cp / 32));
@@ -253,7 +262,7 @@ static GemmArgs base_args(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_
   memset(&g, 0, sizeof(g));
   g.sk_ws = tl_sk_ws; g.sk_ws_floats = tl_sk_ws ? SPLITK_SCRATCH_FLOATS : 0;
   g.a_hi = a_hi; g.a_lo = a_lo; g.lda = lda;
-  g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk; g.w_t3 = w.t3;
+  g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk; g.w_t3 = w.t3; g.w_tl = w.tl;
   g.M = M; g.N = w.N; g.nkt = w.nkt; g.kt_per_tap = w.nkt; g.conv_taps = 0; g.dil = 1; g.mid_kt = -1;
   g.nz = 1; g.pad_left = -1; g.act = 0; g.out_fmt = -1; g.vt_fmt = -1;
   return g;
@@ -528,6 +537,13 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
       NSCHK(pack_geglu_bias(&m->owned, &r.b_ffin, b1->p, f, r.ffin.rows_p));
       NSCHK(pack_linear(pc_cond, &r.ffout, w2->p, dim, f, 1, s)); r.b_ffout = b2->p;
     }
+  }
+  // tiled images of the per-step mixed linear weights (gemm3_kernel.h): +1 copy of 12.6 MB per layer at d512
+  NSCHK(build_lin_tiles(&m->owned, &m->w_skip, s)); NSCHK(build_lin_tiles(&m->owned, &m->w_final, s)); NSCHK(build_lin_tiles(&m->owned, &m->w_pred, s));
+  for (auto& ly : m->layers) {
+    NSCHK(build_lin_tiles(&m->owned, &ly.qkv, s)); NSCHK(build_lin_tiles(&m->owned, &ly.out, s));
+    NSCHK(build_lin_tiles(&m->owned, &ly.ffin, s)); NSCHK(build_lin_tiles(&m->owned, &ly.ffout, s));
+    if (cond) { NSCHK(build_lin_tiles(&m->owned, &ly.cq, s)); NSCHK(build_lin_tiles(&m->owned, &ly.cout, s)); }
   }
   {   // device-side list of the registered parameter tensors (read in place: they alias the module's parameters)
     std::vector<const float*> ptrs; std::vector<long> numels;

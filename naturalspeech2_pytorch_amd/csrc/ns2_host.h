@@ -15,6 +15,7 @@ struct PackedW {                 // bf16 split-plane weight, rows padded to 128,
   bf16_t* hi = nullptr; bf16_t* lo = nullptr;
   int rows_p = 0, ldk = 0, N = 0, nkt = 0, kt_per_tap = 0;
   int fmt = 0;                   // PlaneFmt: bf16 planes (precisions 1 / 3), dense IEEE half (2), FMT_H8 lines (4)
+  bf16_t* tl = nullptr;          // FMT_H8 linear weights: the tiled LDS images of the lean mixed linear kernel (gemm3_kernel.h), or null
   bf16_t* t3 = nullptr;          // k = 3 conv weights in dense IEEE half: the tiled LDS images of the dedicated FF-conv kernel (ffconv_kernel.h), or null
 };
 
@@ -38,7 +39,8 @@ int gemm_wavenet(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_lo, int l
 int pack_weight_public(const float* w, int rows, int cols, int taps, int geglu, const float* extra, int precision, PackedW* out,
                        std::vector<void*>* owned, hipStream_t s);
 std::vector<int> geglu_row_map(int f, int rows_p);
-int build_conv3_tiles(std::vector<void*>* owned, PackedW* w, hipStream_t s);   // model_exec.cpp: (re)build w->t3 from the row-major pack
+int build_conv3_tiles(std::vector<void*>* owned, PackedW* w, hipStream_t s);
+int build_lin_tiles(std::vector<void*>* owned, PackedW* w, hipStream_t s);     // model_exec.cpp: (re)build w->tl (FMT_H8 packs; a no-op for other formats)   // model_exec.cpp: (re)build w->t3 from the row-major pack
 
 }  // namespace ns2
 

@@ -48,6 +48,7 @@ struct GemmArgs {
   const bf16_t* a_hi; const bf16_t* a_lo; int lda;
   // W operand: packed weights, bf16 split planes [ceil(N/128)*128, ldw], K contiguous
   const bf16_t* w_hi; const bf16_t* w_lo; int ldw;
+  const bf16_t* w_tl;       // optional: the same FMT_H8 linear weight as tiled LDS images (gemm3_kernel.h); null = none
   const bf16_t* w_t3;       // optional: the same conv weight (k = 3, dense IEEE half) as tiled LDS images (ffconv_kernel.h); null = none
   int M, N;          // N = valid output columns
   int nkt;           // number of 32-wide K tiles (total, all taps/phases)
@@ -102,7 +103,10 @@ void force_gemm_kernel(int k);                                          // 0 aut
 // the dedicated FF causal conv kernel (ffconv_kernel.h, compiled in gemm2.hip): tiled weight images
 size_t ffconv3_tiled_bytes_of(int N, int Cp);
 hipError_t ffconv3_build_tiles(const bf16_t* w_hi, int ldw, int Cp, int rows_p, int N, bf16_t* out, hipStream_t s);
-int ffconv3_lda(int Cp);                                                // activations' row length (elements) the kernel wants for Cp packed columns per tap
+int ffconv3_lda(int Cp);
+// the lean mixed linear kernel (gemm3_kernel.h, compiled in gemm2.hip): tiled weight images of an FMT_H8 pack [rows_p][ldk]
+size_t gemm3_tiled_bytes_of(int rows_p, int nkt);
+hipError_t gemm3_build_tiles(const bf16_t* w_hi, int ldk, int rows_p, bf16_t* out, hipStream_t s);                                                // activations' row length (elements) the kernel wants for Cp packed columns per tap
 constexpr long SPLITK_SCRATCH_FLOATS = 512L * 128 * 128;                // what any split needs at most: slices x output tiles <= 512 tiles of 128 x 128 (32 MiB)
 
 // flash attention forward, head dim 64, non-causal (ATT:77-155 hot path)

@@ -112,3 +112,87 @@ def test_model_step_is_bit_identical_with_and_without_the_ffconv3_kernel(precisi
             _force(0)
     assert torch.isfinite(y_new).all()
     assert torch.equal(y_new, y_old)
+
+
+# ---------------------------------------------------------------------------------------------- the lean mixed linear kernel (gemm3_kernel.h)
+LIN_CASES = [
+    # M, K, N            what the shape reaches
+    (2048, 512, 1536),   # q | k | v widths: even tile count, 6 full column tiles
+    (1024, 1365, 512),   # FF-out: K = 1376 = 43 tiles (odd: the peeled steady tile), 2 column tiles
+    (512, 96, 200),      # the smallest K (3 tiles: peel + tail only), a partly valid column tile
+    (768, 160, 300),     # 5 tiles (peel + one pair + tail), N = 256 + 44
+    (256, 128, 128),     # 4 tiles (no steady pair), one row tile, half a column tile
+]
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("M,K,N", LIN_CASES)
+def test_gemm3_f32_split_equal_gemm2_bit_for_bit(M, K, N):
+    g = torch.Generator().manual_seed(7 + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    bias, resid = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    a = ops.split(x.to(DEV), precision=4)
+    pw = ops.PackedWeight(w.to(DEV), precision=4).tile_linear()
+    outs = {}
+    try:
+        for k in (5, 2):
+            _force(k)
+            outs[k] = (ops.linear_f32(pw, a, bias=bias, resid=resid, precision=4), ops.linear_split(pw, a, bias=bias, precision=4).buf.clone(),
+                       ops.linear_f32(pw, a, precision=4, act=1))
+    finally:
+        _force(0)
+    for i in range(3):
+        assert torch.equal(outs[5][i], outs[2][i]), f"output {i} of the lean kernel differs from gemm2_kernel's"
+    ref = x.double() @ w.double().t() + bias.cpu().double() + resid.cpu().double()
+    assert _rel(outs[5][0].cpu(), ref) < 2e-4
+
+
+@pytest.mark.parametrize("B,N,d", [(4, 256, 512), (2, 512, 128)])
+def test_gemm3_qkv_and_geglu_equal_gemm2_bit_for_bit(B, N, d):
+    g = torch.Generator().manual_seed(11 + d)
+    M, f = B * N, int(d * 8 / 3)
+    x = torch.randn(M, d, generator=g)
+    a = ops.split(x.to(DEV), precision=4)
+    wq = ops.PackedWeight((torch.randn(3 * 512, d, generator=g) * d ** -0.5).to(DEV), precision=4).tile_linear()
+    w1 = ops.PackedWeight((torch.randn(2 * f, d, generator=g) * d ** -0.5).to(DEV), geglu=True, precision=4).tile_linear()
+    pb = ops.geglu_pack_bias(torch.randn(2 * f, generator=g).to(DEV), f)
+    outs = {}
+    try:
+        for k in (5, 2):
+            _force(k)
+            q, vt = ops.linear_qkv(wq, a, seq_len=N, split_col=1024, precision=4)
+            h = ops.linear_geglu(w1, a, pb, precision=4)
+            outs[k] = (q.buf.clone(), vt.buf.clone(), h.buf.clone())
+    finally:
+        _force(0)
+    for i in range(3):
+        assert torch.equal(outs[5][i], outs[2][i])
+
+
+@pytest.mark.parametrize("precision", ["hybrid", "mixed"])
+@pytest.mark.parametrize("kw,B,N,cond", [(dict(dim=128, depth=2), 16, 1024, False), (dict(dim=512, depth=1), 4, 1024, False),
+                                         (dict(dim=512, depth=1, dim_prompt=512, condition_on_prompt=True), 4, 512, True)])
+def test_model_step_is_bit_identical_with_and_without_the_round6_kernels(precision, kw, B, N, cond):
+    m = Model(**kw, precision=precision)
+    sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=3)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = make_input("x", (B, N, kw["dim"]), seed=4).to(DEV)
+    t = make_input("times", (B,), seed=4, uniform=True).to(DEV)
+    extra = {}
+    if cond:
+        extra = dict(prompt=make_input("prompt", (B, 40, 512), seed=6).to(DEV), cond=make_input("cond", (B, 512, N), seed=7).to(DEV))
+    with torch.no_grad():
+        try:
+            _force(0)
+            y_new = m(x, t, **extra).clone()
+            _force(4)
+            y_old = m(x, t, **extra).clone()
+        finally:
+            _force(0)
+    assert torch.isfinite(y_new).all()
+    assert torch.equal(y_new, y_old)
