@@ -42,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PMC_TRAFFIC = "r05_pmc_traffic.json"  # profiles/: committed PMC profile of the dominant kernel (tools/pmc_mfma_bench.sh, r05_pmc_mfma.json)
-PARITY_RECORD = "r05_parity.json"    # profiles/: the tracked key-wise parity record (tests/parity_record.py)
+PARITY_RECORD = "r06_parity.json"    # profiles/: the tracked key-wise parity record (tests/parity_record.py)
 PEAK_16BIT_TFLOPS = 2500.0         # dense bf16 / f16 MFMA peak, MI355X_MICROARCH.md (spec; 2495 measured)
 PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (RVQ)
 UTT_GFLOP = {(512, 12, False): 316.37, (512, 12, True): 331.98, (128, 6, False): 26.74}   # per 1024-frame utterance, SURVEY §8d
@@ -138,7 +138,7 @@ def train_step_side(dev):
                         loss_mixed=res["mixed"][1], loss_exact=res["exact"][1], loss_composite=res["composite"][1],
                         loss_iteration=f"all after 2 warm-up + {iters} Adam steps from the same init", timing="the faster of two timed windows of steps",
                         parity="every parameter's .grad vs the reference's own autograd in both arithmetics: tests/test_backward_gpu.py, "
-                               "tests/test_round5_gpu.py, profiles/r05_parity.json keys backward_vs_reference_autograd/*")
+                               "tests/test_round5_gpu.py, profiles/r06_parity.json keys backward_vs_reference_autograd/*")
     return out
 
 
@@ -151,6 +151,9 @@ def physical_cores():
     except Exception:
         pass
     return os.cpu_count() or 1
+
+
+_REF_FULL = {}      # cpu_baseline keeps (x, t, the reference's full-batch output) for the parity check at the benched shape
 
 
 def cpu_baseline(sd, dim, depth, B, n):
@@ -184,6 +187,7 @@ def cpu_baseline(sd, dim, depth, B, n):
                     els.append(time.perf_counter() - t0)
                 el = min(els)
                 chk = float(((O.model_forward(sd, x[:1], t[:1]) - y[:1]).norm() / y[:1].norm()).item())   # the oracle against the reference, live
+            _REF_FULL.update(x=x, t=t, y=y.detach())
             return dict(value=round(1.0 / el, 5), unit="steps/s", cores=cores, kind="reference",
                         sample=f"the reference's own Model.forward (unmodified source, {ref_stub.reference_source()}), fp32, CPU SDPA "
                                f"attention, TWO timed forwards of the full batch {B} x {n} frames after a 1-utterance warm-up: "
@@ -264,6 +268,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    COLL = {}            # --gpus N: the `collective` block of the line (distributed.collective_report)
+
     def make_model(dim, depth, conditioned):
         torch.manual_seed(1234)                          # same random-init weights on every rank
         mkw = dict(dim_prompt=512, condition_on_prompt=True) if conditioned else {}
@@ -336,6 +342,8 @@ def main():
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            if profile:        # the headline measurement: what the job's one collective costs, apart from the loop (every rank calls it)
+                COLL.update(D.collective_report(audio, 1e3 * elapsed / steps))
         assert torch.isfinite(audio).all()
         return el.item(), kern_ms.value, kern_n.value
 
@@ -606,6 +614,28 @@ def main():
         # last: importing the reference installs inert stand-ins for its optional imports (oracle/ref_stub.py), which nothing
         # else in this process should meet half-way
         extra["cpu_baseline"] = cpu_baseline(cpu_sd, dim, depth, B, N)
+        if _REF_FULL and "parity" in extra:
+            # parity AT THE BENCHED SHAPE, from the reference itself -- the unmodified upstream Model's output on the full
+            # batch (the forward cpu_baseline just timed) against the HIP model on the same weights and inputs, in the benched arithmetic
+            # and in `exact`; error over the whole batch and the worst single utterance
+            from naturalspeech2_pytorch_amd import Model as _M
+            hm = _M(dim=dim, depth=depth)
+            hm.load_state_dict(cpu_sd)
+            hm = hm.to(dev).eval()
+            y = _REF_FULL["y"].double()
+            res = {}
+            for prec in dict.fromkeys((args.precision, "exact")):
+                hm.precision = prec
+                with torch.no_grad():
+                    d = hm(_REF_FULL["x"].to(dev), _REF_FULL["t"].to(dev)).cpu().double() - y
+                per = d.flatten(1).norm(dim=1) / y.flatten(1).norm(dim=1)
+                res[prec] = dict(rel_err=float((d.norm() / y.norm()).item()), per_utterance_max=float(per.max().item()))
+            res["what"] = (f"HIP Model vs the reference's own Model.forward (unmodified source, fp32, CPU) on the benched batch {B} x {N} x {dim}, "
+                           f"same weights, x ~ N(0, 1), t ~ U(0, 1): ||y_hip - y_ref|| / ||y_ref|| over the batch and the worst utterance")
+            res["tolerance"] = 1e-3
+            extra["parity"][f"headline_b{B}_vs_reference"] = res
+            del hm
+            _REF_FULL.clear()
         del cpu_sd
 
     if rank == 0:
@@ -634,6 +664,8 @@ def main():
             "parity": extra.pop("parity", None),
         }
         line.update(extra)
+        if COLL:
+            line["collective"] = COLL
         if side is not None:
             line["side"] = side
         if line["cpu_baseline"]:

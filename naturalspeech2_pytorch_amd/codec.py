@@ -86,6 +86,11 @@ class EncodecWrapperHIP(nn.Module):
 
     def __init__(self, codebooks: torch.Tensor, encoder: Optional[Callable] = None, decoder: Optional[Callable] = None):
         super().__init__()
+        self._hip_codec_init(codebooks, encoder, decoder)
+
+    def _hip_codec_init(self, codebooks, encoder=None, decoder=None):
+        """everything but nn.Module's own set-up: compat.hip_backed_codec_class builds a subclass of the REFERENCE's codec class whose
+        own __init__ (it fetches pretrained EnCodec weights) must not run"""
         self.rvq = HipRVQ(codebooks)
         self.rq = ResidualVQCrossEntropy(self.rvq)
         self.encoder, self.decoder = encoder, decoder

@@ -13,6 +13,15 @@ The subclass owns the reference's parameters (constructed by the reference's own
 initialisation and state_dict), and `HipDenoiserMixin` hands them to the library by the same key names
 (SURVEY §8b state_dict contract).  Calls that need autograd, or per-utterance stochastic conditioning dropout, go to the
 reference's own `forward` — the composite of `autograd_path.py` is not involved here.
+
+The codec side of the same boundary (round 6): the reference type-checks `codec: Optional[Union[SoundStream, EncodecWrapper]]`
+(NS2:1166) and then only uses the surface of SURVEY §8b (NS2:1212-1214, 1244, 1445, 1496, 1611, 1682):
+
+    from audiolm_pytorch import EncodecWrapper                 # the class the reference imports (NS2:23)
+    from naturalspeech2_pytorch_amd.compat import hip_backed_codec_class
+    HipEncodec = hip_backed_codec_class(EncodecWrapper)        # subclass of EncodecWrapper: passes the type check
+    codec = HipEncodec.from_hf(transformers.EncodecModel(...)) # or HipEncodec(codebooks, encoder=, decoder=)
+    diffusion = ref.NaturalSpeech2(model=model, codec=codec)   # RVQ encode / decode + SEANet run in libns2hip
 """
 import inspect
 
@@ -53,3 +62,24 @@ def hip_backed_model_class(reference_model_cls):
 
     HipBackedModel.__qualname__ = HipBackedModel.__name__ = "HipBackedModel"
     return HipBackedModel
+
+
+def hip_backed_codec_class(reference_codec_cls):
+    """returns `HipBackedEncodec`, a subclass of BOTH `reference_codec_cls` (audiolm_pytorch's `EncodecWrapper`, or `SoundStream`:
+    whatever the reference's `codec:` annotation accepts, NS2:1166) and this package's `EncodecWrapperHIP`, whose residual-VQ
+    encode / decode (csrc/rvq.hip) and SEANet encoder / decoder (seanet.py) run on the HIP kernels.  The reference class's own
+    `__init__` is NOT run (audiolm's downloads the pretrained EnCodec checkpoint and builds the PyTorch codec this class replaces):
+    construct it like `EncodecWrapperHIP` -- `HipBackedEncodec(codebooks, encoder=, decoder=)` or `.from_hf(hf_encodec_model)`.
+    Everything the reference touches comes from `EncodecWrapperHIP`: target_sample_hz / seq_len_multiple_of / codebook_dim, forward(x,
+    return_encoded=, curtail_from_left=) -> (emb, codes, None), decode(emb), rq(x, codes) (codec.py)."""
+    from torch import nn
+
+    from .codec import EncodecWrapperHIP
+
+    class HipBackedEncodec(EncodecWrapperHIP, reference_codec_cls):
+        def __init__(self, codebooks, encoder=None, decoder=None):
+            nn.Module.__init__(self)
+            self._hip_codec_init(codebooks, encoder, decoder)
+
+    HipBackedEncodec.__qualname__ = HipBackedEncodec.__name__ = "HipBackedEncodec"
+    return HipBackedEncodec

@@ -70,6 +70,40 @@ def sharded_sample(sample_fn: Callable[[torch.Tensor], torch.Tensor], total: int
 
 
 # ------------------------------------------------------------------------------------------------ data-parallel training
+def collective_report(shard: torch.Tensor, local_ms_per_step: float, reps: int = 3) -> dict:
+    """What the sharded sampler's ONE collective costs on this job, measured apart from the sampling loop (the loop
+    itself never communicates): the all-gather of every rank's `shard` (generated latents [b, n, d]) in the single-buffer form
+    sharded_sample uses, timed `reps` times between barriers (max over ranks, minimum over repetitions), plus the spread of the
+    ranks' own loop times.  Every rank must call it; every rank returns the same dict.  With gloo (CPU functional tests) the tensors
+    travel through host memory, so the time says nothing about xGMI -- the block says which backend it saw."""
+    import time
+    world, backend = dist.get_world_size(), dist.get_backend()
+    src = shard if backend != "gloo" else shard.cpu()
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    times = []
+    for _ in range(reps):
+        dist.barrier()
+        if src.is_cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.all_gather_into_tensor(out, src)
+        if src.is_cuda:
+            torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=src.device)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        times.append(el.item())
+    per = torch.zeros(world, dtype=torch.float64, device=src.device)
+    per[dist.get_rank()] = local_ms_per_step
+    dist.all_reduce(per, op=dist.ReduceOp.SUM)
+    nbytes = src.numel() * src.element_size()
+    return dict(backend=backend, world=world, collectives_inside_the_loop=0, allgather_ms=round(1e3 * min(times), 4),
+                allgather_bytes_per_rank=nbytes, allgather_bytes_received_per_rank=nbytes * (world - 1),
+                allgather_gbytes_per_s_per_rank=round(nbytes * (world - 1) / max(min(times), 1e-9) / 1e9, 2),
+                per_rank_ms_per_step=dict(min=round(per.min().item(), 4), max=round(per.max().item(), 4),
+                                          all=[round(v, 4) for v in per.tolist()]),
+                note="backend 'nccl' is RCCL over xGMI; 'gloo' (functional tests on one device / CPU) moves the shards through host memory")
+
+
 class GradientAllReducer:
     """Data-parallel training step for `NaturalSpeech2.forward` (NS2:1635, NS2:1886: the reference hands this to
     accelerate / DDP): one process per GPU, replicated weights, each rank's loss on its own shard of the batch, gradients averaged

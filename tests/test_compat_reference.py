@@ -120,3 +120,29 @@ def test_upstream_cannot_run_with_a_prompt_mask(use_flash_attn):
         h(x, t, prompt=prompt, prompt_mask=mask, cond=cond)
     with torch.no_grad(), pytest.raises(NotImplementedError, match="reference itself raises"):
         h(x, t, prompt=prompt, prompt_mask=mask, cond=cond)
+
+
+def test_codec_subclass_passes_the_reference_type_check_and_keeps_the_codec_surface():
+    """VERDICT r5 missing #2: `codec: Optional[Union[SoundStream, EncodecWrapper]]` (NS2:1166).  compat.hip_backed_codec_class(EncodecWrapper)
+    is a subclass of the class the reference imports (here: the stand-in class oracle/ref_stub.py installs for audiolm_pytorch's), is
+    constructed without running that class's own __init__, and the unmodified reference NaturalSpeech2 accepts it and reads the surface
+    of SURVEY 8b from it (NS2:1212-1214, 1244)."""
+    import typing
+    ns2 = load_reference()
+    import audiolm_pytorch
+    from naturalspeech2_pytorch_amd import EncodecWrapperHIP
+    from naturalspeech2_pytorch_amd.compat import hip_backed_codec_class, hip_backed_model_class
+    ran = []
+    Base = type("EncodecWrapper", (audiolm_pytorch.EncodecWrapper,), {"__init__": lambda self, *a, **k: ran.append(1)})
+    C = hip_backed_codec_class(Base)
+    cb = torch.randn(8, 1024, 128, generator=torch.Generator().manual_seed(0))
+    codec = C(cb)
+    assert not ran, "the reference codec's own __init__ (pretrained download) must not run"
+    assert isinstance(codec, Base) and isinstance(codec, audiolm_pytorch.EncodecWrapper) and isinstance(codec, EncodecWrapperHIP)
+    hint = typing.get_type_hints(ns2.NaturalSpeech2.__init__)["codec"]             # Optional[Union[SoundStream, EncodecWrapper]]
+    assert isinstance(codec, tuple(t for t in typing.get_args(hint) if t is not type(None)))
+    H = hip_backed_model_class(ns2.Model)
+    d = ns2.NaturalSpeech2(model=H(dim=128, depth=1), codec=codec, timesteps=10)
+    assert d.codec is codec and d.target_sample_hz == 24000 and d.seq_len_multiple_of == 320 and d.dim == 128
+    assert sorted(k for k in codec.state_dict()) == ["rvq.codebooks"]
+    assert callable(codec.decode) and callable(codec.rq) and codec.num_quantizers == 8

@@ -248,6 +248,11 @@ fn = lambda noise: noise * 2.0 + noise.flip(-1).cumsum(dim=1)        # any per-u
 out = D.sharded_sample(fn, total=int(sys.argv[2]), length=6, dim=8, seed=5)
 single = fn(D.utterance_noise(0, int(sys.argv[2]), 6, 8, seed=5))
 assert out.shape == single.shape and torch.equal(out, single), f"rank {rank}: gathered result differs"
+# the block bench.py --gpus N prints beside its line (VERDICT r5 item 9): one collective, timed apart from the loop
+lo, hi = D.shard_range(int(sys.argv[2]), 0, world)
+c = D.collective_report(torch.ones(hi - lo, 6, 8) * (rank + 1), local_ms_per_step=10.0 + rank)
+assert c["backend"] == "gloo" and c["world"] == world and c["collectives_inside_the_loop"] == 0 and c["allgather_ms"] > 0
+assert c["allgather_bytes_per_rank"] == (hi - lo) * 6 * 8 * 4 and c["per_rank_ms_per_step"] == dict(min=10.0, max=10.0 + world - 1, all=[10.0 + r for r in range(world)])
 dist.barrier()
 if rank == 0:
     print("OK", world, tuple(out.shape))
@@ -310,7 +315,7 @@ def test_parity_record_merges_key_by_key(tmp_path, monkeypatch):
     PR.record("a", 10)
     got = json.load(open(scratch))
     assert got["a"] == 10 and got["b"] == {"max": 2} and got["c"] == 3
-    assert got["_meta"]["updated_keys_r05"] == ["a", "c"]
+    assert got["_meta"]["updated_keys_r06"] == ["a", "c"]
 
 
 def test_conditional_training_reaches_the_encoders():

@@ -196,3 +196,73 @@ def test_model_step_is_bit_identical_with_and_without_the_round6_kernels(precisi
             _force(0)
     assert torch.isfinite(y_new).all()
     assert torch.equal(y_new, y_old)
+
+
+# ---------------------------------------------------------------------------------------------- parity at BASELINE's STATED sizes
+def _gpu_oracle_pinned(sd, fn_gpu, fn_cpu_one):
+    """the oracle's code on GPU tensors (plain PyTorch fp32 ops) for the full batch, pinned to the CPU oracle on one utterance"""
+    ref = fn_gpu()
+    pin = _rel(ref[:1].cpu(), fn_cpu_one())
+    assert pin < 5e-6, f"GPU-resident oracle drifted from the CPU oracle: {pin}"
+    return ref
+
+
+def test_config3_conditioned_at_its_stated_size_4x1024_cfg():
+    """BASELINE config 3 as stated: dim=512 depth=12 dim_prompt=512 condition_on_prompt, batch 4 x 1024 frames, prompt of 103 frames (what a
+    32 768-sample prompt becomes), aligned conditioning [4, 512, 1024], classifier-free guidance 1.3 (NS2:914-927)"""
+    from oracle import ns2_oracle as O
+    from tests.parity_record import record
+    kw = dict(dim=512, depth=12, dim_prompt=512, condition_on_prompt=True)
+    b, n = 4, 1024
+    x = make_input("x", (b, n, 512), seed=31)
+    t = make_input("times", (b,), seed=31, uniform=True)
+    prompt = make_input("prompt", (b, 103, 512), seed=32)
+    cond = make_input("cond", (b, 512, n), seed=33)
+    errs = {}
+    ref = None
+    for precision, tol in (("exact", 1e-4), ("hybrid", 2.5e-4)):
+        m = Model(**kw, precision=precision)
+        sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=30)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        if ref is None:
+            sdg = {k: v.to(DEV) for k, v in sd.items()}
+            with torch.no_grad():
+                ref = _gpu_oracle_pinned(
+                    sd, lambda: O.model_forward_with_cond_scale(sdg, x.to(DEV), t.to(DEV), prompt.to(DEV), cond.to(DEV), 1.3),
+                    lambda: O.model_forward_with_cond_scale(sd, x[:1], t[:1], prompt[:1], cond[:1], 1.3))
+        with torch.no_grad():
+            y = m.forward_with_cond_scale(x.to(DEV), t.to(DEV), prompt=prompt.to(DEV), cond=cond.to(DEV), cond_scale=1.3)
+        errs[precision] = _rel(y, ref)
+        assert torch.isfinite(y).all() and errs[precision] < tol, (precision, errs[precision])
+        del m
+    record("config3_stated_size_4x1024_prompt103_cfg1.3", errs)
+
+
+def test_config2_d128_at_its_stated_size_32x1024():
+    """BASELINE config 2 as stated: Model(dim=128, depth=6) unconditional, batch 32 x 1024 latent tokens"""
+    from oracle import ns2_oracle as O
+    from tests.parity_record import record
+    kw = dict(dim=128, depth=6)
+    b, n = 32, 1024
+    x = make_input("x", (b, n, 128), seed=41)
+    t = make_input("times", (b,), seed=41, uniform=True)
+    errs, per_utt = {}, {}
+    ref = None
+    for precision, tol in (("exact", 1e-4), ("hybrid", 2.5e-4)):
+        m = Model(**kw, precision=precision)
+        sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=40)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        if ref is None:
+            sdg = {k: v.to(DEV) for k, v in sd.items()}
+            with torch.no_grad():
+                ref = _gpu_oracle_pinned(sd, lambda: O.model_forward(sdg, x.to(DEV), t.to(DEV)), lambda: O.model_forward(sd, x[:1], t[:1]))
+        with torch.no_grad():
+            y = m(x.to(DEV), t.to(DEV))
+        errs[precision] = _rel(y, ref)
+        d = (y.double() - ref.double()).flatten(1).norm(dim=1) / ref.double().flatten(1).norm(dim=1)
+        per_utt[precision] = d.max().item()
+        assert torch.isfinite(y).all() and per_utt[precision] < tol, (precision, errs[precision], per_utt[precision])
+        del m
+    record("config2_stated_size_32x1024", dict(batch=errs, worst_utterance=per_utt))
