@@ -165,6 +165,7 @@ class _PackedCache:
             self.map[key] = (hit[0], sig, hit[2], (w, extra), refs, self.pass_id, parts)  # keep the sources alive until the stream has consumed them
             return hit[0]
         pw = ops.PackedWeight(w, extra1x1=extra, precision=self.precision, **pack_kw)
+        self._table = None                   # (a hit whose source changed shape gets a NEW pack: the re-pack table still names the old one's storage)
         self.map[key] = (pw, sig, (tuple(w.shape), None if extra is None else tuple(extra.shape)), (w, extra), refs, self.pass_id, parts)
         return pw
 
@@ -446,12 +447,43 @@ class _Scale:
     becomes 2^5 ... 2^6, which leaves 2^10 of head-room before 65504 for growth inside the graph and ~2^19 below for small values.
     Token-sized gradients stay scaled between the Functions; whatever leaves the scaled domain -- parameter gradients, FiLM /
     adaptive-norm conditioning gradients, x.grad -- is multiplied by 1 / s (`unscale`).  Values that still leave the half range are
-    COUNTED by the converting kernels (ops.saturation_count): `overflowed()` tells a training loop to skip / repeat the step."""
+    COUNTED by the converting kernels: `overflowed()` (below) compares the device's range counters after the pass with their values
+    when the pass began and tells a training loop to skip / repeat the step -- the counterpart of GradScaler's inf check
+    (`model._last_loss_scale.overflowed()` after `loss.backward()`)."""
     TARGET = 64.0
 
     def __init__(self):
         self.s = None
         self.inv = None
+        self._before = self._peek()          # stream-ordered: the counters as they stand when the pass is enqueued
+
+    @staticmethod
+    def _peek():
+        """the five range counters of the device (ns2_saturation_peek_async: forward GEMMs / attention / pointwise;
+        ns2_saturation_peek_train_async: the training kernels), copied to pinned memory on the current stream -- no synchronisation"""
+        if not torch.cuda.is_available():
+            return None
+        try:
+            lib = _lib.load()
+        except Exception:
+            return None
+        buf = torch.zeros(5, dtype=torch.int32).pin_memory()
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.ns2_saturation_peek_async(buf.data_ptr(), s), "ns2_saturation_peek_async")
+        _lib.check(lib.ns2_saturation_peek_train_async(buf.data_ptr() + 16, s), "ns2_saturation_peek_train_async")
+        ev = torch.cuda.Event()
+        ev.record()
+        return buf, ev
+
+    def overflowed(self) -> bool:
+        """did a conversion of this pass (forward activations, scaled gradients) leave the IEEE-half range?  Call after `backward()`;
+        waits for the pass (one event synchronisation).  True: the gradients of this step are clamped somewhere -- skip the optimizer
+        step (and train on with `train_precision="exact"` if it keeps happening: bf16 planes have the fp32 range)."""
+        if self._before is None:
+            return False
+        after, ev = self._peek()
+        ev.synchronize()
+        return bool((after != self._before[0]).any().item())
 
     def choose(self, g):
         amax = g.detach().abs().amax().clamp_min(1e-30).float()
@@ -947,10 +979,12 @@ def _forward_train(m, x, times, prompt, cond, cond_drop_prob):
         pc = F.silu(_lin(getattr(m.to_prompt_cond, "1"), prompt.float().mean(dim=1)))
         pc = torch.where(dm[:, None], m.null_prompt_cond, pc)
         t = torch.cat((t, pc), dim=-1)
-        c = torch.where(dm[:, None, None], _enter(m.null_prompt_tokens), _resampler(m.perceiver_resampler, prompt.float(), heads))   # [b, Lm, d]
+        # (`prompt` and `cond` come from trainable modules upstream -- the prompt / phoneme encoders, NS2:1635 -- so their gradients
+        # leave the scaled domain like x's: ADVICE r5)
+        c = torch.where(dm[:, None, None], _enter(m.null_prompt_tokens), _resampler(m.perceiver_resampler, _enter(prompt.float()), heads))   # [b, Lm, d]
         # cond_to_model_dim: 1x1 conv over channel-first cond (NS2:978) = a Linear over the frames
         n_c = cond.shape[-1]
-        cm = GemmFn.apply(_c(cond.float().transpose(1, 2)).reshape(b * n_c, -1), m.cond_to_model_dim.weight, m.cond_to_model_dim.bias, None,
+        cm = GemmFn.apply(_enter(_c(cond.float().transpose(1, 2)).reshape(b * n_c, -1)), m.cond_to_model_dim.weight, m.cond_to_model_dim.bias, None,
                           n_c, 1)
         cm = cm.reshape(b, n_c, d)
         cm = torch.where(mask()[:, None, None], _enter(m.null_cond).t()[None], cm)

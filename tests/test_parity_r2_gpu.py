@@ -85,59 +85,70 @@ def test_mixed_mode_matches_reference_golden(path, precision):
     assert 1e-7 < worst < CEIL[precision], f"{precision}-mode rel {worst}"
 
 
-@pytest.mark.parametrize("precision", ["hybrid", "mixed", "half"])
-def test_precision_sweep_headline_architecture(precision):
+def test_precision_sweep_headline_architecture():
     """d512/L12 x 1024 frames: 8 weight seeds x diffusion times {0.002, 0.5, 0.999} (one utterance each), per-utterance error
-    against the fp32 oracle; the MAX over the sweep is what is asserted and what bench.py quotes."""
+    against the fp32 oracle; the MAX over the sweep is what is asserted and what bench.py quotes.  Round 6: one model per seed serves
+    the three arithmetics (`model.precision = ...` re-packs the same parameters) and the oracle runs on GPU tensors, pinned to the CPU
+    oracle on the first seed -- the sweep took 207 s of the suite's 733 s."""
     kw = dict(dim=512, depth=12)
     times = torch.tensor([0.002, 0.5, 0.999])
-    errs = []
+    errs = {p: [] for p in ("hybrid", "mixed", "half")}
     for seed in range(8):
-        m, sd = build(kw, seed=100 + seed, precision=precision)
+        m, sd = build(kw, seed=100 + seed, precision="hybrid")
         x = make_input("x", (3, 1024, 512), seed=200 + seed)
         with torch.no_grad():
-            y = m(x.to(DEV), times.to(DEV))
-            if seed not in _SWEEP_REF:
-                _SWEEP_REF[seed] = O.model_forward(sd, x, times)
-            ref = _SWEEP_REF[seed]
-        assert torch.isfinite(y).all()
-        errs.append(rel_rows(y, ref))
-        del m
+            ref = O.model_forward({k: v.to(DEV) for k, v in sd.items()}, x.to(DEV), times.to(DEV))
+            if seed == 0:
+                pin = rel(ref[:1], O.model_forward(sd, x[:1], times[:1]))
+                assert pin < 5e-6, f"GPU-resident oracle drifted from the CPU oracle: {pin}"
+            for precision in errs:
+                m.precision = precision
+                y = m(x.to(DEV), times.to(DEV))
+                assert torch.isfinite(y).all()
+                errs[precision].append(rel_rows(y, ref))
+        del m, ref
         torch.cuda.empty_cache()
-    flat = [e for row in errs for e in row]
-    record(f"sweep_d512_L12/{precision}", dict(max=max(flat), mean=sum(flat) / len(flat), per_seed_per_time=errs,
-                                               times=times.tolist(), seeds=8))
-    print(f"{precision}: max {max(flat):.2e} mean {sum(flat) / len(flat):.2e} over 8 seeds x 3 times")
-    assert max(flat) < CEIL[precision], f"{precision}: max rel err over the sweep {max(flat)}"
+    for precision, e in errs.items():
+        flat = [v for row in e for v in row]
+        record(f"sweep_d512_L12/{precision}", dict(max=max(flat), mean=sum(flat) / len(flat), per_seed_per_time=e,
+                                                   times=times.tolist(), seeds=8))
+        print(f"{precision}: max {max(flat):.2e} mean {sum(flat) / len(flat):.2e} over 8 seeds x 3 times")
+    for precision, e in errs.items():
+        assert max(v for row in e for v in row) < CEIL[precision], f"{precision}: max rel err over the sweep {max(v for row in e for v in row)}"
 
 
 _COND_REF = {}
 
 
-@pytest.mark.parametrize("precision", ["hybrid", "mixed", "half"])
-def test_conditioned_cfg_d512(precision):
+def test_conditioned_cfg_d512():
     """BASELINE config 3 architecture with classifier-free guidance (two forwards mixed at cond_scale 1.3, NS2:914-927),
-    three weight / input seeds; the maximum is recorded and asserted."""
+    three weight / input seeds, three arithmetics on the same model object; the maximum is recorded and asserted."""
     kw = dict(dim=512, depth=12, dim_prompt=512, condition_on_prompt=True)
     b, n = 2, 512
-    errs = []
+    errs = {p: [] for p in ("hybrid", "mixed", "half")}
     for seed in (9, 19, 29):
-        m, sd = build(kw, seed=seed, precision=precision)
+        m, sd = build(kw, seed=seed, precision="hybrid")
         x = make_input("x", (b, n, 512), seed=seed + 1)
         t = make_input("times", (b,), seed=seed + 1, uniform=True)
         prompt = make_input("prompt", (b, 103, 512), seed=seed + 1)
         cond = make_input("cond", (b, 512, n), seed=seed + 1)
         with torch.no_grad():
-            y = m.forward_with_cond_scale(x.to(DEV), t.to(DEV), prompt=prompt.to(DEV), cond=cond.to(DEV), cond_scale=1.3)
-            if seed not in _COND_REF:
-                _COND_REF[seed] = O.model_forward_with_cond_scale(sd, x, t, prompt, cond, 1.3)
-        assert torch.isfinite(y).all()
-        errs.append(rel(y, _COND_REF[seed]))
-        del m
+            ref = O.model_forward_with_cond_scale({k: v.to(DEV) for k, v in sd.items()}, x.to(DEV), t.to(DEV), prompt.to(DEV), cond.to(DEV), 1.3)
+            if seed == 9:
+                pin = rel(ref[:1], O.model_forward_with_cond_scale(sd, x[:1], t[:1], prompt[:1], cond[:1], 1.3))
+                assert pin < 5e-6, f"GPU-resident oracle drifted from the CPU oracle: {pin}"
+            for precision in errs:
+                m.precision = precision
+                y = m.forward_with_cond_scale(x.to(DEV), t.to(DEV), prompt=prompt.to(DEV), cond=cond.to(DEV), cond_scale=1.3)
+                assert torch.isfinite(y).all()
+                errs[precision].append(rel(y, ref))
+        del m, ref
         torch.cuda.empty_cache()
-    record(f"conditioned_cfg_d512/{precision}", max(errs))
-    record(f"conditioned_cfg_d512_per_seed/{precision}", errs)
-    assert max(errs) < CEIL[precision], f"{precision}: rel {errs}"
+    for precision, e in errs.items():
+        record(f"conditioned_cfg_d512/{precision}", max(e))
+        record(f"conditioned_cfg_d512_per_seed/{precision}", e)
+    for precision, e in errs.items():
+        assert max(e) < CEIL[precision], f"{precision}: rel {e}"
 
 
 def test_ddim_trajectory_50_steps():

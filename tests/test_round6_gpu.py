@@ -266,3 +266,44 @@ def test_config2_d128_at_its_stated_size_32x1024():
         assert torch.isfinite(y).all() and per_utt[precision] < tol, (precision, errs[precision], per_utt[precision])
         del m
     record("config2_stated_size_32x1024", dict(batch=errs, worst_utterance=per_utt))
+
+
+# ---------------------------------------------------------------------------------------------- mixed training, external conditioning inputs
+def test_mixed_training_unscales_the_gradients_of_cond_and_prompt_and_reports_overflow():
+    """train_precision="mixed" runs its backward on loss-scaled gradients (training._Scale).  `prompt` and `cond` come from trainable
+    modules upstream (SpeechPromptEncoder, the phoneme / pitch encoders: NS2:1635), so their gradients must leave the scaled domain
+    like x's -- round 5 returned them 2^27 times too large.  Conditioned d128 / L2 on the MI355X: every gradient incl. d/dprompt and
+    d/dcond of the mixed arithmetic against the exact one; `_Scale.overflowed()` is False on a sane pass and True once a conversion
+    left the IEEE-half range (activations x 1e6)."""
+    kw = dict(dim=128, depth=2, dim_prompt=96, condition_on_prompt=True, cond_drop_prob=0.)
+    m = Model(**kw, precision="hybrid")
+    m.load_state_dict(make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=61))
+    m = m.to(DEV).train()
+    b, n = 2, 256
+    x = make_input("x", (b, n, 128), seed=62).to(DEV)
+    t = make_input("times", (b,), seed=62, uniform=True).to(DEV)
+    prompt = make_input("prompt", (b, 37, 96), seed=63).to(DEV)
+    cond = make_input("cond", (b, 96, n), seed=64).to(DEV)
+
+    def grads(tp, xs=1.0):
+        m.train_precision = tp
+        for p in m.parameters():
+            p.grad = None
+        xx, pp, cc = (v.clone().requires_grad_(True) for v in (x * xs, prompt, cond))
+        y = m(xx, t, prompt=pp, cond=cc)
+        (y * make_input("gw", tuple(y.shape), seed=65).to(DEV) * 1e-7).sum().backward()
+        torch.cuda.synchronize()
+        return dict(x=xx.grad.clone(), prompt=pp.grad.clone(), cond=cc.grad.clone())
+
+    try:
+        g0 = grads("exact")
+        g1 = grads("mixed")
+        sc = m._last_loss_scale
+        assert sc is not None and float(sc.s) >= 2.0 ** 16 and not sc.overflowed()
+        for k in g0:
+            assert torch.isfinite(g1[k]).all() and _rel(g1[k], g0[k]) < 1e-3, (k, _rel(g1[k], g0[k]))
+        grads("mixed", xs=1e6)                            # activations far outside the half range: the forward's conversions clamp
+        assert m._last_loss_scale.overflowed()
+    finally:
+        m.train_precision = "exact"
+        ops.saturation_count(reset=True)

@@ -251,9 +251,14 @@ def test_mixed_training_arithmetic_needs_and_gets_its_loss_scale(cond):
         for p in m.parameters():
             p.grad = None
         xx = x.clone().requires_grad_(True)
-        y = fwd(m, xx, t, **extra)
+        # the external conditioning inputs come from trainable modules upstream (prompt / phoneme encoders, NS2:1635): their gradients
+        # must leave the scaled domain too (they came out 2^27 times too large)
+        ex = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) else v) for k, v in extra.items()}
+        y = fwd(m, xx, t, **ex)
         (y * make_input("gw", tuple(y.shape), seed=11) * 1e-7).sum().backward()          # the magnitude of dL/dy of a mean-reduced loss
-        return xx.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        g = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        g.update({f"<input {k}>": v.grad.clone() for k, v in ex.items() if torch.is_tensor(v)})
+        return xx.grad.clone(), g
 
     dx0, g0 = grads(model_forward_autograd)
     prev = training.set_backend(MixedEmuBackend())

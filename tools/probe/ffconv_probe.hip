@@ -22,6 +22,47 @@ using namespace ns2;
 
 namespace ffc {
 
+// epi_planes_fast<PF_H8, true> (gemm_epi_fast.h) with switches, to see where the FMT_H8 epilogue's time goes: CVT = the three-part
+// conversion + LDS staging (else: the raw accumulator bits are staged), STORE = the 16-byte global stores
+template <bool CVT, bool STORE>
+NS2_DEVINL void epi_h8_variant(f32x16 (&acc)[4][2], const GemmArgs& g, int row_base, int col_base, int lane, unsigned char* wbuf) {
+  constexpr int ROWB = 256, RS = ROWB + 16, RPP = 64;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const bool odd = lane & 1;
+  float bc[2] = {g.bias[col_base + l31], g.bias[col_base + 32 + l31]};
+  const long rsb = pld(g.ldo_s, true) * 2;
+  unsigned char* gbase = reinterpret_cast<unsigned char*>(g.out_hi) + (long)row_base * rsb + (long)(col_base >> 5) * 128;
+  RangeTrack rt;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+      const int mi = pass * 2 + mh;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+          const float v0 = acc[mi][ni][2 * rp] + bc[ni], v1 = acc[mi][ni][2 * rp + 1] + bc[ni];
+          const int r = 2 * rp + (odd ? 1 : 0);
+          const int lr = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if constexpr (CVT) {
+            const float recv = lane_xor1(odd ? v0 : v1);
+            const float c_lo = odd ? recv : v0, c_hi = odd ? v1 : recv;
+            lds_put2<PF_H8>(wbuf + lr * RS, ni * 32 + (l31 & ~1), c_lo, c_hi, rt);
+          } else {
+            *reinterpret_cast<float*>(wbuf + lr * RS + (ni * 32 + l31) * 4) = v0 + v1;
+          }
+          if ((rp & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (STORE) lds_flush_rows<ROWB, RPP>(wbuf, gbase + (long)pass * RPP * rsb, rsb, lane);
+    else { const uint4 v = *reinterpret_cast<const uint4*>(wbuf + lane * 16); if (v.x == 0x12345678u) *reinterpret_cast<uint4*>(gbase) = v; }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if constexpr (CVT) rt.flush(H8_MAX);
+}
+
 constexpr int RB = 128;                       // LDS row bytes = 64 halves = one K tile of one row
 constexpr int A_ROWS = 264;                   // A'(it): input rows m0 - 8 ... m0 + 255 (33 pieces of 8 rows)
 constexpr int A_BUF = A_ROWS * RB;            // 33792
@@ -350,7 +391,12 @@ struct Kern {
       ga.M = g.M; ga.N = g.N; ga.bias = g.bias; ga.out_hi = reinterpret_cast<bf16_t*>(g.out); ga.out_lo = ga.out_hi + 32;
       ga.ldo_s = g.ldo; ga.out_ncols = g.ldo; ga.out_fmt = FMT_H8; ga.epi = EPI_SPLIT;
       unsigned char* const wbuf = smem + wave * EPI_LDS_WAVE_BYTES;
-      if (col_base + 64 <= g.N) epi_planes_fast<PF_H8, true>(c.acc, ga, 0, row_base, col_base, lane, wbuf);
+      if (col_base + 64 <= g.N) {
+        if constexpr (EPI == 0) epi_planes_fast<PF_H8, true>(c.acc, ga, 0, row_base, col_base, lane, wbuf);
+        else if constexpr (EPI == 3) epi_h8_variant<true, false>(c.acc, ga, row_base, col_base, lane, wbuf);
+        else if constexpr (EPI == 4) epi_h8_variant<false, true>(c.acc, ga, row_base, col_base, lane, wbuf);
+        else epi_h8_variant<true, true>(c.acc, ga, row_base, col_base, lane, wbuf);
+      }
       else gemm_epilogue<EPI_SPLIT, 4, 2>(c.acc, ga, 0, row_base, col_base, 0, lane);
     }
   }
@@ -499,6 +545,9 @@ int main(int argc, char** argv) {
     {"S2 noDMA (reads+MFMA+barriers)", ffc::ffc_kernel<1, 2, 2, 2>},
     {"S2 noREADS (DMA+MFMA+barriers)", ffc::ffc_kernel<1, 3, 2, 2>},
     {"S2 MFMA+barriers", ffc::ffc_kernel<1, 4, 2, 2>},
+    {"S4 epilogue: convert, no stores", ffc::ffc_kernel<1, 0, 3, 4>},
+    {"S4 epilogue: stores, no conversion", ffc::ffc_kernel<1, 0, 4, 4>},
+    {"S4 epilogue: local copy (cvt+store)", ffc::ffc_kernel<1, 0, 5, 4>},
     {"S4 h8 A nt  W nt", ffc::ffc_kernel<1, 0, 0, 4, 1, 1>},
     {"S4 h8 A sc1 W sc1", ffc::ffc_kernel<1, 0, 0, 4, 2, 2>},
     {"S4 h8 A sc0sc1 W sc0sc1", ffc::ffc_kernel<1, 0, 0, 4, 3, 3>},
