@@ -112,6 +112,10 @@ int ns2_conv3_input_ld(int cols);
  * ns2_weight_tile_linear builds them for a weight packed with taps = 1 at precision 4 (also with geglu = 1); ns2_linear_f32 / _split /
  * _split_as / _qkv / _geglu then take the kernel when M % 256 == 0 and K >= 96.  Same life-cycle rules as ns2_weight_tile_conv3. */
 int ns2_weight_tile_linear(ns2_weight* w, void* stream);
+/* ... and so has the WavenetResBlock of the hybrid plan (csrc/wavenet3_kernel.h; NS2:597-642): ns2_weight_tile_wavenet builds the tiled
+ * images of a weight packed with taps = 3 and extra1x1 at precision 4 (square, channels % 256 == 0); ns2_wavenet_block at precision 5
+ * then takes the lean kernel when M % 256 == 0, seq_len % 256 == 0 and dilation <= 128.  Bit-identical to the general kernel. */
+int ns2_weight_tile_wavenet(ns2_weight* w, void* stream);
 /* same, with the output planes in the format of ANOTHER precision (out_precision 3: bf16 hi / lo lines from a precision-4 product --
  * the q | k | v projection of the mixed training arithmetic, whose attention stays bf16 x3) */
 int ns2_linear_split_as(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* a_lo, int lda, int M, int conv_taps,

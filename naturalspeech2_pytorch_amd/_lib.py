@@ -111,6 +111,7 @@ SIGNATURES = {
     "ns2_weight_update": (I, [P, P, P, P]),
     "ns2_weight_tile_conv3": (I, [P, P]),
     "ns2_weight_tile_linear": (I, [P, P]),
+    "ns2_weight_tile_wavenet": (I, [P, P]),
     "ns2_conv3_input_ld": (I, [I]),
     "ns2_saturation_peek_train_async": (I, [P, P]),
     "ns2_grad_prep_slices": (L, [I, L]),

@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 113; }   // 113: ns2_weight_tile_conv3 + ns2_conv3_input_ld (the dedicated FF causal conv kernel, ffconv_kernel.h), ns2_weight_tile_linear (gemm3_kernel.h), ns2_debug_force_gemm(4 / 5); 112: ns2_seanet_resblock_narrow; 111: training entry points take a precision (3 = bf16 x3, 4 = mixed on FMT_H8 lines), ns2_linear_split_as; 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 113; }   // 113: ns2_weight_tile_conv3 + ns2_conv3_input_ld (the dedicated FF causal conv kernel, ffconv_kernel.h), ns2_weight_tile_linear (gemm3_kernel.h), ns2_weight_tile_wavenet (wavenet3_kernel.h), ns2_debug_force_gemm(4 / 5); 112: ns2_seanet_resblock_narrow; 111: training entry points take a precision (3 = bf16 x3, 4 = mixed on FMT_H8 lines), ns2_linear_split_as; 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 5, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel, 3 = auto without split-K, 4 = auto without the dedicated FF-conv kernel, 5 = auto, the FF-conv kernel whenever eligible");
   force_gemm_kernel(kernel);
@@ -91,6 +91,22 @@ extern "C" int ns2_weight_tile_conv3(ns2_weight* w, void* stream) {
 extern "C" int ns2_weight_tile_linear(ns2_weight* w, void* stream) {
   ARGCHK(w && w->taps == 1 && !w->has_extra && w->w.fmt == FMT_H8 && w->w.nkt >= 3, "ns2_weight_tile_linear: a linear weight (taps = 1, K >= 96) packed for precision 4");
   return build_lin_tiles(&w->owned, &w->w, (hipStream_t)stream);
+}
+// Give a WavenetResBlock weight (taps = 3 + the 1x1 res conv, packed for precision 4) the tiled images of the lean block kernel of the
+// hybrid plan (wavenet3_kernel.h): ns2_wavenet_block at precision 5 then takes that kernel when channels % 256 == 0 (square), M and
+// seq_len are multiples of 256 and dilation <= 128.  Same life-cycle rules as ns2_weight_tile_conv3.
+extern "C" int ns2_weight_tile_wavenet(ns2_weight* w, void* stream) {
+  ARGCHK(w && w->taps == 3 && w->has_extra && !w->geglu && w->w.fmt == FMT_H8 && (w->cols_p % 128) == 0 && w->w.N == w->cols_p && (w->w.N % 256) == 0,
+         "ns2_weight_tile_wavenet: a square WavenetResBlock weight (taps = 3, extra1x1) packed for precision 4, channels a multiple of 256");
+  PackedW& W = w->w;
+  if (!W.tw1) {
+    void *t1 = nullptr, *t2 = nullptr;
+    HIPRET(hipMalloc(&t1, wavenet3_tiles_bytes(W.rows_p, w->cols_p, 1, 1))); w->owned.push_back(t1);
+    HIPRET(hipMalloc(&t2, wavenet3_tiles_bytes(W.rows_p, w->cols_p, 1, 2))); w->owned.push_back(t2);
+    W.tw1 = static_cast<bf16_t*>(t1); W.tw2 = static_cast<bf16_t*>(t2);
+  }
+  HIPRET(wavenet3_build_tiles(W.hi, W.rows_p, w->cols_p, 1, W.tw1, W.tw2, (hipStream_t)stream));
+  return NS2_OK;
 }
 extern "C" int ns2_conv3_input_ld(int cols) { return cols > 0 ? ffconv3_lda((cols + 31) / 32 * 32) : 0; }
 extern "C" void ns2_weight_free(ns2_weight* w) {

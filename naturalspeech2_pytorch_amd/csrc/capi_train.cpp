@@ -36,6 +36,7 @@ extern "C" int ns2_weight_update(ns2_weight* w, const float* w_src, const float*
                               w->w.fmt));
   if (w->w.t3) return build_conv3_tiles(&w->owned, &w->w, s);      // the tiled copies follow the pack (no allocation: they exist)
   if (w->w.tl) return build_lin_tiles(&w->owned, &w->w, s);
+  if (w->w.tw1) HIPRET(wavenet3_build_tiles(w->w.hi, w->w.rows_p, w->cols_p, 1, w->w.tw1, w->w.tw2, s));
   return NS2_OK;
 }
 

@@ -24,6 +24,7 @@
 #include "gemm2_epilogue.h"
 #include "ffconv_kernel.h"
 #include "gemm3_kernel.h"
+#include "wavenet3_kernel.h"
 
 namespace ns2 {
 
@@ -1063,6 +1064,7 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
   const int f = forced_kernel();
   if (f == 5 && ffconv3_eligible(g, precision)) return launch_ffconv3(g, s);      // test hook: the dedicated kernels whatever the size
   if (f == 5 && gemm3_eligible(g, precision)) return launch_gemm3(g, s);
+  if (f == 5 && wavenet3_eligible(g, precision)) return launch_wavenet3(g, s);
   // Small products (a batch of 1 ... 4 utterances) split K when the caller lent scratch (splitk_plan above).
   // (f == 3: automatic kernel choice, never split -- A/B hook.)
   if ((f == 0 || f == 4) && g.sk_ws && g.epi != EPI_WAVENET && g.nz <= 1 && !g.dil_z && g.ksplit == 0) {
@@ -1079,6 +1081,7 @@ hipError_t launch_gemm(const GemmArgs& g_in, int precision, hipStream_t s) {
   if ((f == 0 || f == 3) && ffconv3_eligible(g, precision)) return launch_ffconv3(g, s);
   // the mixed linear products on full row tiles: the lean kernel (gemm3_kernel.h)
   if ((f == 0 || f == 3) && gemm3_eligible(g, precision)) return launch_gemm3(g, s);
+  if ((f == 0 || f == 3) && wavenet3_eligible(g, precision)) return launch_wavenet3(g, s);
   switch (precision) {
     case 3: return launch2_epi<3, false>(g, s);
     case 4: return launch2_epi<2, true>(g, s);
@@ -1094,6 +1097,8 @@ hipError_t ffconv3_build_tiles(const bf16_t* w_hi, int ldw, int Cp, int rows_p, 
 int ffconv3_lda(int Cp) { return ffconv3_tiles_per_tap(Cp) * 64; }
 size_t gemm3_tiled_bytes_of(int rows_p, int nkt) { return gemm3_tiled_bytes(rows_p, nkt); }
 hipError_t gemm3_build_tiles(const bf16_t* w_hi, int ldk, int rows_p, bf16_t* out, hipStream_t s) { return launch_gemm3_tile(w_hi, ldk, rows_p, out, s); }
+size_t wavenet3_tiles_bytes(int rows_p, int dp, int nz, int phase) { return phase == 1 ? wavenet3_tiles1_bytes(rows_p, dp, nz) : wavenet3_tiles2_bytes(rows_p, dp, nz); }
+hipError_t wavenet3_build_tiles(const bf16_t* w_hi, int rows_p, int dp, int nz, bf16_t* t1, bf16_t* t2, hipStream_t s) { return launch_wavenet3_tiles(w_hi, rows_p, dp, nz, t1, t2, s); }
 
 NS2_DEFINE_SATURATION_READER(gemm2)
 

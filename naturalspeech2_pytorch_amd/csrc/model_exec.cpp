@@ -262,7 +262,7 @@ static GemmArgs base_args(const PackedW& w, const bf16_t* a_hi, const bf16_t* a_
   memset(&g, 0, sizeof(g));
   g.sk_ws = tl_sk_ws; g.sk_ws_floats = tl_sk_ws ? SPLITK_SCRATCH_FLOATS : 0;
   g.a_hi = a_hi; g.a_lo = a_lo; g.lda = lda;
-  g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk; g.w_t3 = w.t3; g.w_tl = w.tl;
+  g.w_hi = w.hi; g.w_lo = w.lo; g.ldw = w.ldk; g.w_t3 = w.t3; g.w_tl = w.tl; g.w_tw1 = w.tw1; g.w_tw2 = w.tw2;
   g.M = M; g.N = w.N; g.nkt = w.nkt; g.kt_per_tap = w.nkt; g.conv_taps = 0; g.dil = 1; g.mid_kt = -1;
   g.nz = 1; g.pad_left = -1; g.act = 0; g.out_fmt = -1; g.vt_fmt = -1;
   return g;
@@ -538,6 +538,15 @@ extern "C" int ns2_model_finalize(ns2_model* m, void* stream) {
       NSCHK(pack_linear(pc_cond, &r.ffout, w2->p, dim, f, 1, s)); r.b_ffout = b2->p;
     }
   }
+  // tiled images of the Wavenet stacks for the lean block kernel of the hybrid plan (wavenet3_kernel.h): 20 MB per stack at d512
+  if (hybrid_plan(m->cfg.precision) && (m->dp % 128) == 0 && (dim % 256) == 0)
+    for (int st = 0; st < S; ++st) {
+      PackedW& W = m->w_wn[st];
+      if (W.fmt != FMT_H8) continue;
+      NSCHK(dev_alloc(&m->owned, (void**)&W.tw1, wavenet3_tiles_bytes(W.rows_p, m->dp, L, 1)));
+      NSCHK(dev_alloc(&m->owned, (void**)&W.tw2, wavenet3_tiles_bytes(W.rows_p, m->dp, L, 2)));
+      HIPCHK(wavenet3_build_tiles(W.hi, W.rows_p, m->dp, L, W.tw1, W.tw2, s));
+    }
   // tiled images of the per-step mixed linear weights (gemm3_kernel.h): +1 copy of 12.6 MB per layer at d512
   NSCHK(build_lin_tiles(&m->owned, &m->w_skip, s)); NSCHK(build_lin_tiles(&m->owned, &m->w_final, s)); NSCHK(build_lin_tiles(&m->owned, &m->w_pred, s));
   for (auto& ly : m->layers) {

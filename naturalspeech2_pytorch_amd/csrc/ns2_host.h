@@ -16,6 +16,7 @@ struct PackedW {                 // bf16 split-plane weight, rows padded to 128,
   int rows_p = 0, ldk = 0, N = 0, nkt = 0, kt_per_tap = 0;
   int fmt = 0;                   // PlaneFmt: bf16 planes (precisions 1 / 3), dense IEEE half (2), FMT_H8 lines (4)
   bf16_t* tl = nullptr;          // FMT_H8 linear weights: the tiled LDS images of the lean mixed linear kernel (gemm3_kernel.h), or null
+  bf16_t* tw1 = nullptr; bf16_t* tw2 = nullptr;   // a Wavenet stack's FMT_H8 weights: tiled images of the lean block kernel (wavenet3_kernel.h), or null
   bf16_t* t3 = nullptr;          // k = 3 conv weights in dense IEEE half: the tiled LDS images of the dedicated FF-conv kernel (ffconv_kernel.h), or null
 };
 

@@ -49,6 +49,7 @@ struct GemmArgs {
   // W operand: packed weights, bf16 split planes [ceil(N/128)*128, ldw], K contiguous
   const bf16_t* w_hi; const bf16_t* w_lo; int ldw;
   const bf16_t* w_tl;       // optional: the same FMT_H8 linear weight as tiled LDS images (gemm3_kernel.h); null = none
+  const bf16_t* w_tw1; const bf16_t* w_tw2;   // optional (EPI_WAVENET, hybrid plan): tiled images of the dilated conv's half parts / of the res conv (wavenet3_kernel.h)
   const bf16_t* w_t3;       // optional: the same conv weight (k = 3, dense IEEE half) as tiled LDS images (ffconv_kernel.h); null = none
   int M, N;          // N = valid output columns
   int nkt;           // number of 32-wide K tiles (total, all taps/phases)
@@ -106,7 +107,10 @@ hipError_t ffconv3_build_tiles(const bf16_t* w_hi, int ldw, int Cp, int rows_p, 
 int ffconv3_lda(int Cp);
 // the lean mixed linear kernel (gemm3_kernel.h, compiled in gemm2.hip): tiled weight images of an FMT_H8 pack [rows_p][ldk]
 size_t gemm3_tiled_bytes_of(int rows_p, int nkt);
-hipError_t gemm3_build_tiles(const bf16_t* w_hi, int ldk, int rows_p, bf16_t* out, hipStream_t s);                                                // activations' row length (elements) the kernel wants for Cp packed columns per tap
+hipError_t gemm3_build_tiles(const bf16_t* w_hi, int ldk, int rows_p, bf16_t* out, hipStream_t s);
+// the lean Wavenet block kernel of the hybrid plan (wavenet3_kernel.h): tiled images of a stack's nz matrices [rows_p][4 dp]
+size_t wavenet3_tiles_bytes(int rows_p, int dp, int nz, int phase);
+hipError_t wavenet3_build_tiles(const bf16_t* w_hi, int rows_p, int dp, int nz, bf16_t* t1, bf16_t* t2, hipStream_t s);                                                // activations' row length (elements) the kernel wants for Cp packed columns per tap
 constexpr long SPLITK_SCRATCH_FLOATS = 512L * 128 * 128;                // what any split needs at most: slices x output tiles <= 512 tiles of 128 x 128 (32 MiB)
 
 // flash attention forward, head dim 64, non-causal (ATT:77-155 hot path)

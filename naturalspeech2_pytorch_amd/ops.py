@@ -150,6 +150,11 @@ class PackedWeight:
         check(_lib.load().ns2_weight_tile_conv3(self.handle, _stream()), "ns2_weight_tile_conv3")
         return self
 
+    def tile_wavenet(self) -> "PackedWeight":
+        """give a WavenetResBlock weight (taps = 3 + extra1x1) packed at precision 4 the tiled images of the lean block kernel (include/ns2hip.h)"""
+        check(_lib.load().ns2_weight_tile_wavenet(self.handle, _stream()), "ns2_weight_tile_wavenet")
+        return self
+
     def tile_linear(self) -> "PackedWeight":
         """give a linear weight packed at precision 4 the tiled images of the lean mixed linear kernel (include/ns2hip.h)"""
         check(_lib.load().ns2_weight_tile_linear(self.handle, _stream()), "ns2_weight_tile_linear")

@@ -307,3 +307,38 @@ def test_mixed_training_unscales_the_gradients_of_cond_and_prompt_and_reports_ov
     finally:
         m.train_precision = "exact"
         ops.saturation_count(reset=True)
+
+
+# ---------------------------------------------------------------------------------------------- the lean Wavenet block kernel (wavenet3_kernel.h)
+@pytest.mark.parametrize("B,N,d,dil", [(4, 1024, 512, 1), (4, 1024, 512, 16), (2, 1024, 512, 128), (3, 256, 256, 2), (2, 512, 256, 64),
+                                       (1, 768, 512, 32)])
+def test_wavenet3_block_equals_gemm2_bit_for_bit_and_the_fp64_block(B, N, d, dil):
+    """WavenetResBlock of the hybrid plan (NS2:597-642): dilated conv as one half product, res conv mixed.  Shapes: first row tiles of
+    utterances with every dilation's rows in front of them (dilation 128: the whole first tile of tap 0), utterances of one tile."""
+    g = torch.Generator().manual_seed(77 + d + dil)
+    M = B * N
+    x = torch.randn(M, d, generator=g)
+    wc = torch.randn(d, d, 3, generator=g) * (3 * d) ** -0.5
+    wr = torch.randn(d, d, 1, generator=g) * d ** -0.5
+    bc, br = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    film = torch.randn(B, 2 * d, generator=g)
+    a = ops.split(x.to(DEV), precision=4)
+    pw = ops.PackedWeight(wc.to(DEV), extra1x1=wr.to(DEV), precision=4).tile_wavenet()
+    outs = {}
+    try:
+        for k in (5, 2):
+            _force(k)
+            outs[k] = ops.wavenet_block(pw, a, N, dil, bc.to(DEV), br.to(DEV), film.to(DEV), precision=5).buf.clone()
+    finally:
+        _force(0)
+    assert torch.equal(outs[5], outs[2]), "lean Wavenet block kernel differs from gemm2_kernel<2, EPI_WAVENET, true, 1>"
+    # fp64 restatement on the operands as the kernels see them (x and the conv weights rounded to half for the dilated conv)
+    xd = x.double().reshape(B, N, d).transpose(1, 2)
+    xh = x.half().double().reshape(B, N, d).transpose(1, 2)
+    h = torch.nn.functional.conv1d(torch.nn.functional.pad(xh, (2 * dil, 0)), wc.half().double(), bc.double(), dilation=dil)
+    gam, bet = film.double()[:, :d, None], film.double()[:, d:, None]
+    h = h * gam + bet
+    h = torch.tanh(h) * torch.sigmoid(h)
+    ref = (h + torch.nn.functional.conv1d(xd, wr.double(), br.double())).transpose(1, 2).reshape(M, d)
+    got = ops.join(ops.Planes(outs[5], M, d, True, "h8"), d).cpu().double()
+    assert ((got - ref).norm() / ref.norm()).item() < 3e-4
