@@ -41,7 +41,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_TRAFFIC = "r05_pmc_traffic.json"  # profiles/: committed PMC profile of the dominant kernel (tools/pmc_mfma_bench.sh, r05_pmc_mfma.json)
+PMC_TRAFFIC = "r06_pmc_traffic.json"  # profiles/: committed PMC profile of the dominant kernel (tools/pmc_mfma_bench.sh, r06_pmc_mfma.json)
 PARITY_RECORD = "r06_parity.json"    # profiles/: the tracked key-wise parity record (tests/parity_record.py)
 PEAK_16BIT_TFLOPS = 2500.0         # dense bf16 / f16 MFMA peak, MI355X_MICROARCH.md (spec; 2495 measured)
 PEAK_F32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32 (RVQ)

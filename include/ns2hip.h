@@ -281,6 +281,10 @@ int64_t ns2_model_cond_bytes(const ns2_model* m, int B, int N, int n_prompt, int
  * -> `cond_state` (caller-owned, ns2_model_cond_bytes).  drop != 0 == cond_drop_prob 1 (the CFG null branch). */
 int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_prompt, const float* cond, int n_cond, int drop, int B,
                            int N, void* cond_state, void* workspace, int64_t workspace_bytes, void* stream);
+/* Classifier-free guidance as ONE batch (NS2:914-927: cond and null forward of the same x): state_out (ns2_model_cond_bytes for 2 B
+ * utterances) = the arrays of state_a (B utterances, e.g. drop = 0) followed by those of state_b (drop = 1).  ns2_model_forward with
+ * batch 2 B, x and times repeated, then ns2_cfg_mix of the two halves.  Stream-ordered device copies, no allocation. */
+int ns2_model_cond_stack(ns2_model* m, const void* state_a, const void* state_b, int B, int N, int n_cond, void* state_out, void* stream);
 /* Model.forward (NS2:929-1000) for x [B, N, dim], times [B] -> out [B, N, dim]; cond_state null iff unconditional;
  * n_cond = the n_cond the cond_state was prepared with */
 int ns2_model_forward(ns2_model* m, const float* x, const float* times, const void* cond_state, int n_cond, float* out, int B,

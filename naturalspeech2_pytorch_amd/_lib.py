@@ -96,6 +96,7 @@ SIGNATURES = {
     "ns2_model_workspace_bytes": (L, [P, I, I, I, I]),
     "ns2_model_cond_bytes": (L, [P, I, I, I, I]),
     "ns2_model_prepare_cond": (I, [P, P, I, P, I, I, I, I, P, P, L, P]),
+    "ns2_model_cond_stack": (I, [P, P, P, I, I, I, P, P]),
     "ns2_model_forward": (I, [P, P, P, P, I, P, I, I, P, L, P]),
     "ns2_model_table_cols": (I, [P]),
     "ns2_model_time_table_workspace_bytes": (L, [P, I]),

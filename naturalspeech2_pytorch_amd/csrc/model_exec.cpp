@@ -780,6 +780,35 @@ static int norm_call(const float* x, int ldx, int M, int d, int seq_len, const f
 }
 
 // ------------------------------------------------------------------------------------------------ prepare_cond
+// Classifier-free guidance as ONE batch of 2 B utterances (NS2:914-927): every array of a cond_state is batch-major, so the
+// state of [the B conditioned utterances | the same B with the null substitutes] is the two prepared states laid end to end per array.
+// stream-ordered D2D copies, no allocation; done once per (prompt, cond) by the caller, like the states themselves.
+extern "C" int ns2_model_cond_stack(ns2_model* m, const void* state_a, const void* state_b, int B, int N, int n_cond, void* state_out, void* stream) {
+  if (!m || !m->finalized || !m->cfg.condition_on_prompt) { set_error("ns2_model_cond_stack: a finalized conditional model"); return NS2_ERR_STATE; }
+  if (!state_a || !state_b || !state_out || B <= 0 || N <= 0 || n_cond <= 0) { set_error("ns2_model_cond_stack: bad arguments"); return NS2_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  CondState a, b, o;
+  carve_cond(m, &a, const_cast<void*>(state_a), 0, B, N, n_cond);
+  carve_cond(m, &b, const_cast<void*>(state_b), 0, B, N, n_cond);
+  carve_cond(m, &o, state_out, 0, 2 * B, N, n_cond);
+  auto put = [&](void* dst, const void* sa, const void* sb, size_t bytes) -> hipError_t {
+    hipError_t e = hipMemcpyAsync(dst, sa, bytes, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(static_cast<char*>(dst) + bytes, sb, bytes, hipMemcpyDeviceToDevice, s);
+  };
+  HIPCHK(put(o.prompt_cond, a.prompt_cond, b.prompt_cond, sizeof(float) * (size_t)B * m->dt));
+  HIPCHK(put(o.pbias, a.pbias, b.pbias, sizeof(float) * (size_t)B * m->Jtot));
+  HIPCHK(put(o.condadd, a.condadd, b.condadd, sizeof(float) * (size_t)B * n_cond * m->dim));
+  const bool il = fmts_for(op_precision(m->cfg.precision)).xatt_il;
+  const size_t eb = sizeof(bf16_t) * (il ? 2 : 1);
+  for (int l = 0; l < m->cfg.depth; ++l) {
+    HIPCHK(put(o.ck[l].hi, a.ck[l].hi, b.ck[l].hi, eb * (size_t)B * m->Lm * m->a));
+    HIPCHK(put(o.cvt[l].hi, a.cvt[l].hi, b.cvt[l].hi, eb * (size_t)B * m->a * a.Lmp));
+  }
+  // (the 32-byte header slot of a state is reserved and unread)
+  return NS2_OK;
+}
+
 extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_prompt, const float* cond, int n_cond, int drop,
                                       int B, int N, void* cond_state, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!m || !m->finalized) { set_error("model not finalized"); return NS2_ERR_STATE; }

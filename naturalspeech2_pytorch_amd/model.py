@@ -364,6 +364,53 @@ class HipDenoiserMixin:
         ns.cond_cache[bool(drop)] = (key, state, prompt, cond)     # keep the inputs alive with the cache entry
         return state
 
+    def _cond_state_cfg(self, ns, prompt, cond, B, N):
+        """the conditioning of ONE 2B-utterance batch [conditioned | null substitutes] (ns2_model_cond_stack), cached like the two states"""
+        sa, sb = self._cond_state(ns, prompt, cond, False, B, N), self._cond_state(ns, prompt, cond, True, B, N)
+        key = (sa.data_ptr(), sb.data_ptr(), ns.cond_cache[False][0], B, N)
+        hit = ns.cond_cache.get("cfg")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        lib = _lib.load()
+        n_p, n_c = prompt.shape[1], cond.shape[2]
+        state = torch.empty(lib.ns2_model_cond_bytes(ns.handle, 2 * B, N, n_p, n_c), dtype=torch.uint8, device=prompt.device)
+        check(lib.ns2_model_cond_stack(ns.handle, sa.data_ptr(), sb.data_ptr(), B, N, n_c, state.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream), "ns2_model_cond_stack")
+        ns.cond_cache["cfg"] = (key, state)
+        return state
+
+    # classifier-free guidance as one batch of 2B utterances instead of two passes of B (SURVEY 8f-1; NS2:914-927): pays while the
+    # step is bound by launches and per-block latency rather than by work -- measured (bench.py side.small_batch): b = 4 x 1024 frames
+    # conditioned d512 / L12: two passes 2 x 4.4 ms, one batch of 8: 6.0 ms; from 16 utterances up two passes are as fast
+    CFG_ONE_BATCH_MAX = 8
+
+    @torch.no_grad()
+    def _forward_hip_cfg(self, x, times, prompt, cond, cond_scale, cond_row=None):
+        from . import ops
+        dim = self._hip_cfg["dim"]
+        self._guards()
+        ns = self._ensure_native()
+        B, N, _ = x.shape
+        xin = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+        pr = prompt if (prompt.dtype == torch.float32 and prompt.is_contiguous()) else prompt.float().contiguous()
+        cd = cond if (cond.dtype == torch.float32 and cond.is_contiguous()) else cond.float().contiguous()
+        state = self._cond_state_cfg(ns, pr, cd, B, N)
+        n_c = cd.shape[2]
+        ws = self._workspace(ns, 2 * B, N, pr.shape[1], n_c)
+        x2 = torch.cat((xin, xin), dim=0)
+        out2 = torch.empty_like(x2)
+        lib = _lib.load()
+        if cond_row is None:
+            t = times.to(device=xin.device, dtype=torch.float32).contiguous()
+            check(lib.ns2_model_forward(ns.handle, x2.data_ptr(), torch.cat((t, t)).data_ptr(), state.data_ptr(), n_c, out2.data_ptr(), 2 * B, N,
+                                        ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "ns2_model_forward")
+        else:
+            check(lib.ns2_model_forward_row(ns.handle, x2.data_ptr(), cond_row.data_ptr(), state.data_ptr(), n_c, out2.data_ptr(), 2 * B, N,
+                                            ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "ns2_model_forward_row")
+        self._after_hip_forward(ns)
+        out = ops.cfg_mix(out2[:B], out2[B:], cond_scale)
+        return out if out.dtype == x.dtype else out.to(x.dtype)
+
     def clear_cond_cache(self):
         """forget the cached step-invariant conditioning (call when prompt / cond were rewritten in place through `.data`)"""
         self._native.cond_cache = {}
@@ -440,16 +487,24 @@ class HipDenoiserMixin:
             check(_lib.load().ns2_model_forward_row(ns.handle, xin.data_ptr(), cond_row.data_ptr(), state_ptr, n_c, out.data_ptr(), B, N,
                                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
                   "ns2_model_forward_row")
+        self._after_hip_forward(ns)
+        return out if out.dtype == x.dtype else out.to(x.dtype)
+
+    def _after_hip_forward(self, ns):
         if self._range_guarded() and not torch.cuda.is_current_stream_capturing():
             ns.calls_since_peek += 1
             if ns.sat_event is None and (ns.peek_now or ns.calls_since_peek >= self.SAT_PEEK_EVERY):
                 self._peek_saturation()
                 ns.peek_now = False
         ns.last_call = time.monotonic()
-        return out if out.dtype == x.dtype else out.to(x.dtype)
 
     def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
         """NS2:914-927."""
+        if (cond_scale != 1. and self._hip_cfg["condition_on_prompt"] and not torch.is_grad_enabled() and len(args) == 2 and args[0].is_cuda
+                and args[0].shape[0] <= self.CFG_ONE_BATCH_MAX and kwargs.get("prompt") is not None and kwargs.get("cond") is not None
+                and kwargs.get("prompt_mask") is None and set(kwargs) <= {"prompt", "cond", "cond_row", "prompt_mask"}
+                and not torch.cuda.is_current_stream_capturing()):
+            return self._forward_hip_cfg(args[0], args[1], kwargs["prompt"], kwargs["cond"], cond_scale, cond_row=kwargs.get("cond_row"))
         logits = self.forward(*args, cond_drop_prob=0., **kwargs)
         if cond_scale == 1.:
             return logits

@@ -175,7 +175,9 @@ def test_gemm3_qkv_and_geglu_equal_gemm2_bit_for_bit(B, N, d):
 
 @pytest.mark.parametrize("precision", ["hybrid", "mixed"])
 @pytest.mark.parametrize("kw,B,N,cond", [(dict(dim=128, depth=2), 16, 1024, False), (dict(dim=512, depth=1), 4, 1024, False),
-                                         (dict(dim=512, depth=1, dim_prompt=512, condition_on_prompt=True), 4, 512, True)])
+                                         (dict(dim=512, depth=1, dim_prompt=512, condition_on_prompt=True), 4, 512, True),
+                                         (dict(dim=256, depth=1), 16, 512, False),          # wavenet3 with one column tile, K loops of 8 / 12 tiles
+                                         (dict(dim=384, depth=1, wavenet_layers=4), 8, 768, False)])   # 1.5 column tiles: wavenet3 not eligible, the others are
 def test_model_step_is_bit_identical_with_and_without_the_round6_kernels(precision, kw, B, N, cond):
     m = Model(**kw, precision=precision)
     sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=3)
@@ -342,3 +344,45 @@ def test_wavenet3_block_equals_gemm2_bit_for_bit_and_the_fp64_block(B, N, d, dil
     ref = (h + torch.nn.functional.conv1d(xd, wr.double(), br.double())).transpose(1, 2).reshape(M, d)
     got = ops.join(ops.Planes(outs[5], M, d, True, "h8"), d).cpu().double()
     assert ((got - ref).norm() / ref.norm()).item() < 3e-4
+
+
+# ---------------------------------------------------------------------------------------------- classifier-free guidance as one 2B batch
+def test_cfg_as_one_batch_equals_two_passes_and_the_oracle():
+    """NS2:914-927: null + (cond - null) * scale.  For small batches the conditioned and the null forward run as ONE batch of 2 B utterances
+    (Model._forward_hip_cfg: the two prepared conditioning states laid end to end, ns2_model_cond_stack): same result as two passes to fp32
+    rounding (another K split may apply), same distance from the oracle; also through a time-table row and along a sampled trajectory."""
+    from oracle import ns2_oracle as O
+    from naturalspeech2_pytorch_amd import NaturalSpeech2
+    kw = dict(dim=128, depth=2, dim_prompt=96, condition_on_prompt=True)
+    m = Model(**kw, precision="exact")
+    sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=71)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    b, n = 3, 256
+    x = make_input("x", (b, n, 128), seed=72).to(DEV)
+    t = make_input("times", (b,), seed=72, uniform=True).to(DEV)
+    prompt = make_input("prompt", (b, 37, 96), seed=73).to(DEV)
+    cond = make_input("cond", (b, 96, n), seed=74).to(DEV)
+    with torch.no_grad():
+        assert b <= m.CFG_ONE_BATCH_MAX
+        y1 = m.forward_with_cond_scale(x, t, prompt=prompt, cond=cond, cond_scale=1.3)
+        y1b = m.forward_with_cond_scale(x, t, prompt=prompt, cond=cond, cond_scale=1.3)
+        old, m.CFG_ONE_BATCH_MAX = m.CFG_ONE_BATCH_MAX, 0
+        try:
+            y2 = m.forward_with_cond_scale(x, t, prompt=prompt, cond=cond, cond_scale=1.3)
+        finally:
+            m.CFG_ONE_BATCH_MAX = old
+        ref = O.model_forward_with_cond_scale(sd, x.cpu(), t.cpu(), prompt.cpu(), cond.cpu(), 1.3)
+    assert torch.equal(y1, y1b)
+    assert _rel(y1, y2) < 2e-6, _rel(y1, y2)
+    assert _rel(y1.cpu(), ref) < 1e-4 and abs(_rel(y1.cpu(), ref) - _rel(y2.cpu(), ref)) < 2e-6
+    # the sampler (time table rows + CFG) gives the same trajectory either way
+    d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=6).to(DEV)
+    noise = make_input("noise", (b, n, 128), seed=75).to(DEV)
+    o1 = d.sample(length=n, noise=noise, prompt_enc=prompt, cond=cond, cond_scale=1.5)
+    old, m.CFG_ONE_BATCH_MAX = m.CFG_ONE_BATCH_MAX, 0
+    try:
+        o2 = d.sample(length=n, noise=noise, prompt_enc=prompt, cond=cond, cond_scale=1.5)
+    finally:
+        m.CFG_ONE_BATCH_MAX = old
+    assert _rel(o1, o2) < 1e-6, _rel(o1, o2)

@@ -26,7 +26,7 @@ for kind in ("mfma", "wait", "tcc", "fetch", "write"):
             res[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, d in res.items():
-    if "gemm2_kernel" not in k and "attn_kernel" not in k and "rmsnorm_kernel" not in k: continue
+    if not any(n in k for n in ("gemm2_kernel", "gemm3_kernel", "ffconv3_kernel", "wavenet3_kernel", "attn_kernel", "rmsnorm_kernel")): continue
     m = {c: sum(v) / len(v) for c, v in d.items()}
     e = dict(launches=len(d.get("SQ_WAVE_CYCLES", d.get("FETCH_SIZE", [0]))), counters_mean_per_launch=m)
     if m.get("GRBM_GUI_ACTIVE"):
