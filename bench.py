@@ -582,6 +582,25 @@ def main():
                         out[label] = round(1e3 * (time.perf_counter() - t0) / 20, 3)
                     finally:
                         lib.ns2_debug_force_gemm(0)
+                if conditioned:
+                    # classifier-free guidance (NS2:914-927) at this batch: ONE batch of 2 b utterances (Model._forward_hip_cfg, round 6)
+                    # against the two passes of b it replaces (CFG_ONE_BATCH_MAX = 0 switches it off)
+                    keep = model.CFG_ONE_BATCH_MAX
+                    for label, lim in (("cfg1.3_ms_per_step", keep), ("cfg1.3_ms_per_step_two_passes", 0)):
+                        model.CFG_ONE_BATCH_MAX = lim
+                        try:
+                            x = audio.clone()
+                            for i in range(30):
+                                if i == 10:
+                                    torch.cuda.synchronize()
+                                    t0 = time.perf_counter()
+                                o = model.forward_with_cond_scale(x, None, cond_scale=1.3, cond_row=tab[i], **kw)
+                                ops.ddim_step(x, o, tcur[i], tcur[i + 1], "v", "sigmoid", 1.0, out=x)
+                            torch.cuda.synchronize()
+                            out[label] = round(1e3 * (time.perf_counter() - t0) / 20, 3)
+                        finally:
+                            model.CFG_ONE_BATCH_MAX = keep
+                    out["cfg1.3_over_cond_scale_1"] = round(out["cfg1.3_ms_per_step"] / out["ms_per_step"], 3)
             out["utterance_steps_per_s"] = round(b * 1e3 / out["ms_per_step"], 1)
             return out
 

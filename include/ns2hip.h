@@ -146,6 +146,13 @@ int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col
                   uint16_t* o_hi, uint16_t* o_lo, int ldo, int B, int H, int Nq, int Nk, float scale,
                   const uint8_t* key_mask, int precision, void* stream);
 
+/* the same with the head dimension named: 32, 64 or 128 (the reference's `dim_head` keyword, NS2:814-831 -> Attention ATT:77-155;
+ * q / k columns of head h start at col0 + h * head_dim, vt rows at h * head_dim); scale is the caller's (dim_head ** -0.5) */
+int ns2_attention_hd(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi,
+                     const uint16_t* k_lo, int ldk, int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld,
+                     uint16_t* o_hi, uint16_t* o_lo, int ldo, int B, int H, int Nq, int Nk, float scale,
+                     const uint8_t* key_mask, int precision, int head_dim, void* stream);
+
 /* RMSNorm.forward (NS2:727-746).  gamma may be null; cond (may be null) holds [gamma_c | beta_c] per batch row */
 int ns2_rmsnorm(const float* x, int ldx, int M, int d, int seq_len, const float* gamma, const float* cond, int cond_ld,
                 uint16_t* out_hi, uint16_t* out_lo, int ldo, float* out_f32, int ldo_f, int precision, void* stream);
@@ -257,7 +264,7 @@ int ns2_rvq_decode(const int64_t* codes, const float* codebooks, float* emb, int
 /* ------------------------------------------------------------------ Model (NS2:811-1000) */
 typedef struct ns2_model ns2_model;
 typedef struct {
-  int dim, depth, dim_head, heads, ff_mult, wavenet_layers, wavenet_stacks, dim_cond_mult;   /* NS2:814-823 */
+  int dim, depth, dim_head, heads, ff_mult, wavenet_layers, wavenet_stacks, dim_cond_mult;   /* NS2:814-823; dim_head 32, 64 or 128 */
   int condition_on_prompt, dim_prompt, num_latents_m, resampler_depth;                       /* NS2:826-831 */
   int precision;               /* 3 = bf16 x3 split "exact", 4 = fp16 + fp8 correction terms "mixed", 2 = fp16 single product
                                   "half", 1 = bf16 single product "fast"; 5 = "hybrid": the per-site plan of this model

@@ -66,6 +66,7 @@ SIGNATURES = {
     "ns2_linear_qkv": (I, [P, P, P, I, I, I, I, P, P, I, P, P, I, I, P]),
     "ns2_wavenet_block": (I, [P, P, P, I, I, I, I, P, P, P, I, P, P, I, I, P]),
     "ns2_attention": (I, [P, P, I, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, F, P, I, P]),
+    "ns2_attention_hd": (I, [P, P, I, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, F, P, I, I, P]),
     "ns2_rmsnorm": (I, [P, I, I, I, I, P, P, I, P, P, I, P, I, I, P]),
     "ns2_skinny_linear_workspace_bytes": (L, [I, I, I]),
     "ns2_skinny_linear": (I, [P, I, P, P, P, I, I, I, I, I, P, L, P]),

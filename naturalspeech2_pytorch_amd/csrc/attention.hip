@@ -21,8 +21,14 @@
 
 namespace ns2 {
 
-constexpr int AT_ROWB = 144;               // 128 B payload + 16 B pad
-constexpr int AT_PLANE = 64 * AT_ROWB;     // 9216 B
+constexpr int AT_ROWB = 144;               // V^T tile row: 64 keys = 128 B payload + 16 B pad
+// head dimension D (32 / 64 / 128; round 6): K tile rows hold D dims = 2 D bytes + 16 B pad (5 / 9 / 17 sixteen-byte slots: coprime to 16,
+// conflict-free ds_read_b128 fragments), the V^T tile has D rows
+template <int D> struct AtGeom {
+  static constexpr int ROWB_K = 2 * D + 16;
+  static constexpr int KPLANE = 64 * ROWB_K;
+  static constexpr int VPLANE = D * AT_ROWB;
+};
 
 NS2_DEVINL uint4 ld16g(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 
@@ -45,13 +51,17 @@ NS2_DEVINL uint4 mask_chunk(uint4 v, int nvalid) {
 // wave's exp / max / convert work with another's MFMAs.  Four waves (<= 128 VGPRs) spills 60+ registers.
 // WLSE: also write the log-sum-exp the backward kernels recompute P from (training); a separate instantiation, so the inference
 // kernels keep their register allocation (three waves per SIMD is a one-register margin, see above)
-template <int NSPLIT, bool F16, int NW, bool WLSE>
-__global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(const AttnArgs a) {
+template <int NSPLIT, bool F16, int NW, bool WLSE, int D = 64>
+__global__ __launch_bounds__(64 * NW, ((NSPLIT == 3 && D == 128) ? 1 : (NSPLIT == 3 || D == 128) ? 2 : 3)) void attn_kernel(const AttnArgs a) {
+  using G = AtGeom<D>;
+  constexpr int DC = D / 16;                         // 16-deep k chunks of the q . k contraction
+  constexpr int DT = D / 32;                         // 32-row output tiles of O^T
   constexpr int NP = (NSPLIT == 3) ? 2 : 1;
   constexpr int QB = 32 * NW;                        // query rows per workgroup
   constexpr int NT = 64 * NW;                        // threads
-  constexpr int CPT = 512 / NT;                      // 16-B chunks of one 64 x 64 plane per thread (2 or 1)
-  constexpr int STAGE_BYTES = 2 * NP * AT_PLANE;     // K planes then V^T planes
+  constexpr int CPT = 8 * D / NT;                    // 16-B chunks of one plane per thread: the K tile has 64 x D / 8, the V^T tile D x 8
+  static_assert(CPT >= 1 && CPT * NT == 8 * D, "whole chunks per thread");
+  constexpr int STAGE_BYTES = NP * (G::KPLANE + G::VPLANE);     // K planes then V^T planes
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,35 +83,38 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(co
   const bool qil = a.q_lo != nullptr, kil = a.k_lo != nullptr, vil = a.vt_lo != nullptr, oil = a.o_lo != nullptr;
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = l31][d = 16c + 8hi .. +7]
-  bf16x8 qf[NP][4];
+  bf16x8 qf[NP][DC];
 #pragma unroll
   for (int p = 0; p < NP; ++p)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < DC; ++c) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (q_ok) v = ld16g(q_pl[p] + ((long)b * a.Nq + qrow) * pld(a.ldq, qil) + pcol(a.q_col0 + h * 64 + 16 * c + 8 * hi, qil));
+      if (q_ok) v = ld16g(q_pl[p] + ((long)b * a.Nq + qrow) * pld(a.ldq, qil) + pcol(a.q_col0 + h * D + 16 * c + 8 * hi, qil));
       qf[p][c] = *reinterpret_cast<bf16x8*>(&v);
     }
 
   // ---- staging coordinates: CPT chunks per plane per thread
-  int srow[CPT], sch[CPT];
+  int srow[CPT], sch[CPT];          // V^T tile: feature row / 8-key chunk
+  int krow[CPT], kch[CPT];          // K tile: key row / 8-dim chunk
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = tid + NT * i;
     srow[i] = c >> 3;
     sch[i] = c & 7;
+    krow[i] = c / (D / 8);
+    kch[i] = c % (D / 8);
   }
   struct Regs { uint4 k[NP][CPT]; uint4 v[NP][CPT]; };
 
   auto load_tile = [&](Regs& rg, int key0) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int key = key0 + srow[i];
+      const int key = key0 + krow[i];
       const bool kok = key < a.Nk;
-      const long koff = ((long)b * a.Nk + key) * pld(a.ldk, kil) + pcol(a.k_col0 + h * 64 + sch[i] * 8, kil);
+      const long koff = ((long)b * a.Nk + key) * pld(a.ldk, kil) + pcol(a.k_col0 + h * D + kch[i] * 8, kil);
       const int vkey = key0 + sch[i] * 8;
       const int nvalid = a.Nk - vkey;
-      const long voff = ((long)b * a.H * 64 + h * 64 + srow[i]) * pld(a.vt_ld, vil) + pcol(vkey, vil);
+      const long voff = ((long)b * a.H * D + h * D + srow[i]) * pld(a.vt_ld, vil) + pcol(vkey, vil);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         rg.k[p][i] = kok ? ld16g(k_pl[p] + koff) : make_uint4(0u, 0u, 0u, 0u);
@@ -118,23 +131,23 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(co
     unsigned char* base = smem + s * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int off = srow[i] * AT_ROWB + sch[i] * 16;
+      const int offk = krow[i] * G::ROWB_K + kch[i] * 16, offv = srow[i] * AT_ROWB + sch[i] * 16;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        *reinterpret_cast<uint4*>(base + p * AT_PLANE + off) = rg.k[p][i];
-        *reinterpret_cast<uint4*>(base + (NP + p) * AT_PLANE + off) = rg.v[p][i];
+        *reinterpret_cast<uint4*>(base + p * G::KPLANE + offk) = rg.k[p][i];
+        *reinterpret_cast<uint4*>(base + NP * G::KPLANE + p * G::VPLANE + offv) = rg.v[p][i];
       }
     }
   };
 
   // pi: swap bits 2 and 3 of the MFMA row index -> key row inside a 32-key sub-tile
   const int pi_row = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-  const int k_frag_off = pi_row * AT_ROWB + hi * 16;          // + js*32*ROWB + c*32
+  const int k_frag_off = pi_row * G::ROWB_K + hi * 16;        // + js*32*ROWB_K + c*32
   const int v_frag_off = l31 * AT_ROWB + hi * 16;             // + dt*32*ROWB + js*64 + g1*32
 
-  f32x16 ot[2];
+  f32x16 ot[DT];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
@@ -159,11 +172,11 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(co
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[js][r] = 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < DC; ++c) {
         bf16x8 kf[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-          kf[p] = *reinterpret_cast<const bf16x8*>(sb + p * AT_PLANE + k_frag_off + js * 32 * AT_ROWB + c * 32);
+          kf[p] = *reinterpret_cast<const bf16x8*>(sb + p * G::KPLANE + k_frag_off + js * 32 * G::ROWB_K + c * 32);
         if constexpr (NSPLIT == 3) {
           st[js] = mma16<F16>(kf[1], qf[0][c], st[js]);
           st[js] = mma16<F16>(kf[0], qf[1][c], st[js]);
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(co
     l_run = l_run * alpha + psum;
     if (__any(alpha != 1.0f)) {                           // the running maximum rarely moves after the first tiles
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
     }
@@ -233,11 +246,11 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(co
           }
         }
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
           bf16x8 vf[NP];
 #pragma unroll
           for (int p = 0; p < NP; ++p)
-            vf[p] = *reinterpret_cast<const bf16x8*>(sb + (NP + p) * AT_PLANE + v_frag_off + dt * 32 * AT_ROWB +
+            vf[p] = *reinterpret_cast<const bf16x8*>(sb + NP * G::KPLANE + p * G::VPLANE + v_frag_off + dt * 32 * AT_ROWB +
                                                     js * 64 + g1 * 32);
           if constexpr (NSPLIT == 3) {
             ot[dt] = mma16<F16>(vf[1], pf[0], ot[dt]);
@@ -258,28 +271,32 @@ __global__ __launch_bounds__(64 * NW, (NSPLIT == 3 ? 2 : 3)) void attn_kernel(co
   if (q_ok) {
     bf16_t* orow = a.o_hi + ((long)b * a.Nq + qrow) * pld(a.ldo, oil);
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq)
-        store_cols4(orow, h * 64 + 32 * dt + 8 * gq + 4 * hi, ot[dt][4 * gq + 0] * inv, ot[dt][4 * gq + 1] * inv,
+        store_cols4(orow, h * D + 32 * dt + 8 * gq + 4 * hi, ot[dt][4 * gq + 0] * inv, ot[dt][4 * gq + 1] * inv,
                     ot[dt][4 * gq + 2] * inv, ot[dt][4 * gq + 3] * inv, a.o_fmt, oil);
   }
 }
 
-template <int NSPLIT, bool F16, int NW, bool WLSE>
+template <int NSPLIT, bool F16, int NW, bool WLSE, int D = 64>
 static hipError_t launch_attn_w(const AttnArgs& a, hipStream_t s) {
-  const size_t lds = 2 * 2 * (NSPLIT == 3 ? 2 : 1) * AT_PLANE;
+  const size_t lds = 2 * (NSPLIT == 3 ? 2 : 1) * (AtGeom<D>::KPLANE + AtGeom<D>::VPLANE);
   static DynLdsAttr attr;
   {
-    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attn_kernel<NSPLIT, F16, NW, WLSE>), (int)lds);
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&attn_kernel<NSPLIT, F16, NW, WLSE, D>), (int)lds);
     if (e != hipSuccess) return e;
   }
   dim3 grid(((a.Nq + 32 * NW - 1) / (32 * NW)) * a.H * a.B);
-  hipLaunchKernelGGL((attn_kernel<NSPLIT, F16, NW, WLSE>), grid, dim3(64 * NW), lds, s, a);
+  hipLaunchKernelGGL((attn_kernel<NSPLIT, F16, NW, WLSE, D>), grid, dim3(64 * NW), lds, s, a);
   return hipGetLastError();
 }
 template <int NSPLIT, bool F16>
 static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t s) {
+  const int D = a.D > 0 ? a.D : 64;
+  if (D == 32) return a.lse ? hipErrorInvalidValue : launch_attn_w<NSPLIT, F16, 4, false, 32>(a, s);      // (the backward kernels have a head dim of 64:
+  if (D == 128) return a.lse ? hipErrorInvalidValue : launch_attn_w<NSPLIT, F16, 4, false, 128>(a, s);    //  training.unsupported_reason)
+  if (D != 64) return hipErrorInvalidValue;
   if constexpr (NSPLIT == 3) { if (a.lse) return launch_attn_w<NSPLIT, F16, 4, true>(a, s); }   // training runs in precision 3
   else if (a.lse) return hipErrorInvalidValue;
   return launch_attn_w<NSPLIT, F16, 4, false>(a, s);

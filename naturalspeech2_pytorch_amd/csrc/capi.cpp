@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 113; }   // 113: ns2_weight_tile_conv3 + ns2_conv3_input_ld (the dedicated FF causal conv kernel, ffconv_kernel.h), ns2_weight_tile_linear (gemm3_kernel.h), ns2_weight_tile_wavenet (wavenet3_kernel.h), ns2_debug_force_gemm(4 / 5); 112: ns2_seanet_resblock_narrow; 111: training entry points take a precision (3 = bf16 x3, 4 = mixed on FMT_H8 lines), ns2_linear_split_as; 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 114; }   // 114: ns2_attention_hd (head dims 32 / 64 / 128), ns2_model_create takes dim_head 32 / 128; 113: ns2_weight_tile_conv3 + ns2_conv3_input_ld (the dedicated FF causal conv kernel, ffconv_kernel.h), ns2_weight_tile_linear (gemm3_kernel.h), ns2_weight_tile_wavenet (wavenet3_kernel.h), ns2_debug_force_gemm(4 / 5); 112: ns2_seanet_resblock_narrow; 111: training entry points take a precision (3 = bf16 x3, 4 = mixed on FMT_H8 lines), ns2_linear_split_as; 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 5, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel, 3 = auto without split-K, 4 = auto without the dedicated FF-conv kernel, 5 = auto, the FF-conv kernel whenever eligible");
   force_gemm_kernel(kernel);
@@ -209,12 +209,14 @@ extern "C" int ns2_wavenet_block(const ns2_weight* w, const uint16_t* a_hi, cons
                       ldo, 0, ldo, precision, (hipStream_t)stream, p1_half);
 }
 
-extern "C" int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi,
-                             const uint16_t* k_lo, int ldk, int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld,
-                             uint16_t* o_hi, uint16_t* o_lo, int ldo, int B, int H, int Nq, int Nk, float scale,
-                             const uint8_t* key_mask, int precision, void* stream) {
+extern "C" int ns2_attention_hd(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi,
+                                const uint16_t* k_lo, int ldk, int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld,
+                                uint16_t* o_hi, uint16_t* o_lo, int ldo, int B, int H, int Nq, int Nk, float scale,
+                                const uint8_t* key_mask, int precision, int head_dim, void* stream) {
   ARGCHK(q_hi && k_hi && vt_hi && o_hi && prec_ok(precision), "ns2_attention: bad arguments");
+  ARGCHK(head_dim == 32 || head_dim == 64 || head_dim == 128, "ns2_attention: head_dim must be 32, 64 or 128");
   AttnArgs a;
+  a.D = head_dim;
   a.lse = nullptr;
   a.q_hi = q_hi; a.q_lo = q_lo; a.ldq = ldq; a.q_col0 = q_col0;
   a.k_hi = k_hi; a.k_lo = k_lo; a.ldk = ldk; a.k_col0 = k_col0;
@@ -223,6 +225,13 @@ extern "C" int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = scale; a.kmask = key_mask;
   HIPRET(launch_attention(a, precision, (hipStream_t)stream));
   return NS2_OK;
+}
+extern "C" int ns2_attention(const uint16_t* q_hi, const uint16_t* q_lo, int ldq, int q_col0, const uint16_t* k_hi,
+                             const uint16_t* k_lo, int ldk, int k_col0, const uint16_t* vt_hi, const uint16_t* vt_lo, int vt_ld,
+                             uint16_t* o_hi, uint16_t* o_lo, int ldo, int B, int H, int Nq, int Nk, float scale,
+                             const uint8_t* key_mask, int precision, void* stream) {
+  return ns2_attention_hd(q_hi, q_lo, ldq, q_col0, k_hi, k_lo, ldk, k_col0, vt_hi, vt_lo, vt_ld, o_hi, o_lo, ldo, B, H, Nq, Nk, scale,
+                          key_mask, precision, 64, stream);
 }
 
 extern "C" int ns2_rmsnorm(const float* x, int ldx, int M, int d, int seq_len, const float* gamma, const float* cond, int cond_ld,

@@ -253,6 +253,7 @@ extern "C" int ns2_attention_lse(const uint16_t* q_hi, const uint16_t* q_lo, int
   ARGCHK(q_hi && k_hi && vt_hi && o_hi && lse && precision >= 1 && precision <= 4, "ns2_attention_lse: bad arguments");
   ARGCHK(o_precision == 0 || o_precision == 3 || o_precision == 4, "ns2_attention_lse: o_precision 0 (= precision), 3 (bf16 hi / lo) or 4 (FMT_H8)");
   AttnArgs a;
+  a.D = 64;
   a.q_hi = q_hi; a.q_lo = q_lo; a.ldq = ldq; a.q_col0 = q_col0;
   a.k_hi = k_hi; a.k_lo = k_lo; a.ldk = ldk; a.k_col0 = k_col0;
   a.vt_hi = vt_hi; a.vt_lo = vt_lo; a.vt_ld = vt_ld;

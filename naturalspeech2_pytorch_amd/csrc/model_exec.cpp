@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <map>
 #include <string>
 #include <vector>
@@ -353,7 +354,7 @@ static const Param* find_param(const ns2_model* m, const std::string& k) {
 
 extern "C" int ns2_model_create(const ns2_model_config* cfg, ns2_model** out) {
   if (!cfg || !out) { set_error("null argument"); return NS2_ERR_ARG; }
-  if (cfg->dim_head != 64) { set_error("dim_head must be 64 (attention kernel head dim), got %d", cfg->dim_head); return NS2_ERR_ARG; }
+  if (cfg->dim_head != 32 && cfg->dim_head != 64 && cfg->dim_head != 128) { set_error("dim_head must be 32, 64 or 128 (the head dims the attention kernel is built for), got %d", cfg->dim_head); return NS2_ERR_ARG; }
   if (cfg->dim % 32) { set_error("dim must be a multiple of 32, got %d", cfg->dim); return NS2_ERR_ARG; }
   if (cfg->precision < 1 || cfg->precision > 6) { set_error("precision must be 1 (bf16), 2 (fp16), 3 (bf16 x3), 4 (fp16 + fp8 correction terms), 5 (4, with the FF causal conv and the Wavenet's dilated convs as one fp16 product) or 6 (5, with the whole feed-forward branch as fp16 products)"); return NS2_ERR_ARG; }
   if (cfg->wavenet_layers < 1 || cfg->wavenet_layers > 16 || cfg->wavenet_stacks < 1) { set_error("bad wavenet shape"); return NS2_ERR_ARG; }
@@ -756,14 +757,15 @@ static int tap_planes(ns2_model* m, const char* name, Planes p, int ld, int64_t 
 
 static int attention_call(const bf16_t* q_hi, const bf16_t* q_lo, int ldq, int q_col0, const bf16_t* k_hi, const bf16_t* k_lo,
                           int ldk, int k_col0, Planes vt, int vt_ld, Planes o, int ldo, int B, int H, int Nq, int Nk, int prec,
-                          hipStream_t s) {
+                          hipStream_t s, int dim_head) {
   AttnArgs a;
+  a.D = dim_head;
   a.lse = nullptr;
   a.q_hi = q_hi; a.q_lo = q_lo; a.ldq = ldq; a.q_col0 = q_col0;
   a.k_hi = k_hi; a.k_lo = k_lo; a.ldk = ldk; a.k_col0 = k_col0;
   a.vt_hi = vt.hi; a.vt_lo = vt.lo; a.vt_ld = vt_ld;
   a.o_hi = o.hi; a.o_lo = o.lo; a.ldo = ldo; a.o_fmt = o.fmt;
-  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = 0.125f;       // dim_head ** -0.5  (ATT:128 / SDPA default)
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.scale = 1.0f / sqrtf((float)dim_head);       // dim_head ** -0.5  (ATT:128 / SDPA default; 0.125 exactly at 64)
   a.kmask = nullptr;
   HIPCHK(launch_attention(a, prec, s));
   return NS2_OK;
@@ -862,7 +864,7 @@ extern "C" int ns2_model_prepare_cond(ns2_model* m, const float* prompt, int n_p
       HIPCHK(launch_split(w.latf, dim, nullptr, 0, 0, 0, w.latp.hi, w.latp.lo, dp, B * Lm, dim, 0, s, w.latp.fmt));
       NSCHK(gemm_split(r.q, w.latp.hi, w.latp.lo, dp, B * Lm, 0, 1, 0, nullptr, w.qk.hi, w.qk.lo, a, prec, s, -1, 0, w.qk.fmt));
       NSCHK(gemm_qkv(r.kv, w.ctxp.hi, w.ctxp.lo, dp, B * Nctx, Nctx, a, w.rkv.hi, w.rkv.lo, a, w.rvt.hi, w.rvt.lo, w.Nctxp, prec, s));
-      NSCHK(attention_call(w.qk.hi, w.qk.lo, a, 0, w.rkv.hi, w.rkv.lo, a, 0, w.rvt, w.Nctxp, w.o, a, B, H, Lm, Nctx, prec, s));
+      NSCHK(attention_call(w.qk.hi, w.qk.lo, a, 0, w.rkv.hi, w.rkv.lo, a, 0, w.rvt, w.Nctxp, w.o, a, B, H, Lm, Nctx, prec, s, m->cfg.dim_head));
       NSCHK(gemm_f32(r.out, w.o.hi, w.o.lo, a, B * Lm, 0, 1, 0, nullptr, w.latf, dim, w.latf, dim, prec, s));
       // FeedForward without conv (NS2:1009-1025)
       HIPCHK(launch_split(w.latf, dim, nullptr, 0, 0, 0, w.latp.hi, w.latp.lo, dp, B * Lm, dim, 0, s, w.latp.fmt));
@@ -1019,14 +1021,14 @@ static int forward_impl(ns2_model* m, const float* x, const float* times, const 
     const bool last = l + 1 == m->cfg.depth;
     // self attention (its norm ran behind the previous update)
     PROF(PC_GEMM_QKV, gemm_qkv(ly.qkv, w.xn.hi, w.xn.lo, dp, M, N, 2 * a, w.qk.hi, w.qk.lo, 2 * a, w.vt.hi, w.vt.lo, w.Nkp, prec, s));
-    PROF(PC_ATTENTION, attention_call(w.qk.hi, w.qk.lo, 2 * a, 0, w.qk.hi, w.qk.lo, 2 * a, a, w.vt, w.Nkp, w.o, a, B, H, N, N, prec, s));
+    PROF(PC_ATTENTION, attention_call(w.qk.hi, w.qk.lo, 2 * a, 0, w.qk.hi, w.qk.lo, 2 * a, a, w.vt, w.Nkp, w.o, a, B, H, N, N, prec, s, m->cfg.dim_head));
     // out-projection + residual, then the norm of what follows: the cross attention (conditioned) or the feed-forward
     NSCHK(update_then_norm(ly.out, w.o, a, nullptr, true, prec, nullptr, layer_cond(l, cond ? 1 : m->nnorm - 1), cond ? w.xn : xn_ff));
     snprintf(name, sizeof name, "layer%d.attn", l);
     NSCHK(tap_f32(m, name, w.xres, (int64_t)M * dim, s));
     if (cond) {   // cross attention to the resampled prompt tokens (NS2:799-803)
       PROF(PC_GEMM_SPLIT, gemm_split(ly.cq, w.xn.hi, w.xn.lo, dp, M, 0, 1, 0, nullptr, w.xq.hi, w.xq.lo, a, prec, s, -1, 0, w.xq.fmt));
-      PROF(PC_ATTENTION, attention_call(w.xq.hi, w.xq.lo, a, 0, cs.ck[l].hi, cs.ck[l].lo, a, 0, cs.cvt[l], cs.Lmp, w.o, a, B, H, N, Lm, xprec, s));
+      PROF(PC_ATTENTION, attention_call(w.xq.hi, w.xq.lo, a, 0, cs.ck[l].hi, cs.ck[l].lo, a, 0, cs.cvt[l], cs.Lmp, w.o, a, B, H, N, Lm, xprec, s, m->cfg.dim_head));
       NSCHK(update_then_norm(ly.cout, w.o, a, nullptr, true, prec, nullptr, layer_cond(l, m->nnorm - 1), xn_ff));
     }
     // feedforward: Linear -> GEGLU -> causal conv k3 -> Linear (NS2:1009-1025); precision 6: the whole branch on dense IEEE-half planes

@@ -122,6 +122,7 @@ struct AttnArgs {
   int o_fmt;                                           // PlaneFmt of o (-1: the operand format; FMT_H8 feeds a precision-4 GEMM)
   int q_col0, k_col0;
   int B, H, Nq, Nk;
+  int D;                                               // head dimension: 32, 64 or 128 (0 = 64); head h at columns col0 + D h, V^T rows H D per utterance
   float scale;
   const unsigned char* kmask;                            // optional key-padding mask [B, Nk], 1 = attend (ATT:92-94, 136-138)
   float* lse;                                            // optional [B, H, Nq]: log2 of the softmax denominator of the SCALED scores

@@ -241,17 +241,20 @@ def wavenet_block(w: PackedWeight, a: Planes, seq_len: int, dilation: int, conv_
     return out
 
 
-def attention(q: Planes, k: Planes, vt: Planes, B: int, H: int, Nq: int, Nk: int, q_col0=0, k_col0=0, scale=0.125,
-              precision=3, key_mask: Optional[torch.Tensor] = None) -> Planes:
-    """vt: transposed value planes [B * H*64, vt_ld]; key_mask: optional bool/uint8 [B, Nk], True = attend (ATT:92-94)."""
-    out = _out_planes(B * Nq, H * 64, q.device, precision)
+def attention(q: Planes, k: Planes, vt: Planes, B: int, H: int, Nq: int, Nk: int, q_col0=0, k_col0=0, scale=None,
+              precision=3, key_mask: Optional[torch.Tensor] = None, head_dim: int = 64) -> Planes:
+    """vt: transposed value planes [B * H*head_dim, vt_ld]; key_mask: optional bool/uint8 [B, Nk], True = attend (ATT:92-94);
+    head_dim 32 / 64 / 128, scale defaults to head_dim ** -0.5 (ATT:128)."""
+    if scale is None:
+        scale = head_dim ** -0.5
+    out = _out_planes(B * Nq, H * head_dim, q.device, precision)
     km = None
     if key_mask is not None:
         km = key_mask.to(torch.uint8).contiguous()
         assert km.shape == (B, Nk)
-    check(_lib.load().ns2_attention(q.hi, q.lo, q.ld, q_col0, k.hi, k.lo, k.ld,
-                                    k_col0, vt.hi, vt.lo, vt.ld, out.hi, out.lo,
-                                    H * 64, B, H, Nq, Nk, scale, _p(km), precision, _stream()), "ns2_attention")
+    check(_lib.load().ns2_attention_hd(q.hi, q.lo, q.ld, q_col0, k.hi, k.lo, k.ld,
+                                       k_col0, vt.hi, vt.lo, vt.ld, out.hi, out.lo,
+                                       H * head_dim, B, H, Nq, Nk, scale, _p(km), precision, head_dim, _stream()), "ns2_attention_hd")
     return out
 
 

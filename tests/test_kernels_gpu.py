@@ -324,6 +324,39 @@ def test_attention(B, H, Nq, Nk, prec):
     assert e < {3: 3e-5, 1: 2e-2, 2: 8e-4, 4: 5e-4}[prec], f"rel err {e}"
 
 
+@pytest.mark.parametrize("prec", [3, 2, 4])
+@pytest.mark.parametrize("D", [32, 128])
+@pytest.mark.parametrize("B,H,Nq,Nk,masked", [(2, 4, 200, 200, False), (1, 2, 1024, 1024, False), (2, 3, 70, 135, True), (1, 2, 129, 16, False)])
+def test_attention_head_dims(B, H, Nq, Nk, masked, D, prec):
+    """round 6: the reference's `dim_head` keyword (NS2:814-831; Attend ATT:77-155, scale = dim_head ** -0.5) at 32 and 128:
+    same kernel, head dimension as a template parameter; padding poisoned, key-padding mask on one case"""
+    a_dim = H * D
+    q, k, v = rnd(B * Nq, a_dim, seed=120), rnd(B * Nk, a_dim, seed=121), rnd(B * Nk, a_dim, seed=122)
+    qp, kp = asplit(q, prec), asplit(k, prec)
+    vt_ld = ops.round_up(Nk, 32)
+    vt_f = torch.full((B, a_dim, vt_ld), float("nan"), device=DEV)
+    vt_f[:, :, :Nk] = v.reshape(B, Nk, a_dim).transpose(1, 2)
+    vt = asplit(vt_f.reshape(B * a_dim, vt_ld), prec, ldo=vt_ld)
+    mask = None
+    if masked:
+        mask = (torch.rand(B, Nk, generator=torch.Generator().manual_seed(123)) > 0.4)
+        mask[0, :5] = False
+        mask = mask.to(DEV)
+    o = ops.attention(qp, kp, vt, B, H, Nq, Nk, precision=prec, key_mask=mask, head_dim=D)
+
+    def heads(p, n):
+        return exact(p).reshape(B, n, H, D).permute(0, 2, 1, 3)
+    ve = exact(vt).reshape(B, a_dim, vt_ld)[:, :, :Nk].reshape(B, H, D, Nk).transpose(2, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", heads(qp, Nq), heads(kp, Nk)) * D ** -0.5
+    if masked:
+        sim = sim.masked_fill(~mask[:, None, None, :], -torch.finfo(torch.float32).max)
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), ve).permute(0, 2, 1, 3).reshape(B * Nq, a_dim)
+    got = ops.join(o)
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    e = rel(got, ref)
+    assert e < {3: 3e-5, 2: 8e-4, 4: 5e-4}[prec], f"rel err {e}"
+
+
 def test_attention_key_padding_mask():
     """ATT:136-138: masked keys get -finfo.max before the softmax (also when they are the first / middle keys)."""
     B, H, Nq, Nk = 2, 2, 70, 150

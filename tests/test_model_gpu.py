@@ -89,7 +89,7 @@ def test_model_taps_match_reference(path):
     # oracle taps for the residual stream after layer 0 (reference hooks only expose sub-module outputs)
     otaps = {}
     with torch.no_grad():
-        O.model_forward(sd, x, t, prompt, cond, taps=otaps)
+        O.model_forward(sd, x, t, prompt, cond, taps=otaps, dim_head=kw.get("dim_head", 64))
     assert rel(got["layer0"].reshape(b, n, d), otaps["transformer.layer0"]) < 1e-4
     assert rel(out, fix["outputs"]["cond_scale_1.0"]) < 1e-4
 
@@ -212,7 +212,7 @@ def test_errors_are_loud():
             m(x, torch.zeros(1, device=DEV), prompt_mask=torch.ones(1, 3, dtype=torch.bool))
     with pytest.raises(Exception):
         with torch.no_grad():
-            Model(dim=64, depth=1, dim_head=32).to(DEV)(x, torch.zeros(1, device=DEV))   # unsupported head dim
+            Model(dim=64, depth=1, dim_head=48).to(DEV)(x, torch.zeros(1, device=DEV))   # a head dim the attention kernel is not built for
 
 
 def test_training_path_autograd():
