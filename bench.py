@@ -104,23 +104,45 @@ def train_step_side(dev):
 
             for _ in range(2):
                 step()
-            # two timed windows, the faster one is reported: the step issues ~2000 launches from Python, and a neighbour's CPU load on
-            # the box (the pod's GPU slots share the host) once turned a 100 ms step into 150 ms for one window (profiles/README.md)
-            wins = []
-            for kw_ in ((k + 1) // 2, k // 2):
-                if kw_ == 0:
-                    continue
+
+            def window(fn, kw_):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(kw_):
-                    loss = step()
+                    last = fn()
                 torch.cuda.synchronize()
-                wins.append((time.perf_counter() - t0) / kw_)
+                return (time.perf_counter() - t0) / kw_, last
+
+            # Round 6: the HIP backends' loss + backward is replayed from ONE HIP graph (training.GraphedTrainStep: same
+            # kernels, gradients bit-identical -- tests/test_round6_gpu.py::test_graphed_training_step); fused Adam stays outside it.  The
+            # eager pass (~2000 launches enqueued from Python, at the mercy of the host's other tenants) is timed beside it for 2 steps.
+            eager_dt = None
+            done = 0
+            if backend == "hip":
+                from naturalspeech2_pytorch_amd import training
+                eager_dt, loss = window(step, 2)
+                done = 2
+                gs = training.GraphedTrainStep(lambda a, t_, z: d(a, times=t_, noise=z), (audio, times, noise), m)
+
+                def step():                                   # noqa: F811
+                    loss = gs(audio, times, noise)
+                    opt.step()
+                    return loss
+            wins = []
+            for kw_ in ((k - done + 1) // 2, (k - done) // 2):
+                if kw_ <= 0:
+                    continue
+                w, loss = window(step, kw_)
+                wins.append(w)
+                done += kw_
             dt = min(wins)
-            for _ in range(iters - k):                   # (untimed) so that every backend reports the loss of the SAME iteration
+            for _ in range(iters - done):                # (untimed) so that every backend reports the loss of the SAME iteration
                 loss = step()
+            res[name + "_windows"] = [round(1e3 * w, 2) for w in wins]
+            res[name + "_eager"] = eager_dt
             res[name] = (dt, float(loss.detach()))
-            del m, d, opt
+            gs = None
+            del m, d, opt, gs
             torch.cuda.empty_cache()
         flops = 3.0 * UTT_GFLOP[(kw["dim"], kw["depth"], False)] * 1e9 * b * n / 1024        # forward + dgrad + wgrad
         best = min(("mixed", "exact"), key=lambda q: res[q][0])
@@ -128,6 +150,9 @@ def train_step_side(dev):
         out[tag] = dict(metric=f"warm training step (loss + backward + fused Adam), Model(dim={kw['dim']}, depth={kw['depth']}), {b} x {n} frames",
                         ms_per_step=round(ms, 2), train_precision=best, iterations=iters, steps_per_s=round(1e3 / ms, 3),
                         mixed_ms_per_step=round(1e3 * res["mixed"][0], 2), exact_ms_per_step=round(1e3 * res["exact"][0], 2),
+                        launch_path="loss + backward replayed from one HIP graph (training.GraphedTrainStep), fused Adam outside it",
+                        timed_windows_ms={q: res[q + "_windows"] for q in ("mixed", "exact")},
+                        eager_ms_per_step={q: round(1e3 * res[q + "_eager"], 2) for q in ("mixed", "exact")},
                         algorithmic_tflops=round(flops / (ms * 1e-3) / 1e12, 1), algorithmic_flops="3 x the forward's (SURVEY 8d)",
                         frac_of_16bit_peak=round(flops / (ms * 1e-3) / 1e12 / PEAK_16BIT_TFLOPS, 4),
                         arithmetic={"mixed": "IEEE-half product + both correction terms on the fp8 MFMA (2 MFMA units per algorithmic FLOP) on FMT_H8 "

@@ -100,8 +100,8 @@ int ns2_linear_split(const ns2_weight* w, const uint16_t* a_hi, const uint16_t* 
                      int pad_left, int act, int precision, void* stream);
 /* The feed-forward causal conv (CausalConv1d(f, f, 3), NS2:1016 / 583-595) as one IEEE-half product has a kernel of its own
  * (csrc/ffconv_kernel.h).  It reads the weight as pre-tiled LDS images: ns2_weight_tile_conv3 builds them for a weight packed with
- * taps = 3 at precision 2 (one-time set-up, allocates once; ns2_weight_update keeps them current; the packs of ns2_weights_repack
- * must not have them).  A later ns2_linear_split / ns2_linear_split_as call with that weight takes the kernel when: conv_taps = 3,
+ * taps = 3 at precision 2 (one-time set-up, allocates once; ns2_weight_update keeps them current; after ns2_weights_repack call
+ * ns2_weights_retile).  A later ns2_linear_split / ns2_linear_split_as call with that weight takes the kernel when: conv_taps = 3,
  * dilation = 1, pad_left = -1, act = 0, M % 256 == 0, seq_len % 256 == 0, lda == ns2_conv3_input_ld(cols) (dense half rows padded to
  * a multiple of 128 columns; the padding is never multiplied), output dense half or FMT_H8 lines.  Results are bit-identical to the
  * general kernel's (same products, same summation order).  ns2_model_finalize does all of this for precisions 2 / 5 / 6. */
@@ -362,6 +362,9 @@ typedef struct {
 int64_t ns2_weights_repack_table_bytes(int n);
 int ns2_weights_repack_build(const ns2_repack_part* parts, int n, void* table_device, int64_t table_bytes, int64_t* total_blocks, void* stream);
 int ns2_weights_repack(const void* table_device, int n, int64_t total_blocks, void* stream);
+/* after ns2_weights_repack: rebuild the tiled images (ns2_weight_tile_conv3 / _linear / _wavenet) of those weights that have them --
+ * one small launch per such weight, stream-ordered, no allocation.  With it packs that carry images may be part of a repack table. */
+int ns2_weights_retile(ns2_weight* const* weights, int n, void* stream);
 
 /* fp32 gradient x [M, C] (row stride ldx) -> any of
  *   row planes [M, ld_row] (zero beyond C)                                  -- the A operand of the dgrad GEMM;

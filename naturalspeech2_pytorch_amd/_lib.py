@@ -123,6 +123,7 @@ SIGNATURES = {
     "ns2_weights_repack_table_bytes": (L, [I]),
     "ns2_weights_repack_build": (I, [P, I, P, L, POINTER(c_int64), P]),
     "ns2_weights_repack": (I, [P, I, L, P]),
+    "ns2_weights_retile": (I, [P, I, P]),
     "ns2_wgrad_workspace_bytes": (L, [I, I, L]),
     "ns2_wgrad": (I, [P, P, P, P, L, I, I, I, I, P, P, L, I, P]),
     "ns2_wgrad_rows_preferred": (I, [I, I, L]),

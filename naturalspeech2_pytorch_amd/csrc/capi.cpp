@@ -43,7 +43,7 @@ static inline int prec_ok(int p) { return p >= 1 && p <= 4; }
 static inline int op_fmt(int p) { return p == 2 ? FMT_F16 : (p == 4 ? FMT_H8 : FMT_BF16); }
 
 extern "C" const char* ns2_last_error(void) { return g_err; }
-extern "C" int ns2_version(void) { return 114; }   // 114: ns2_attention_hd (head dims 32 / 64 / 128), ns2_model_create takes dim_head 32 / 128; 113: ns2_weight_tile_conv3 + ns2_conv3_input_ld (the dedicated FF causal conv kernel, ffconv_kernel.h), ns2_weight_tile_linear (gemm3_kernel.h), ns2_weight_tile_wavenet (wavenet3_kernel.h), ns2_debug_force_gemm(4 / 5); 112: ns2_seanet_resblock_narrow; 111: training entry points take a precision (3 = bf16 x3, 4 = mixed on FMT_H8 lines), ns2_linear_split_as; 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
+extern "C" int ns2_version(void) { return 115; }   // 115: ns2_weights_retile; 114: ns2_attention_hd (head dims 32 / 64 / 128), ns2_model_create takes dim_head 32 / 128; 113: ns2_weight_tile_conv3 + ns2_conv3_input_ld (the dedicated FF causal conv kernel, ffconv_kernel.h), ns2_weight_tile_linear (gemm3_kernel.h), ns2_weight_tile_wavenet (wavenet3_kernel.h), ns2_debug_force_gemm(4 / 5); 112: ns2_seanet_resblock_narrow; 111: training entry points take a precision (3 = bf16 x3, 4 = mixed on FMT_H8 lines), ns2_linear_split_as; 110: backward pass (capi_train.cpp: ns2_wgrad, ns2_attention_bwd, ...), ns2_weight_update; 109: ns2_seanet_conv_narrow; 108: ns2_seanet_prep2; 107: ns2_lstm2 (two LSTM layers, one launch); 106: ns2_saturation_peek_async; 105: ns2_lstm_layer takes the scratch size (persistent recurrence); 104: model precision 5 (per-site plan); 103: precision 2 / 4 at op level, caller-owned skinny-linear scratch
 extern "C" int ns2_debug_force_gemm(int kernel) {
   ARGCHK(kernel >= 0 && kernel <= 5, "ns2_debug_force_gemm: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel, 3 = auto without split-K, 4 = auto without the dedicated FF-conv kernel, 5 = auto, the FF-conv kernel whenever eligible");
   force_gemm_kernel(kernel);
@@ -86,8 +86,7 @@ extern "C" int ns2_weight_tile_conv3(ns2_weight* w, void* stream) {
 }
 // Give a linear weight (taps = 1; also the GEGLU packing) packed for precision 4 (FMT_H8 lines) the tiled images of the lean mixed linear
 // kernel (gemm3_kernel.h): ns2_linear_f32 / _split / _qkv / _geglu then take that kernel when M % 256 == 0 and K >= 96.  One-time set-up
-// (allocates on the first call); ns2_weight_update refreshes the images with the pack; packs refreshed through ns2_weights_repack must
-// not have them (the table does not know the copy).
+// (allocates on the first call); ns2_weight_update refreshes the images with the pack; after ns2_weights_repack, ns2_weights_retile does.
 extern "C" int ns2_weight_tile_linear(ns2_weight* w, void* stream) {
   ARGCHK(w && w->taps == 1 && !w->has_extra && w->w.fmt == FMT_H8 && w->w.nkt >= 3, "ns2_weight_tile_linear: a linear weight (taps = 1, K >= 96) packed for precision 4");
   return build_lin_tiles(&w->owned, &w->w, (hipStream_t)stream);

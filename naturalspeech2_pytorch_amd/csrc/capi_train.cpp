@@ -72,6 +72,22 @@ extern "C" int ns2_weights_repack_build(const ns2_repack_part* parts, int n, voi
   *total_blocks = blocks;
   return NS2_OK;
 }
+// the tiled images (ffconv_kernel.h / gemm3_kernel.h / wavenet3_kernel.h) of weights whose packs ns2_weights_repack has just refreshed:
+// one small launch per weight that has images, none for the others; stream-ordered, no allocation (the images exist)
+extern "C" int ns2_weights_retile(ns2_weight* const* ws, int n, void* stream) {
+  ARGCHK(ws && n > 0, "ns2_weights_retile: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < n; ++i) {
+    ns2_weight* w = ws[i];
+    ARGCHK(w, "ns2_weights_retile: null weight");
+    int r = NS2_OK;
+    if (w->w.t3) r = build_conv3_tiles(&w->owned, &w->w, s);
+    else if (w->w.tl) r = build_lin_tiles(&w->owned, &w->w, s);
+    else if (w->w.tw1) HIPRET(wavenet3_build_tiles(w->w.hi, w->w.rows_p, w->cols_p, 1, w->w.tw1, w->w.tw2, s));
+    if (r != NS2_OK) return r;
+  }
+  return NS2_OK;
+}
 extern "C" int ns2_weights_repack(const void* table_device, int n, int64_t total_blocks, void* stream) {
   ARGCHK(table_device && n > 0 && total_blocks > 0, "ns2_weights_repack: bad arguments");
   HIPRET(launch_repack(static_cast<const RepackDesc*>(table_device), n, (long)total_blocks, (hipStream_t)stream));

@@ -72,11 +72,15 @@ class _PackedCache:
     same iteration, 0.3700 against 0.3630; tests/test_round5_gpu.py::test_fused_optimizer_steps_reach_the_packed_weights).
     A frozen weight is re-packed only when its version moves."""
 
+    LEAN = False        # tile images of the lean mixed linear kernel for the training packs: measured 100.1 vs 98.8 ms per d512 / L12 step WITH them
+                        # (the per-pass re-tiling launches cost more than the eligible products gain; tools/exp_graphed_train.py --lean): off
+
     def __init__(self, precision=3):
         self.map = {}
         self.precision = precision
         self.pass_id = 0
         self._table = None          # (signature, device table, parts kept alive, n, total_blocks): every trainable pack, one launch per pass
+        self.lean = self.LEAN       # give mixed linear packs the tile images of the lean kernel (class attribute: the A/B of tools/exp_graphed_train.py)
 
     # ---- one launch per pass (ns2_weights_repack): possible once every entry has told where its values live (`parts`)
     @staticmethod
@@ -123,9 +127,12 @@ class _PackedCache:
             table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             total = ctypes.c_int64(0)
             check(lib.ns2_weights_repack_build(arr, len(parts), table.data_ptr(), nbytes, ctypes.byref(total), _s()), "ns2_weights_repack_build")
-            self._table = (sig, table, len(parts), total.value, keys)
-        _, table, n, total, _ = self._table
+            tiled = [self.map[k][0].handle.value for k in keys if getattr(self.map[k][0], "tiled", False)]
+            self._table = (sig, table, len(parts), total.value, keys, (ctypes.c_void_p * len(tiled))(*tiled) if tiled else None, len(tiled))
+        _, table, n, total, _, tiled, nt = self._table
         check(lib.ns2_weights_repack(table.data_ptr(), n, total, _s()), "ns2_weights_repack")
+        if nt:                                # the lean kernels' tile images follow their packs (one small launch per tiled weight)
+            check(lib.ns2_weights_retile(tiled, nt, _s()), "ns2_weights_retile")
         return True
 
     def begin_pass(self):
@@ -165,6 +172,9 @@ class _PackedCache:
             self.map[key] = (hit[0], sig, hit[2], (w, extra), refs, self.pass_id, parts)  # keep the sources alive until the stream has consumed them
             return hit[0]
         pw = ops.PackedWeight(w, extra1x1=extra, precision=self.precision, **pack_kw)
+        if self.precision == 4 and w.ndim == 2 and extra is None and not pack_kw.get("geglu") and w.shape[1] >= 96 and self.lean:
+            pw.tile_linear()                 # round 6: the lean mixed linear kernel (csrc/gemm3_kernel.h) for the forward and dgrad products
+            pw.tiled = True                  # on whole 256-row tiles -- bit-identical to gemm2_kernel<2, *>, 10-15 % faster
         self._table = None                   # (a hit whose source changed shape gets a NEW pack: the re-pack table still names the old one's storage)
         self.map[key] = (pw, sig, (tuple(w.shape), None if extra is None else tuple(extra.shape)), (w, extra), refs, self.pass_id, parts)
         return pw
@@ -461,8 +471,8 @@ class _Scale:
     def _peek():
         """the five range counters of the device (ns2_saturation_peek_async: forward GEMMs / attention / pointwise;
         ns2_saturation_peek_train_async: the training kernels), copied to pinned memory on the current stream -- no synchronisation"""
-        if not torch.cuda.is_available():
-            return None
+        if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+            return None                      # (under capture GraphedTrainStep peeks around the replay instead)
         try:
             lib = _lib.load()
         except Exception:
@@ -1056,3 +1066,86 @@ def unsupported_reason(m):
         if p.dtype != torch.float32:
             return f"parameter {name} is {p.dtype} (fp32 master weights are required)"
     return None
+
+
+# =============================================================================================== the step as one HIP graph
+class _LossOf(torch.nn.Module):
+    """`loss_fn` as the forward of a module that owns `root`: lets torch.func.functional_call run it on substitute parameters"""
+
+    def __init__(self, root, loss_fn):
+        super().__init__()
+        self.root, self.loss_fn = root, loss_fn
+
+    def forward(self, *inputs):
+        return self.loss_fn(*inputs)
+
+
+class GraphedTrainStep:
+    """`loss = loss_fn(*inputs); loss.backward()` of a FIXED shape captured once in a HIP graph and replayed per step.
+
+    Why: a d512 / L12 training pass enqueues ~2 000 launches from Python (the autograd Functions above are coarse, but each is a
+    dozen library calls); on a host whose cores are shared the enqueue, not the GPU, set the step time (98 ms vs 151 ms for the same
+    kernels, profiles/README.md), and at BASELINE config 1's size (d128 / L6, 4 x 1024) the GPU waits for Python: 20 ms eager, 12 ms
+    replayed.  Everything this file launches is capture-safe after a warm pass -- the weight packs are refreshed by ONE
+    `ns2_weights_repack` launch that reads the parameters' own storage (`_PackedCache._repack_all`), the loss scale of the mixed
+    arithmetic is chosen on the device (`_Scale.choose`), buffers come from PyTorch's allocator (its graph-private pool during
+    capture), random draws (conditioning dropout, times / noise when `loss_fn` draws them) go through PyTorch's graph-aware
+    generator -- so the replay runs the same kernels on the same operands: loss and gradients are bit-identical to the eager pass
+    (tests/test_round6_gpu.py::test_graphed_training_step).
+
+        step = GraphedTrainStep(lambda a, t, n: diffusion(a, times=t, noise=n), (audio, times, noise), model)
+        loss = step(audio, times, noise)          # .grad of every trainable parameter of `model` is now this batch's gradient
+        optimizer.step()                          # outside the graph (`zero_grad` between replays is unnecessary and harmless)
+
+    `module`: the nn.Module (or a list of them) whose trainable parameters `loss_fn` reaches.  During the warm passes and the capture
+    the module runs on SUBSTITUTE leaves over the same storage (torch.func.functional_call): a parameter's own AccumulateGrad node lives
+    on the stream it was created on -- the default stream whenever an eager pass's `loss` is still referenced -- and the autograd engine
+    would tie that stream into the capture (observed: a crash inside hipStreamEndCapture; tools/exp_graph_crash.py).  The gradients
+    come back from torch.autograd.grad as the graph's own tensors and are attached as `.grad` after every replay.
+
+    The parameters must be updated IN PLACE (every torch optimizer does); re-create the object after changing shapes, freezing /
+    unfreezing parameters or loading a state dict into NEW storage.  `overflowed()` is `_Scale.overflowed` for the replayed pass."""
+
+    def __init__(self, loss_fn, example_inputs, module, warmup=2):
+        root = module if isinstance(module, torch.nn.Module) else torch.nn.ModuleList(list(module))
+        named = [(k, p) for k, p in root.named_parameters() if p.requires_grad]
+        assert named, "GraphedTrainStep: no trainable parameter"
+        self.inputs = [t.detach().clone() for t in example_inputs]
+        assert self.inputs and self.inputs[0].is_cuda, "GraphedTrainStep captures a HIP graph: inputs live on the GPU"
+        self.params = [p for _, p in named]
+        self._subs = {"root." + k: p.detach().requires_grad_(True) for k, p in named}      # kept: the packs of the captured kernels hang on them
+        leaves = list(self._subs.values())
+        fn = _LossOf(root, loss_fn)
+        run = lambda: torch.func.functional_call(fn, self._subs, tuple(self.inputs))       # noqa: E731
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                     # warm passes: packs, tile images, split-K plans, function attributes all exist
+            for _ in range(max(2, warmup)):               # (two at least: the first packs the substitutes' weights, the second builds the
+                torch.autograd.grad(run(), leaves, allow_unused=True)      # one-launch repack table -- a synchronising build, not capturable)
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            loss = run()
+            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        self.loss = loss.detach()
+        self.grads = list(grads)                          # the graph's own tensors: every replay writes them, __call__ attaches them as .grad
+        self._before = None
+
+    def __call__(self, *inputs):
+        assert len(inputs) == len(self.inputs)
+        for s, t in zip(self.inputs, inputs):
+            if t is not s:
+                s.copy_(t)
+        self._before = _Scale._peek()
+        self.graph.replay()
+        for p, g in zip(self.params, self.grads):         # (whatever a zero_grad(set_to_none=True) or an eager pass in between left there)
+            p.grad = g
+        return self.loss
+
+    def overflowed(self) -> bool:
+        if self._before is None:
+            return False
+        after, ev = _Scale._peek()
+        ev.synchronize()
+        return bool((after != self._before[0]).any().item())

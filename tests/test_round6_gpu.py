@@ -311,6 +311,63 @@ def test_mixed_training_unscales_the_gradients_of_cond_and_prompt_and_reports_ov
         ops.saturation_count(reset=True)
 
 
+# ---------------------------------------------------------------------------------------------- the training pass as one HIP graph
+@pytest.mark.parametrize("tprec", ["exact", "mixed"])
+@pytest.mark.parametrize("conditioned", [False, True], ids=["uncond", "cond"])
+def test_graphed_training_step(tprec, conditioned):
+    """training.GraphedTrainStep: loss + backward of a fixed shape captured once, replayed per batch (NS2:1635 + NS2:1886 off the Python
+    launch path).  The replay must be the eager pass bit for bit -- loss and every parameter's .grad -- on the captured batch AND on a new
+    batch copied into the static inputs, after an in-place optimizer step in between (the one repack launch inside the graph reads the
+    parameters' own storage), with conditioning dropout drawn inside the graph."""
+    from naturalspeech2_pytorch_amd import NaturalSpeech2, training
+    kw = dict(dim=128, depth=2)
+    if conditioned:
+        kw.update(dim_prompt=96, condition_on_prompt=True, cond_drop_prob=0.)
+    m = Model(**kw)
+    m.load_state_dict(make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=71))
+    m = m.to(DEV).train()
+    m.train_backend, m.train_precision = "hip", tprec
+    d = NaturalSpeech2(m, codec=None, target_sample_hz=24000).to(DEV)
+    b, n = 2, 256
+    mk = lambda name, shape, seed, **k: make_input(name, shape, seed=seed, **k).to(DEV)    # noqa: E731
+    batch = lambda s: (mk("audio", (b, n, 128), s), mk("times", (b,), s, uniform=True), mk("noise", (b, n, 128), s + 1)) + (   # noqa: E731
+        (mk("prompt", (b, 37, 96), s), mk("cond", (b, 96, n), s)) if conditioned else ())
+
+    def loss_fn(a, t, z, *ex):
+        if ex:
+            return (m(a, t, prompt=ex[0], cond=ex[1]) - z).square().mean()
+        return d(a, times=t, noise=z)
+
+    def eager(ins):
+        for p in m.parameters():
+            p.grad = None
+        loss = loss_fn(*ins)
+        loss.backward()
+        return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+    try:
+        b0, b1 = batch(72), batch(74)
+        keep = loss_fn(*b0)                                          # an eager pass whose autograd graph stays referenced (a training loop's
+        keep.backward(retain_graph=True)                             # `loss` variable): its AccumulateGrad nodes live on the default stream
+        step = training.GraphedTrainStep(loss_fn, b0, m)
+        for ins in (b0, b1):
+            l_e, g_e = eager(ins)
+            for p in m.parameters():
+                p.grad = None                                        # (eager grads gone: the replay must write its own static ones)
+            l_g = step(*ins).detach().clone()
+            assert not step.overflowed()
+            got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+            assert torch.equal(l_g, l_e) and got.keys() == g_e.keys() and len(got) > 20
+            bad = [k for k in got if not torch.equal(got[k], g_e[k])]
+            assert not bad, bad[:5]
+            opt.step()                                               # in place: the next replay / eager pass multiplies the NEW weights
+        assert not torch.equal(eager(b0)[0], l_e)
+    finally:
+        m.train_precision = "exact"
+        ops.saturation_count(reset=True)
+
+
 # ---------------------------------------------------------------------------------------------- the lean Wavenet block kernel (wavenet3_kernel.h)
 @pytest.mark.parametrize("B,N,d,dil", [(4, 1024, 512, 1), (4, 1024, 512, 16), (2, 1024, 512, 128), (3, 256, 256, 2), (2, 512, 256, 64),
                                        (1, 768, 512, 32)])
