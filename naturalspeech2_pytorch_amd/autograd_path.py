@@ -1,9 +1,11 @@
-"""Differentiable PyTorch composite of `Model.forward`, used ONLY when autograd is required
-(`loss.backward()` in training, BASELINE config 1 / NS2:1635, NS2:1886).
+"""Differentiable PyTorch composite of `Model.forward`: fp32 torch ops on the module's own parameters.
 
-The HIP kernels of libns2hip are forward-only (backward kernels are SURVEY §8f item 4, "next"); inference
-(`torch.no_grad()` — `NaturalSpeech2.sample`, `forward_with_cond_scale` in the sampling loop, bench.py) never
-reaches this file.  It reads the module's own parameters so gradients flow to them.
+Since round 4 training has HIP kernels of its own (`training.py`: forward AND backward in libns2hip, `train_backend="hip"`, the
+default of this package's `Model` on an MI355X; NS2:1635, NS2:1886).  This composite is what is left for the cases those kernels do
+not take -- CPU tensors (the CPU test-suite), `train_backend="composite"`, a model `training.unsupported_reason` rejects (a head
+dimension other than 64 in the backward kernels, non-fp32 parameters) -- and the yardstick bench.py times beside the HIP training
+step (`side.train_step.*.pytorch_composite_ms_per_step`).  Inference (`torch.no_grad()` -- `NaturalSpeech2.sample`,
+`forward_with_cond_scale` in the sampling loop, bench.py's timed region) never reaches this file.
 """
 import math
 
