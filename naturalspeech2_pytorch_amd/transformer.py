@@ -43,8 +43,8 @@ class Transformer(nn.Module):
     def __init__(self, dim, *, depth, causal=False, dim_head=64, heads=8, use_flash=False, dropout=0., ff_mult=4,
                  final_norm=False, precision="exact"):
         super().__init__()
-        assert dim_head == 64, "the HIP attention kernel is specialised for dim_head 64 (the reference default)"
-        self.dim, self.depth, self.heads, self.causal, self.dropout = dim, depth, heads, causal, dropout
+        assert dim_head in (32, 64, 128), "the HIP attention kernel is built for head dims 32, 64 (the reference default) and 128"
+        self.dim, self.depth, self.heads, self.causal, self.dropout, self.dim_head = dim, depth, heads, causal, dropout, dim_head
         assert precision in _PRECISIONS, f"precision must be one of {sorted(_PRECISIONS)}"
         self.precision = precision
         self.layers = nn.ModuleList([
@@ -98,12 +98,12 @@ class Transformer(nn.Module):
             raise NotImplementedError("attention dropout is a training-time feature; the HIP path is inference-only")
         b, n, d = x.shape
         prec = _PRECISIONS[self.precision]
-        a = self.heads * 64
+        a = self.heads * self.dim_head
         h = x.reshape(b * n, d).float().contiguous()
         for pk in self._pack():
             xn = ops.rmsnorm(h, gamma=pk["g1"], precision=prec)
             qk, vt = ops.linear_qkv(pk["qkv"], xn, seq_len=n, split_col=2 * a, precision=prec)
-            o = ops.attention(qk, qk, vt, b, self.heads, n, n, q_col0=0, k_col0=a, precision=prec, key_mask=mask)
+            o = ops.attention(qk, qk, vt, b, self.heads, n, n, q_col0=0, k_col0=a, precision=prec, key_mask=mask, head_dim=self.dim_head)
             h = ops.linear_f32(pk["out"], o, resid=h, precision=prec)
             xn = ops.rmsnorm(h, gamma=pk["g2"], precision=prec)
             ffh = ops.linear_geglu(pk["w1"], xn, pk["b1"], precision=prec)

@@ -130,9 +130,9 @@ def gen_rvq():
         print(name, tuple(fix["indices"].shape), tuple(fix["emb"].shape))
 
 
-def gen_transformer(ns2):
+def gen_transformer(ns2, kw=None, name="transformer_d64.pt"):
     """plain Transformer (NS2:1073-1115) with a key-padding mask, as PhonemeEncoder / SpeechPromptEncoder use it."""
-    kw = dict(dim=64, depth=2, final_norm=True)
+    kw = kw or dict(dim=64, depth=2, final_norm=True)
     m = ns2.Transformer(**kw).eval()
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict(make_weights(shapes, seed=21))
@@ -144,8 +144,8 @@ def gen_transformer(ns2):
         y_nomask = m(x)
     torch.save(dict(kind="transformer", kwargs=kw, shapes=shapes, weight_seed=21, input_seed=22, lens=lens,
                     out_masked=y_mask, out_unmasked=y_nomask, torch_version=torch.__version__),
-               os.path.join(OUT, "transformer_d64.pt"))
-    print("transformer", tuple(y_mask.shape))
+               os.path.join(OUT, name))
+    print("transformer", name, tuple(y_mask.shape))
 
 
 def gen_encoders(ns2):
@@ -251,6 +251,8 @@ if __name__ == "__main__":
         gen_model_case(ns2, name, spec)
     gen_ddim(ns2)
     gen_transformer(ns2)
+    gen_transformer(ns2, dict(dim=64, depth=2, final_norm=True, dim_head=32, heads=4), "transformer_d64_hd32.pt")     # round 6: head dims 32 / 128
+    gen_transformer(ns2, dict(dim=64, depth=1, final_norm=False, dim_head=128, heads=2), "transformer_d64_hd128.pt")
     gen_encoders(ns2)
     for name, spec in GRAD_CASES.items():
         gen_grad_case(ns2, name, spec)

@@ -226,9 +226,10 @@ def test_training_path_autograd():
     assert torch.isfinite(loss) and getattr(m.transformer.to_pred, "1").weight.grad is not None
 
 
-def test_plain_transformer_matches_reference_golden():
-    """NS2:1073-1115 with and without the key-padding mask (the block of PhonemeEncoder / SpeechPromptEncoder)."""
-    fix = torch.load(os.path.join(GOLD, "transformer_d64.pt"), weights_only=False)
+@pytest.mark.parametrize("name", ["transformer_d64.pt", "transformer_d64_hd32.pt", "transformer_d64_hd128.pt"])
+def test_plain_transformer_matches_reference_golden(name):
+    """NS2:1073-1115 with and without the key-padding mask (the block of PhonemeEncoder / SpeechPromptEncoder); round 6: head dims 32 / 128"""
+    fix = torch.load(os.path.join(GOLD, name), weights_only=False)
     m = Transformer(**fix["kwargs"])
     own = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert own == {k: tuple(v) for k, v in fix["shapes"].items()}
