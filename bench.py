@@ -135,7 +135,7 @@ def train_step_side(dev):
                 w, loss = window(step, kw_)
                 wins.append(w)
                 done += kw_
-            dt = min(wins)
+            dt = sum(wins) / len(wins)                   # the mean of the windows (no best-of)
             for _ in range(iters - done):                # (untimed) so that every backend reports the loss of the SAME iteration
                 loss = step()
             res[name + "_windows"] = [round(1e3 * w, 2) for w in wins]
@@ -159,9 +159,10 @@ def train_step_side(dev):
                                              "operands under a power-of-two loss scale chosen on the device; attention bf16 x3; fp32 accumulate, fp32 master weights",
                                     "exact": "bf16 x3 split operands (3 MFMA units per algorithmic FLOP), fp32 accumulate, fp32 master weights"},
                         pytorch_composite_ms_per_step=round(1e3 * res["composite"][0], 2),
-                        speedup_vs_pytorch_composite=round(res["composite"][0] / res[best][0], 2),
+                        speedup_vs_pytorch_composite={"exact (same fp32-class arithmetic as the composite)": round(res["composite"][0] / res["exact"][0], 2),
+                                                      "mixed (gradients within 1e-3 of the reference's)": round(res["composite"][0] / res["mixed"][0], 2)},
                         loss_mixed=res["mixed"][1], loss_exact=res["exact"][1], loss_composite=res["composite"][1],
-                        loss_iteration=f"all after 2 warm-up + {iters} Adam steps from the same init", timing="the faster of two timed windows of steps",
+                        loss_iteration=f"all after 2 warm-up + {iters} Adam steps from the same init", timing="mean of the two timed windows of graph replays (timed_windows_ms); the composite: 2 steps",
                         parity="every parameter's .grad vs the reference's own autograd in both arithmetics: tests/test_backward_gpu.py, "
                                "tests/test_round5_gpu.py, profiles/r06_parity.json keys backward_vs_reference_autograd/*")
     return out

@@ -425,7 +425,9 @@ class HipBackend:
 
 
 _BACKEND = None            # a substitute installed by the tests (tests/emu_backend.py)
-_HIP = {}                  # precision -> HipBackend (each with its own packed-weight cache)
+_HIP = {}                  # (device index, precision) -> HipBackend, each with its own packed-weight cache and re-pack table (ADVICE r5:
+                           # models on two GPUs of one process must not share a device table)
+_CUR_DEV = None            # device index of the graph being built (None: the current device)
 _CUR_PREC = 3              # the arithmetic of the graph being BUILT (model_forward_train sets it around its Functions' forwards)
 _CUR_SCALE = None          # ... and its loss scale (None: exact arithmetic)
 TRAIN_PRECISIONS = {"exact": 3, "mixed": 4}
@@ -435,9 +437,11 @@ def backend():
     """the backend the Function whose forward is running should use (it keeps it in ctx for its backward)"""
     if _BACKEND is not None:
         return _BACKEND
-    if _CUR_PREC not in _HIP:
-        _HIP[_CUR_PREC] = HipBackend(_CUR_PREC)
-    return _HIP[_CUR_PREC]
+    dev = _CUR_DEV if _CUR_DEV is not None else (torch.cuda.current_device() if torch.cuda.is_available() else -1)
+    key = (dev, _CUR_PREC)
+    if key not in _HIP:
+        _HIP[key] = HipBackend(_CUR_PREC)
+    return _HIP[key]
 
 
 def set_backend(b):
@@ -944,11 +948,12 @@ def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None
     """`Model.forward` (NS2:929-1000) as a differentiable graph whose token-sized arithmetic is HIP (module docstring).
     `m` owns the reference's parameters (this package's `Model` or `compat.HipBackedModel`).  `m.train_precision`: "exact"
     (default: bf16 x3) or "mixed" (IEEE-half product + fp8 correction terms on FMT_H8 operands under a loss scale, `_Scale`)."""
-    global _CUR_PREC, _CUR_SCALE
+    global _CUR_PREC, _CUR_SCALE, _CUR_DEV
     tp = getattr(m, "train_precision", "exact")
     assert tp in TRAIN_PRECISIONS, f"train_precision must be one of {sorted(TRAIN_PRECISIONS)}"
-    prev = (_CUR_PREC, _CUR_SCALE)
+    prev = (_CUR_PREC, _CUR_SCALE, _CUR_DEV)
     _CUR_PREC = TRAIN_PRECISIONS[tp]
+    _CUR_DEV = x.device.index if x.is_cuda else None
     _CUR_SCALE = _Scale() if tp == "mixed" else None
     bk = backend()
     if hasattr(bk, "packs"):
@@ -960,7 +965,7 @@ def model_forward_train(m, x, times, prompt=None, cond=None, cond_drop_prob=None
             out = _ScaleIn.apply(out, _CUR_SCALE)
         return out
     finally:
-        _CUR_PREC, _CUR_SCALE = prev
+        _CUR_PREC, _CUR_SCALE, _CUR_DEV = prev
 
 
 def _forward_train(m, x, times, prompt, cond, cond_drop_prob):
