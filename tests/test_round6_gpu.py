@@ -241,6 +241,29 @@ def test_config3_conditioned_at_its_stated_size_4x1024_cfg():
     record("config3_stated_size_4x1024_prompt103_cfg1.3", errs)
 
 
+@pytest.mark.parametrize("precision,tol", [("exact", 5e-5), ("hybrid", 3e-4), ("half", 1e-3)])
+@pytest.mark.parametrize("dim_head,heads", [(32, 8), (128, 2)])
+def test_head_dims_32_and_128_on_whole_row_tiles(dim_head, heads, precision, tol):
+    """VERDICT r5 #5b beyond the golden sizes: dim 256, 2 x 512 frames, conditioned with guidance -- the shapes at which the executor takes the
+    256-row kernels (lean q | k | v with the LDS-transposed V^T, lean Wavenet block ...) -- with heads of 32 and of 128, against the oracle"""
+    from oracle import ns2_oracle as O
+    kw = dict(dim=256, depth=2, dim_head=dim_head, heads=heads, dim_prompt=64, condition_on_prompt=True, num_latents_m=16)
+    m = Model(**kw, precision=precision)
+    sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=81)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    b, n = 2, 512
+    x = make_input("x", (b, n, 256), seed=82)
+    t = make_input("times", (b,), seed=82, uniform=True)
+    prompt = make_input("prompt", (b, 45, 64), seed=83)
+    cond = make_input("cond", (b, 64, n), seed=84)
+    with torch.no_grad():
+        y = m.forward_with_cond_scale(x.to(DEV), t.to(DEV), prompt=prompt.to(DEV), cond=cond.to(DEV), cond_scale=1.4)
+        ref = O.model_forward_with_cond_scale(sd, x, t, prompt, cond, 1.4, dim_head=dim_head)
+    e = _rel(y.cpu(), ref)
+    assert torch.isfinite(y).all() and e < tol, (dim_head, precision, e)
+
+
 def test_config2_d128_at_its_stated_size_32x1024():
     """BASELINE config 2 as stated: Model(dim=128, depth=6) unconditional, batch 32 x 1024 latent tokens"""
     from oracle import ns2_oracle as O
