@@ -1109,7 +1109,9 @@ class GraphedTrainStep:
     come back from torch.autograd.grad as the graph's own tensors and are attached as `.grad` after every replay.
 
     The parameters must be updated IN PLACE (every torch optimizer does); re-create the object after changing shapes, freezing /
-    unfreezing parameters or loading a state dict into NEW storage.  `overflowed()` is `_Scale.overflowed` for the replayed pass."""
+    unfreezing parameters or loading a state dict into NEW storage.  `overflowed()` is `_Scale.overflowed` for the replayed pass.
+    Tensor hooks on the parameters do not run during a replay (`distributed.GradientAllReducer` overlaps its all-reduces with an EAGER
+    backward through such hooks): a data-parallel loop on the graph all-reduces `step.grads` after the call instead."""
 
     def __init__(self, loss_fn, example_inputs, module, warmup=2):
         root = module if isinstance(module, torch.nn.Module) else torch.nn.ModuleList(list(module))
