@@ -289,6 +289,58 @@ def test_hybrid_plan_with_amplified_ff_branch():
     assert out["mixed"] < 2.5e-4 and out["hybrid"] < 5e-4 and out["half"] < 2e-3, out
 
 
+def test_precision_plans_with_outlier_channels_and_heavy_tails():
+    """the tolerance had only been shown on random-init weights.  No trained checkpoint can be had here (no network), so the
+    statistics trained transformers are known for are imposed on the headline architecture instead: (a) OUTLIER CHANNELS -- in every weight matrix
+    four input columns x16 and four output rows x8 (residual-stream channels two orders of magnitude above the rest, the case that breaks narrow
+    formats); (b) HEAVY TAILS -- every weight multiplied elementwise by exp(0.8 z), z ~ N(0, 1) (kurtosis ~ 30).  d512 / L12, 2 x 1024 frames,
+    every plan against the fp32 oracle (GPU-resident, pinned to the CPU oracle on one utterance).  Recorded; asserted: exact / mixed / hybrid stay
+    inside the 1e-3 tolerance, half is printed (it is the plan without correction terms)."""
+    kw = dict(dim=512, depth=12)
+    b, n = 2, 1024
+    x = make_input("x", (b, n, 512), seed=141)
+    t = torch.tensor([0.3, 0.9])
+    base = make_weights({k: tuple(v.shape) for k, v in Model(**kw).state_dict().items()}, seed=140)
+    g = torch.Generator().manual_seed(142)
+
+    def outliers(sd):
+        out = {}
+        for k, v in sd.items():
+            v = v.clone()
+            if v.ndim >= 2 and min(v.shape[0], v.shape[1]) >= 64:
+                cols = torch.randperm(v.shape[1], generator=g)[:4]
+                rows = torch.randperm(v.shape[0], generator=g)[:4]
+                v[:, cols] *= 16.0
+                v[rows] *= 8.0
+            out[k] = v
+        return out
+
+    def heavy(sd):
+        return {k: (v * torch.exp(0.8 * torch.randn(v.shape, generator=g)) if v.ndim >= 2 else v.clone()) for k, v in sd.items()}
+
+    res = {}
+    for name, make in (("outlier_channels", outliers), ("heavy_tails", heavy)):
+        sd = make(base)
+        sdg = {k: v.to(DEV) for k, v in sd.items()}
+        with torch.no_grad():
+            ref = O.model_forward(sdg, x.to(DEV), t.to(DEV))
+            pin = rel(ref[:1], O.model_forward(sd, x[:1], t[:1]))
+        assert pin < 5e-6 and torch.isfinite(ref).all(), pin
+        res[name] = {"oracle_output_rms": float(ref.pow(2).mean().sqrt())}
+        for precision in ("exact", "mixed", "hybrid", "half"):
+            m = Model(**kw, precision=precision)
+            m.load_state_dict(sd)
+            m = m.to(DEV).eval()
+            with torch.no_grad():
+                y = m(x.to(DEV), t.to(DEV))
+            m.check_saturation(sync=True)
+            res[name][precision] = rel(y, ref)
+            del m
+        print(name, {k: f"{v:.2e}" for k, v in res[name].items()})
+        assert res[name]["exact"] < 1e-4 and res[name]["mixed"] < 1e-3 and res[name]["hybrid"] < 1e-3, res[name]
+    record("stress_d512_L12_b2x1024", res)
+
+
 def test_half_conversion_saturates():
     x = torch.tensor([[1e6, -1e6, 65504.0, 7e4] + [0.0] * 28], device=DEV)
     h = ops.join(ops.split(x, precision=2))[0, :4].tolist()
