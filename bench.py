@@ -436,6 +436,8 @@ def main():
         parity["sweep_d512_L12"] = {k.split("/")[-1]: dict(max=v["max"], mean=v["mean"]) for k, v in sw.items()
                                     if k.startswith("sweep_d512_L12/")}
         parity["sweep_source"] = f"profiles/{PARITY_RECORD} (tests/test_parity_r2_gpu.py: 8 weight seeds x times {{0.002, 0.5, 0.999}})"
+        if "stress_d512_L12_b2x1024" in sw:              # the same architecture with outlier channels / heavy-tailed weights (committed record)
+            parity["stress_d512_L12_b2x1024"] = dict(sw["stress_d512_L12_b2x1024"], source="tests/test_parity_r2_gpu.py::test_precision_plans_with_outlier_channels_and_heavy_tails")
         if not args.no_secondary and not args.conditioned:
             k2 = min(args.steps, 10)
             for other in ("hybrid_ff", "mixed", "half", "exact"):
