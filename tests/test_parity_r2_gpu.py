@@ -45,6 +45,23 @@ def rel_rows(a, b):
     return ((a - b).norm(dim=1) / b.norm(dim=1)).tolist()
 
 
+def gpu_oracle_ddim(sd, noise, steps, **kw):
+    """the oracle's sampling loop (oracle/ns2_oracle.py: plain PyTorch fp32 ops) on GPU tensors -- the CPU loop of a 30-50 step trajectory was
+    half a minute of a shared host per test -- pinned to the CPU oracle on one forward of the first utterance (< 5e-6)"""
+    sdg = {k: v.to(DEV) for k, v in sd.items()}
+    dev = lambda v: v.to(DEV) if torch.is_tensor(v) else v      # noqa: E731
+    with torch.no_grad():
+        t1 = torch.full((1,), 0.5)
+        fkw = {k: v[:1] for k, v in kw.items() if torch.is_tensor(v)}
+        if fkw:
+            pin = rel(O.model_forward_with_cond_scale(sdg, noise[:1].to(DEV), t1.to(DEV), fkw.get("prompt").to(DEV), fkw.get("cond").to(DEV), kw.get("cond_scale", 1.0)),
+                      O.model_forward_with_cond_scale(sd, noise[:1], t1, fkw.get("prompt"), fkw.get("cond"), kw.get("cond_scale", 1.0)))
+        else:
+            pin = rel(O.model_forward(sdg, noise[:1].to(DEV), t1.to(DEV)), O.model_forward(sd, noise[:1], t1))
+        assert pin < 5e-6, f"GPU-resident oracle drifted from the CPU oracle: {pin}"
+        return O.ddim_sample(sdg, noise.to(DEV), steps, **{k: dev(v) for k, v in kw.items()})
+
+
 def build(kw, seed=1, precision="exact", scale_weights=1.0):
     m = Model(**kw, precision=precision)
     own = {k: tuple(v.shape) for k, v in m.state_dict().items()}
@@ -163,8 +180,7 @@ def test_ddim_trajectory_50_steps():
         d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=50)
         y = d.sample(length=256, batch_size=2, noise=noise)
         if ref is None:
-            with torch.no_grad():
-                ref = O.ddim_sample(sd, noise, 50)
+            ref = gpu_oracle_ddim(sd, noise, 50)
         assert torch.isfinite(y).all()
         out[precision] = rel(y, ref)
     record("ddim_50_steps_d128_L6", out)
@@ -176,18 +192,17 @@ def test_ddim_trajectory_headline_architecture():
     """10 DDIM steps at the headline architecture (d512/L12, one utterance of 512 frames) in the benched plan and its neighbours"""
     kw = dict(dim=512, depth=12)
     noise = make_input("noise", (1, 512, 512), seed=38)
-    out, ref = {}, None
+    out = {}
+    m, sd = build(kw, seed=37, precision="hybrid")             # one model object, three arithmetics (the packs are per precision)
+    ref = gpu_oracle_ddim(sd, noise, 10)
+    d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=10)
     for precision in ("hybrid", "mixed", "half"):
-        m, sd = build(kw, seed=37, precision=precision)
-        d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=10)
+        m.precision = precision
         y = d.sample(length=512, batch_size=1, noise=noise)
-        if ref is None:
-            with torch.no_grad():
-                ref = O.ddim_sample(sd, noise, 10)
         assert torch.isfinite(y).all()
         out[precision] = rel(y, ref)
-        del m, d
-        torch.cuda.empty_cache()
+    del m, d
+    torch.cuda.empty_cache()
     record("ddim_10_steps_d512_L12", out)
     print("10-step DDIM trajectory at d512/L12 rel err:", {k: f"{v:.2e}" for k, v in out.items()})
     assert out["hybrid"] < CEIL["hybrid"] and out["mixed"] < CEIL["mixed"] and out["half"] < 2e-3, out
@@ -207,8 +222,7 @@ def test_conditioned_ddim_trajectory_with_cfg():
         d = NaturalSpeech2(m, codec=None, target_sample_hz=24000, timesteps=30).to(DEV).eval()
         y = d.sample(length=256, prompt_enc=p_enc.to(DEV), cond=cond.to(DEV), cond_scale=1.3, noise=noise)
         if ref is None:
-            with torch.no_grad():
-                ref = O.ddim_sample(sd, noise, 30, prompt=p_enc, cond=cond, cond_scale=1.3)
+            ref = gpu_oracle_ddim(sd, noise, 30, prompt=p_enc, cond=cond, cond_scale=1.3)
         assert torch.isfinite(y).all()
         out[precision] = rel(y, ref)
     record("ddim_30_steps_conditioned_cfg_d128_L6", out)
@@ -224,11 +238,13 @@ def test_large_activation_stress():
     t = torch.tensor([0.3, 0.9])
     out = {}
     for scale in (2.0, 8.0):
+        ref = None
         for precision in ("exact", "mixed", "hybrid", "half"):
             m, sd = build(kw, seed=40, precision=precision, scale_weights=scale)
             with torch.no_grad():
                 y = m(x.to(DEV), t.to(DEV))
-                ref = O.model_forward(sd, x, t)
+                if ref is None:
+                    ref = O.model_forward(sd, x, t)          # (the weights depend on the scale only)
             assert torch.isfinite(y).all(), f"{precision} x{scale}: non-finite output"
             out[f"x{scale:g}/{precision}"] = rel(y, ref)
     record("large_activation_stress_d128_L6", out)
