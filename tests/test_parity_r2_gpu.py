@@ -343,15 +343,16 @@ def test_precision_plans_with_outlier_channels_and_heavy_tails():
             pin = rel(ref[:1], O.model_forward(sd, x[:1], t[:1]))
         assert pin < 5e-6 and torch.isfinite(ref).all(), pin
         res[name] = {"oracle_output_rms": float(ref.pow(2).mean().sqrt())}
+        m = Model(**kw, precision="exact")                 # one model object per weight set, four arithmetics (the packs are per precision)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
         for precision in ("exact", "mixed", "hybrid", "half"):
-            m = Model(**kw, precision=precision)
-            m.load_state_dict(sd)
-            m = m.to(DEV).eval()
+            m.precision = precision
             with torch.no_grad():
                 y = m(x.to(DEV), t.to(DEV))
             m.check_saturation(sync=True)
             res[name][precision] = rel(y, ref)
-            del m
+        del m
         print(name, {k: f"{v:.2e}" for k, v in res[name].items()})
         assert res[name]["exact"] < 1e-4 and res[name]["mixed"] < 1e-3 and res[name]["hybrid"] < 1e-3, res[name]
     record("stress_d512_L12_b2x1024", res)
