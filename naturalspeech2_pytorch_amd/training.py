@@ -137,6 +137,10 @@ class _PackedCache:
 
     def begin_pass(self):
         self.pass_id += 1
+        if _WEIGHTS_FROZEN:                  # `with training.weights_unchanged():` -- the packs of the last pass are these weights' (stamp them fresh)
+            for k, v in list(self.map.items()):
+                self.map[k] = (v[0], v[1], v[2], v[3], v[4], self.pass_id, v[6])
+            return
         if self.pass_id > 1 and self._repack_all():
             for k in self._table[4]:                                         # what the launch re-packed is fresh for this pass
                 v = self.map[k]                                              # (a frozen weight is not in the table: its version rule stands)
@@ -442,6 +446,25 @@ def backend():
     if key not in _HIP:
         _HIP[key] = HipBackend(_CUR_PREC)
     return _HIP[key]
+
+
+_WEIGHTS_FROZEN = False
+
+
+class weights_unchanged:
+    """`with training.weights_unchanged():` around training passes that follow another pass WITHOUT an optimizer step in between -- the later
+    micro-batches of gradient accumulation (NS2:1877-1885), several losses on one set of weights: the per-pass refresh of every packed weight
+    (one launch reading all parameters: 1.3 ms at d512 / L12; needed by default because fused optimizers change parameters without bumping the
+    version counters a cache could key on) is skipped and the packs of the previous pass are used as they are (ADVICE r5).  The caller's promise;
+    weights changed inside the block the way a fused optimizer changes them (no version bump) are NOT seen until the first pass outside it."""
+
+    def __enter__(self):
+        global _WEIGHTS_FROZEN
+        self.prev, _WEIGHTS_FROZEN = _WEIGHTS_FROZEN, True
+
+    def __exit__(self, *exc):
+        global _WEIGHTS_FROZEN
+        _WEIGHTS_FROZEN = self.prev
 
 
 def set_backend(b):

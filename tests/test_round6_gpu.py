@@ -391,6 +391,38 @@ def test_graphed_training_step(tprec, conditioned):
         ops.saturation_count(reset=True)
 
 
+def test_weights_unchanged_skips_the_refresh_of_the_packs():
+    """gradient accumulation runs several passes per optimizer step; `training.weights_unchanged()` skips the per-pass refresh
+    of the packed weights.  Same loss and gradients as an ordinary pass; a weight changed INSIDE the block is (by contract) not seen until the
+    first pass outside it (changes that bump the version counter are seen at once, as always)."""
+    from naturalspeech2_pytorch_amd import training
+    m = Model(dim=128, depth=1)
+    m.load_state_dict(make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=95))
+    m = m.to(DEV).train()
+    m.train_backend = "hip"
+    x = make_input("x", (2, 256, 128), seed=96).to(DEV)
+    t = make_input("times", (2,), seed=96, uniform=True).to(DEV)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        y = m(x, t)
+        y.square().mean().backward()
+        return y.detach().clone(), m.wavenet.init_conv.weight.grad.clone()
+
+    y0, g0 = run()
+    with training.weights_unchanged():
+        y1, g1 = run()
+        assert torch.equal(y1, y0) and torch.equal(g1, g0)
+        with torch.no_grad():
+            getattr(m.transformer.to_pred, "1").weight.data.mul_(2.0)     # the last Linear (NS2:783): the output doubles.  Through `.data`: no
+            #                                                                version bump, like a fused optimizer (an ordinary in-place op IS seen)
+        y2, _ = run()
+        assert torch.equal(y2, y0)                                   # stale by contract
+    y3, _ = run()
+    assert _rel(y3, 2.0 * y0) < 1e-5                                 # outside: the packs follow the weights again
+
+
 # ---------------------------------------------------------------------------------------------- the lean Wavenet block kernel (wavenet3_kernel.h)
 @pytest.mark.parametrize("B,N,d,dil", [(4, 1024, 512, 1), (4, 1024, 512, 16), (2, 1024, 512, 128), (3, 256, 256, 2), (2, 512, 256, 64),
                                        (1, 768, 512, 32)])
