@@ -5,6 +5,7 @@ drawn from a CPU torch.Generator per key so that the same tensors can be rebuilt
 loaded into both the reference `Model` (in make_golden.py) and the HIP `Model`.
 """
 import math
+import os
 import zlib
 
 import torch
@@ -16,14 +17,30 @@ def _gen(seed, key):
     return g
 
 
+def _numel(shp):
+    n = 1
+    for d in shp:
+        n *= d
+    return n
+
+
 def make_weights(shapes: dict, seed: int = 0) -> dict:
     """shapes: {state_dict key: shape}. Linear/conv weights ~ N(0, 1/fan_in); biases ~ 0.1 N(0,1);
     gammas ~ 1 + 0.1 N; sinusoid freqs ~ N(0,1); latents / null tokens ~ 0.3 N."""
+    # every key draws from its own generator, so the keys can be drawn in parallel (torch.randn releases the GIL): the 100 M weights of the
+    # headline model took 5-6 s of one core per test that builds it
+    keys = sorted(shapes)
+    big = [k for k in keys if _numel(shapes[k]) >= (1 << 16)]
+    drawn = {}
+    if len(big) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+            for k, r in zip(big, ex.map(lambda kk: torch.randn(tuple(shapes[kk]), generator=_gen(seed, kk)), big)):
+                drawn[k] = r
     sd = {}
-    for k in sorted(shapes):
+    for k in keys:
         shp = tuple(shapes[k])
-        g = _gen(seed, k)
-        r = torch.randn(shp, generator=g)
+        r = drawn.pop(k) if k in drawn else torch.randn(shp, generator=_gen(seed, k))
         if k.endswith("gamma"):
             w = 1.0 + 0.1 * r
         elif k.endswith("bias"):

@@ -241,6 +241,9 @@ def test_config3_conditioned_at_its_stated_size_4x1024_cfg():
     record("config3_stated_size_4x1024_prompt103_cfg1.3", errs)
 
 
+_HD_REF = {}
+
+
 @pytest.mark.parametrize("precision,tol", [("exact", 5e-5), ("hybrid", 3e-4), ("half", 1e-3)])
 @pytest.mark.parametrize("dim_head,heads", [(32, 8), (128, 2)])
 def test_head_dims_32_and_128_on_whole_row_tiles(dim_head, heads, precision, tol):
@@ -259,7 +262,9 @@ def test_head_dims_32_and_128_on_whole_row_tiles(dim_head, heads, precision, tol
     cond = make_input("cond", (b, 64, n), seed=84)
     with torch.no_grad():
         y = m.forward_with_cond_scale(x.to(DEV), t.to(DEV), prompt=prompt.to(DEV), cond=cond.to(DEV), cond_scale=1.4)
-        ref = O.model_forward_with_cond_scale(sd, x, t, prompt, cond, 1.4, dim_head=dim_head)
+        if dim_head not in _HD_REF:                                   # (one CPU-oracle run per head dim serves the three plans)
+            _HD_REF[dim_head] = O.model_forward_with_cond_scale(sd, x, t, prompt, cond, 1.4, dim_head=dim_head)
+        ref = _HD_REF[dim_head]
     e = _rel(y.cpu(), ref)
     assert torch.isfinite(y).all() and e < tol, (dim_head, precision, e)
 
