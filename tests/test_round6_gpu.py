@@ -396,6 +396,46 @@ def test_graphed_training_step(tprec, conditioned):
         ops.saturation_count(reset=True)
 
 
+def test_retile_keeps_the_lean_kernels_images_current_under_the_one_launch_refresh():
+    """`ns2_weights_retile` (include/ns2hip.h): packs that carry the lean mixed linear kernel's tile images can be part of the training path's
+    one-launch refresh.  Off by default (`_PackedCache.LEAN`: measured slower, profiles/r06_training_graph_ab.txt); here it is switched on:
+    mixed-arithmetic losses and gradients over three optimizer steps must equal the default path's bit for bit -- the lean kernel is
+    bit-identical to gemm2_kernel<2, *>, so any difference is a stale image."""
+    from naturalspeech2_pytorch_amd import training
+
+    def run(lean):
+        training._PackedCache.LEAN = lean
+        training._HIP.clear()                                        # fresh backends: the flag is read when a cache is created
+        m = Model(dim=256, depth=1)
+        m.load_state_dict(make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=97))
+        m = m.to(DEV).train()
+        m.train_backend, m.train_precision = "hip", "mixed"
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)   # fused: no version bumps -- only the per-pass refresh sees the steps
+        x = make_input("x", (2, 512, 256), seed=98).to(DEV)
+        t = make_input("times", (2,), seed=98, uniform=True).to(DEV)
+        out = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = m(x, t).square().mean()
+            loss.backward()
+            out.append((loss.detach().clone(), m.wavenet.init_conv.weight.grad.clone(), getattr(m.transformer.to_pred, "1").weight.grad.clone()))
+            opt.step()
+        tiled = sum(1 for bk in training._HIP.values() for v in bk.packs.map.values() if getattr(v[0], "tiled", False))
+        return out, tiled
+
+    try:
+        ref, n0 = run(False)
+        got, n1 = run(True)
+        assert n0 == 0 and n1 > 4, (n0, n1)
+        for (l0, a0, b0), (l1, a1, b1) in zip(ref, got):
+            assert torch.equal(l0, l1) and torch.equal(a0, a1) and torch.equal(b0, b1)
+        assert not torch.equal(ref[0][0], ref[2][0])                  # the steps did change the weights
+    finally:
+        training._PackedCache.LEAN = False
+        training._HIP.clear()
+        ops.saturation_count(reset=True)
+
+
 def test_weights_unchanged_skips_the_refresh_of_the_packs():
     """gradient accumulation runs several passes per optimizer step; `training.weights_unchanged()` skips the per-pass refresh
     of the packed weights.  Same loss and gradients as an ordinary pass; a weight changed INSIDE the block is (by contract) not seen until the
