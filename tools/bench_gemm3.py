@@ -28,10 +28,11 @@ cases = {
     "outproj+res [M,512]x[512,512]": (lambda: ops.linear_f32(wo, x512, resid=r, precision=4), 2.0 * M * d * d),
 }
 force = lambda k: _lib.check(_lib.load().ns2_debug_force_gemm(k))
-res = {(n, k): [] for n in cases for k in (5, 2)}
+KS = (5, 2, 1)
+res = {(n, k): [] for n in cases for k in KS}
 for rd in range(args.rounds):
     for n, (fn, fl) in cases.items():
-        for k in (5, 2):
+        for k in KS:
             force(k)
             for _ in range(3):
                 fn()
@@ -44,5 +45,5 @@ for rd in range(args.rounds):
             res[(n, k)].append(e0.elapsed_time(e1) / args.iters)
 force(0)
 for n, (fn, fl) in cases.items():
-    t = {k: sorted(res[(n, k)])[len(res[(n, k)]) // 2] for k in (5, 2)}
-    print(f"{n:34s} gemm3 {t[5]*1e3:7.1f} us ({fl/t[5]/1e9:6.1f} TF)   gemm2 {t[2]*1e3:7.1f} us ({fl/t[2]/1e9:6.1f} TF)   ratio {t[2]/t[5]:.3f}")
+    t = {k: sorted(res[(n, k)])[len(res[(n, k)]) // 2] for k in KS}
+    print(f"{n:34s} gemm3 {t[5]*1e3:7.1f} us ({fl/t[5]/1e9:6.1f} TF)   gemm2 {t[2]*1e3:7.1f} us ({fl/t[2]/1e9:6.1f} TF)   ratio {t[2]/t[5]:.3f}   128x128 kernel {t[1]*1e3:7.1f} us")
