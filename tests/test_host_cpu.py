@@ -80,6 +80,44 @@ def test_state_dict_contract_matches_reference(path):
     assert own == ref                                    # same keys, same order, same shapes as the reference Model
 
 
+def test_header_is_plain_c_and_a_c_caller_links_against_the_library(tmp_path):
+    """the drop-in boundary is a C ABI (extern "C", plain pointers and sizes, no torch types): include/ns2hip.h must compile as C99 with gcc, and
+    a C program that takes the address of entry points of every section (and calls the ones that need no GPU) must link against libns2hip.so
+    and run -- the binding a maintainer of another host language would write."""
+    import shutil
+    import subprocess
+    from naturalspeech2_pytorch_amd import _lib
+    if shutil.which("gcc") is None or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("needs gcc and the built library")
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdint.h>
+#include "ns2hip.h"
+int main(void) {
+  /* addresses of entry points from every section of the header: unresolved symbols fail the link */
+  typedef void (*fn_t)(void);
+  fn_t fns[] = {(fn_t)ns2_weight_pack, (fn_t)ns2_linear_f32, (fn_t)ns2_linear_qkv, (fn_t)ns2_attention,
+                       (fn_t)ns2_attention_hd, (fn_t)ns2_rmsnorm, (fn_t)ns2_rvq_encode, (fn_t)ns2_model_create,
+                       (fn_t)ns2_model_forward, (fn_t)ns2_ddim_step, (fn_t)ns2_weights_repack, (fn_t)ns2_weights_retile,
+                       (fn_t)ns2_attention_bwd, (fn_t)ns2_weight_tile_linear, (fn_t)ns2_model_cond_stack};
+  int n = 0;
+  for (unsigned i = 0; i < sizeof fns / sizeof fns[0]; ++i) n += fns[i] != 0;
+  ns2_model_config cfg;                       /* the config struct is plain ints */
+  cfg.dim = 64; cfg.depth = 1; cfg.dim_head = 48; cfg.heads = 2;
+  printf("%d %d %d %d\n", n, ns2_version(), ns2_conv3_input_ld(1365), (int)sizeof(cfg) % (int)sizeof(int));
+  return ns2_debug_force_gemm(99) == 0;       /* argument errors come back as codes, nothing throws across the ABI */
+}
+''')
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, "-fsyntax-only", str(src)], check=True)
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lns2hip", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=120).stdout.split()
+    assert out[0] == "15" and int(out[1]) >= 115 and int(out[2]) == 1408 and out[3] == "0", out
+
+
 def test_transformer_state_dict_contract():
     from naturalspeech2_pytorch_amd import Transformer
     fix = torch.load(os.path.join(GOLD, "transformer_d64.pt"), weights_only=False)
