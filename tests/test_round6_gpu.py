@@ -269,6 +269,28 @@ def test_head_dims_32_and_128_on_whole_row_tiles(dim_head, heads, precision, tol
     assert torch.isfinite(y).all() and e < tol, (dim_head, precision, e)
 
 
+def test_long_utterances_4096_frames():
+    """the reference takes any length (NS2:929-1000); everything benched is 1024 frames.  4096 frames (16 row tiles per utterance for the lean
+    kernels, 64 key tiles in attention, dilation 128 reaching across row tiles): exact and hybrid against the oracle's code on GPU tensors
+    (plain PyTorch fp32 ops; the exact plan agreeing with it to 1.2e-5 is the cross-check of both)"""
+    from oracle import ns2_oracle as O
+    kw = dict(dim=512, depth=2)
+    m = Model(**kw, precision="exact")
+    sd = make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=5)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = make_input("x", (2, 4096, 512), seed=6).to(DEV)
+    t = make_input("times", (2,), seed=6, uniform=True).to(DEV)
+    with torch.no_grad():
+        ref = O.model_forward({k: v.to(DEV) for k, v in sd.items()}, x, t)
+        errs = {}
+        for precision, tol in (("exact", 3e-5), ("hybrid", 2.5e-4)):
+            m.precision = precision
+            y = m(x, t)
+            errs[precision] = _rel(y, ref)
+            assert torch.isfinite(y).all() and errs[precision] < tol, errs
+
+
 def test_config2_d128_at_its_stated_size_32x1024():
     """BASELINE config 2 as stated: Model(dim=128, depth=6) unconditional, batch 32 x 1024 latent tokens"""
     from oracle import ns2_oracle as O
